@@ -1,0 +1,185 @@
+"""Model configuration and the integer index arithmetic of the hot path.
+
+Mirrors the config surface of the reference (keys of model_configs/modaltune_gigapath_config.json:1-30
+plus model_configs/other_configs.py:10-24) without importing it.  Everything here is host-side,
+torch-free integer/shape logic shared by the HIP engine, the oracle and the tests.
+"""
+from __future__ import annotations
+
+import dataclasses
+import json
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+# LongNet architecture table for the names LongNetViT builds ("LongNet_{depth}_layers_{dim}_dim",
+# reference slide_encoder.py:122, torchscale/model/LongNetConfig.py:121-179): all 768-d variants use
+# 16 heads, ffn 3072, dilated ratios [1,2,4,8,16].
+BACKBONE_HEADS = 16
+DILATED_RATIOS = (1, 2, 4, 8, 16)
+LN_EPS = 1e-5  # torchscale EncoderConfig.layernorm_eps (architecture/config.py:43); nn.LayerNorm default too
+
+
+@dataclasses.dataclass
+class GeneConfig:
+    """model_configs/other_configs.py:12-21 ("gene_mixer_group")."""
+    latent_dim: int = 256
+    depth: int = 3
+    expansion_groups: float = 0.5
+    expansion_dim: float = 0.5
+    final_groups: int = 64
+
+
+@dataclasses.dataclass
+class ModelConfig:
+    """Keys of model_configs/modaltune_gigapath_config.json (same names, same defaults)."""
+    in_chans: int = 1536
+    embed_dim: int = 768
+    depth: int = 12
+    slide_ngrids: int = 1000
+    tile_size: int = 256
+    max_wsi_size: int = 262144
+    global_pool: bool = False
+    dropout: float = 0.25
+    drop_path_rate: float = 0.1
+    mlp_ratio: float = 4
+    num_heads: int = 12
+    output_dim: int = 256
+    init_values: float = 0.0
+    geneclass_name: str = "gene_mixer_group"
+    interaction_indexes: Sequence[Sequence[int]] = ((0, 3), (4, 7), (8, 11))
+    with_cffn: bool = True
+    cffn_ratio: float = 0.25
+    add_prompt_feature: bool = True
+    use_extra_extractor: bool = True
+    freeze_vit: bool = True
+    with_cp: bool = False
+    use_prompt_sa: bool = True
+    prompt_dropout: float = 0.0
+    prompt_agg: str = "avg"
+    token_agg: str = "sum"
+    pretrained: bool = True
+    clinfeat_dim: int = 5
+    multi_task: int = 3
+    gene: GeneConfig = dataclasses.field(default_factory=GeneConfig)
+
+    # ---- derived ----
+    @property
+    def adapter_dim(self) -> int:          # E = int(768 * 0.25) (adapter_modules.py:153)
+        return int(self.embed_dim * self.cffn_ratio)
+
+    @property
+    def ffn_dim(self) -> int:
+        return int(self.embed_dim * self.mlp_ratio)
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // BACKBONE_HEADS
+
+    @property
+    def is_multi(self) -> bool:            # longvit_adapter.py:88
+        return self.multi_task > 1
+
+    @property
+    def num_tokens(self) -> int:           # T = final_groups + task token (longvit_adapter.py:152-154)
+        return self.gene.final_groups + int(self.is_multi)
+
+    def validate(self):
+        if self.embed_dim != 768 or self.head_dim != 48:
+            raise ValueError("the HIP path is built for the Prov-GigaPath geometry (768-d, 16 heads x 48)")
+        if self.prompt_agg != "avg" or self.token_agg not in ("sum", "cat"):
+            raise NotImplementedError("prompt_agg must be 'avg'; token_agg 'sum' or 'cat'")
+        if not (self.with_cffn and self.use_prompt_sa and self.add_prompt_feature and self.freeze_vit):
+            raise NotImplementedError("only the shipped ModalTune configuration family is supported")
+        if self.interaction_indexes[0][0] != 0:
+            raise NotImplementedError("interaction_indexes must start at layer 0 (both shipped configs do)")
+        last = -1
+        for a, b in self.interaction_indexes:
+            if a != last + 1 or b < a:
+                raise ValueError("interaction_indexes must tile the layers contiguously")
+            last = b
+        if last != self.depth - 1:
+            raise ValueError("interaction_indexes must cover all layers")
+
+    @staticmethod
+    def from_json(path_or_dict, **overrides) -> "ModelConfig":
+        d = dict(path_or_dict) if isinstance(path_or_dict, dict) else json.load(open(path_or_dict))
+        d.update(overrides)
+        names = {f.name for f in dataclasses.fields(ModelConfig)}
+        kw = {k: v for k, v in d.items() if k in names and k != "gene"}
+        if "interaction_indexes" in kw:
+            kw["interaction_indexes"] = tuple(tuple(int(i) for i in p) for p in kw["interaction_indexes"])
+        cfg = ModelConfig(**kw)
+        if isinstance(d.get("gene"), dict):
+            cfg.gene = GeneConfig(**d["gene"])
+        return cfg
+
+
+def segment_lengths(max_wsi_size: int = 262144, tile_size: int = 256) -> List[int]:
+    """LongNetViT.get_optimal_segment_length (reference slide_encoder.py:163-182).
+
+    Five log-spaced lengths from 1024 to (max_wsi_size/tile_size)^2, truncated to int exactly like
+    the reference (np.power(2, linspace).astype(int)) -> [1024, 5792, 32768, 185363, 1048576].
+    """
+    max_seq_len = (max_wsi_size // tile_size) ** 2
+    e = np.linspace(np.log2(1024), int(np.log2(max_seq_len)), 5)
+    return [int(v) for v in np.power(2, e).astype(int)]
+
+
+@dataclasses.dataclass(frozen=True)
+class Branch:
+    """One dilated-attention branch at sequence length N (dilated_attention.py:82-111, 212-253)."""
+    seg: int      # s = min(segment_length, N)
+    ratio: int    # dilation r
+    nseg: int     # ceil(N / s)
+    n: int        # sparse sequence length per (segment, head) = ceil(s / r)  (zero padded)
+
+
+def branch_table(N: int, seg_lengths: Sequence[int], ratios: Sequence[int] = DILATED_RATIOS) -> List[Branch]:
+    out = []
+    for sl, dr in zip(seg_lengths, ratios):
+        s = min(int(sl), N)
+        out.append(Branch(seg=s, ratio=int(dr), nseg=-(-N // s), n=-(-s // int(dr))))
+    return out
+
+
+def coords_to_rowcol(coords: np.ndarray, tile: float = 256.0) -> Tuple[np.ndarray, np.ndarray]:
+    """LongNetViT.coords_to_pos (slide_encoder.py:198-211) split into (row, col) grid indices.
+
+    pos = floor(c0/256)*ngrids + floor(c1/256) + 1; we keep (row, col) because the table row
+    pos_embed[pos] = concat(sincos(col), sincos(row)) (pos_embed.py:42-59: the w-meshgrid goes first).
+    """
+    g = np.floor(np.asarray(coords, dtype=np.float32) / np.float32(tile))
+    return g[..., 0].astype(np.int64), g[..., 1].astype(np.int64)
+
+
+def sincos_1d_table(ngrids: int, dim: int) -> np.ndarray:
+    """1-D sin-cos table [ngrids, dim] in float64 -> float32, following pos_embed.py:62-81.
+
+    The reference's full 2-D table row for grid cell (row, col) is concat(T[col], T[row]) with
+    T = this table at dim = embed_dim/2, so a [ngrids, 384] table replaces the 3 GB buffer.
+    """
+    omega = np.arange(dim // 2, dtype=float)
+    omega /= dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    pos = np.arange(ngrids, dtype=np.float32).reshape(-1)
+    out = np.einsum("m,d->md", pos, omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1).astype(np.float32)
+
+
+def flops_per_slide_step(L: int, T: int, depth: int = 12, seg=None, tasks: int = 3) -> Dict[str, float]:
+    """Algorithmic FLOPs: 2mnk GEMMs, 4*nq*nk*d attention, no recompute counted."""
+    seg = seg or segment_lengths()
+    N, D, F, H, d, E = L + 1, 768, 3072, 16, 48, 192
+    patch = 2.0 * L * 1536 * D
+    gemm_layer = 2.0 * N * (4 * D * D + 2 * D * F)
+    attn_layer = sum(b.nseg * H * b.n * b.n * d * 4.0 for b in branch_table(N, seg))
+    inj = 2.0 * L * (D * E + E * E + E * E + E * D) + 4.0 * L * T * E + 2.0 * T * 2 * D * E
+    ext = 2.0 * T * (D * E + E * E + E * E + E * D) + 4.0 * L * T * E + 2.0 * L * 2 * D * E + 2.0 * T * 2 * D * E
+    adapter = 3 * inj + 5 * ext
+    fwd = patch + depth * (gemm_layer + attn_layer) + adapter
+    bwd = depth * (gemm_layer + 2.5 * attn_layer) + 2 * adapter
+    step = tasks * (fwd + bwd) - (tasks - 1) * patch
+    return {"fwd_pass": fwd, "bwd_pass": bwd, "step": step, "gemm_layer": gemm_layer,
+            "attn_layer": attn_layer, "adapter": adapter, "patch": patch}

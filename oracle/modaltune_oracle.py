@@ -1,0 +1,300 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY (never imported by the product path `modaltune_amd/`).
+
+A from-scratch torch-CPU restatement of the reference's Modal-Adapter train step, written against the
+reference semantics with each function citing the reference file:line it
+follows (paths relative to the reference repo root).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module.
+
+Parity status: PINNED — tests/test_oracle_golden.py checks every function here against golden vectors
+produced by importing and running the reference itself in the build container
+(tests/golden/make_golden.py; fixtures under tests/golden/*.npz).
+
+Everything is functional: weights come in as a {state_dict key -> tensor} mapping using the
+reference's key names, so the same tensors drive the reference, this oracle and the HIP path.
+Dropout / DropPath / AlphaDropout are off (parity is only defined at p = 0).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-5
+
+
+def _ln(x, sd, prefix, eps=LN_EPS):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def _linear(x, sd, prefix):
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+# ------------------------------------------------------------------------------------------------
+# torch.nn.MultiheadAttention(embed_dim=E, heads, batch_first, kdim=vdim=D) as used by the adapter
+# (models/vitadapter/adapter_modules.py:42-49,157-164): separate q/k/v projection weights, a packed
+# in_proj_bias, per-head softmax(q k^T / sqrt(E/heads)) v, concat, out_proj.
+# ------------------------------------------------------------------------------------------------
+def mha(q_in, k_in, v_in, sd, prefix, heads):
+    E = sd[prefix + ".q_proj_weight"].shape[0]
+    b = sd[prefix + ".in_proj_bias"]
+    q = F.linear(q_in, sd[prefix + ".q_proj_weight"], b[:E])
+    k = F.linear(k_in, sd[prefix + ".k_proj_weight"], b[E:2 * E])
+    v = F.linear(v_in, sd[prefix + ".v_proj_weight"], b[2 * E:])
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    hd = E // heads
+    q = q.view(B, Lq, heads, hd).transpose(1, 2)
+    k = k.view(B, Lk, heads, hd).transpose(1, 2)
+    v = v.view(B, Lk, heads, hd).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    a = torch.softmax(s, dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, Lq, E)
+    return F.linear(a, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
+
+
+def cross_attention_pre(tgt, memory, sd, prefix, heads, pos=None, query_pos=None):
+    """CrossAttentionLayer.forward_pre (adapter_modules.py:210-234), normalize_before=True, with_cffn=True."""
+    t2 = _ln(tgt, sd, prefix + ".norm")
+    mem = _ln(memory, sd, prefix + ".norm_kq")
+    q = _linear(t2 if query_pos is None else t2 + query_pos, sd, prefix + ".q_proj")
+    kv = mem if pos is None else mem + pos
+    a = mha(q, kv, kv, sd, prefix + ".multihead_attn", heads)
+    return tgt + _linear(a, sd, prefix + ".output_proj")
+
+
+def injector(x, c, pe, sd, prefix, heads):
+    """Injector.forward (adapter_modules.py:359-369): attn(query=x, feat=c, pos=pe, query_pos=None);
+    y = x + gamma * attn where attn already contains the inner residual."""
+    attn = cross_attention_pre(x, c, sd, prefix + ".attn", heads, pos=pe, query_pos=None)
+    return x + sd[prefix + ".gamma"] * attn
+
+
+def extractor(c, x, pe, sd, prefix, heads):
+    """Extractor.forward (adapter_modules.py:321-335) + FFNLayer.forward_pre (284-287); SURVEY A.2."""
+    attn = cross_attention_pre(c, x, sd, prefix + ".attn", heads, pos=None, query_pos=pe)
+    c1 = c + attn
+    t = _ln(c1, sd, prefix + ".ffn.norm")
+    t = _linear(F.relu(_linear(t, sd, prefix + ".ffn.linear1")), sd, prefix + ".ffn.linear2")
+    return c1 + t
+
+
+def prompt_self_attention(c, pe, sd, prefix, heads):
+    """SelfAttentionLayer.forward_pre (adapter_modules.py:81-94); SURVEY A.3."""
+    t = _ln(c, sd, prefix + ".norm")
+    k_in = t + pe
+    q = _linear(k_in, sd, prefix + ".q_proj")
+    a = mha(q, k_in, t, sd, prefix + ".self_attn", heads)
+    return c + _linear(a, sd, prefix + ".output_proj")
+
+
+# ------------------------------------------------------------------------------------------------
+# Dilated attention (torchscale/component/dilated_attention.py:22-59,82-144,212-255)
+# ------------------------------------------------------------------------------------------------
+def dilated_attention_core(q, k, v, seg_lengths: Sequence[int], ratios: Sequence[int],
+                           return_branches: bool = False):
+    """q,k,v: [B, N, H, d] -> [B, N, H*d].
+
+    Independent restatement: per branch, every head group r walks positions r, r+dr, ... inside each
+    segment; entries beyond the segment or beyond N are all-zero rows that still act as keys
+    (logit 0, value 0: dilated_attention.py:98-101, 24-28).  Branch outputs are mixed with
+    softmax-over-branches of the per-(position, head) LSE, computed without gradient (132-141);
+    (position, head) pairs a branch does not visit carry lse = -1e8 (44, 52).
+    """
+    B, N, H, d = q.shape
+    scale = d ** -0.5
+    outs, lses = [], []
+    for sl, dr in zip(seg_lengths, ratios):
+        s = min(int(sl), N)
+        nseg = -(-N // s)
+        n = -(-s // dr)
+        g = H // dr
+        padN = nseg * s - N
+
+        def sparse(t):
+            t = F.pad(t, (0, 0, 0, 0, 0, padN))                      # zero rows beyond N
+            t = t.view(B, nseg, s, H, d)
+            t = F.pad(t, (0, 0, 0, 0, 0, n * dr - s))                # zero rows beyond the segment
+            t = t.view(B, nseg, n, dr, dr, g, d)                     # [.., i, r1(pos), r2(head group), hh, d]
+            return torch.diagonal(t, dim1=3, dim2=4)                 # [B, nseg, n, g, d, r]: pos offset == head group
+
+        qs, ks, vs = sparse(q), sparse(k), sparse(v)
+        sc = torch.einsum("bjqgdr,bjkgdr->bjrgqk", qs, ks) * scale
+        lse = torch.logsumexp(sc.float() if sc.dtype != torch.float64 else sc, dim=-1)   # [B,nseg,r,g,n]
+        o = torch.einsum("bjrgqk,bjkgdr->bjqgdr", torch.softmax(sc, dim=-1), vs)           # [B,nseg,n,g,d,r]
+        # scatter back to dense [B, N, H, d]; unvisited (pos, head) -> O = 0, lse = -1e8
+        od = q.new_zeros(B, nseg, n, dr, dr, g, d)
+        ld = torch.full((B, nseg, n, dr, dr, g), -1e8, dtype=lse.dtype)
+        idx = torch.arange(dr)
+        od[:, :, :, idx, idx] = o.permute(0, 1, 2, 5, 3, 4)          # [B, nseg, n, r, g, d]
+        ld[:, :, :, idx, idx] = lse.permute(0, 1, 4, 2, 3)           # [B, nseg, n, r, g]
+        od = od.reshape(B, nseg, n * dr, H, d)[:, :, :s].reshape(B, nseg * s, H, d)[:, :N]
+        ld = ld.reshape(B, nseg, n * dr, H)[:, :, :s].reshape(B, nseg * s, H)[:, :N]
+        outs.append(od)
+        lses.append(ld)
+    with torch.no_grad():
+        L = torch.stack(lses, 0)
+        w = torch.softmax(L, dim=0)
+    out = sum(o * w[i].unsqueeze(-1).to(o.dtype) for i, o in enumerate(outs))
+    out = out.reshape(B, N, H * d)
+    if return_branches:
+        return out, outs, lses
+    return out
+
+
+def encoder_layer(x, sd, prefix, seg_lengths, ratios, heads=16):
+    """EncoderLayer.forward (torchscale/architecture/encoder.py:121-175) with DilatedAttention.forward
+    (dilated_attention.py:146-262) and FeedForwardNetwork.forward (feedforward_network.py:132-143);
+    pre-LN (subln), alpha = 1, dropout/droppath off.  SURVEY A.4."""
+    B, N, D = x.shape
+    h = _ln(x, sd, prefix + ".self_attn_layer_norm")
+    q = _linear(h, sd, prefix + ".self_attn.q_proj").view(B, N, heads, D // heads)
+    k = _linear(h, sd, prefix + ".self_attn.k_proj").view(B, N, heads, D // heads)
+    v = _linear(h, sd, prefix + ".self_attn.v_proj").view(B, N, heads, D // heads)
+    a = dilated_attention_core(q, k, v, seg_lengths, ratios)
+    a = _ln(a, sd, prefix + ".self_attn.inner_attn_ln")
+    x = x + _linear(a, sd, prefix + ".self_attn.out_proj")
+    h = _ln(x, sd, prefix + ".final_layer_norm")
+    h = _linear(h, sd, prefix + ".ffn.fc1")
+    h = F.gelu(h.float()).type_as(h)          # GELU is forced to fp32 (feedforward_network.py:136)
+    h = _ln(h, sd, prefix + ".ffn.ffn_layernorm")
+    return x + _linear(h, sd, prefix + ".ffn.fc2")
+
+
+# ------------------------------------------------------------------------------------------------
+# Gene encoder (models/genomic_utils/gene_encoder.py:97-223)
+# ------------------------------------------------------------------------------------------------
+def gene_encoder(genes: Sequence[torch.Tensor], sd, prefix="gene_encoder", depth=3):
+    rows = []
+    for i, g in enumerate(genes):
+        h = F.elu(_linear(g, sd, f"{prefix}.gene_networks.{i}.0.0"))
+        rows.append(F.elu(_linear(h, sd, f"{prefix}.gene_networks.{i}.1.0")))
+    z = torch.cat(rows).unsqueeze(0)                                   # [1, G, 256]
+    for k in range(depth):
+        p = f"{prefix}.mlp_mixer.{k}"
+        t = _ln(z, sd, p + ".0.norm")                                  # token mixing: Conv1d(k=1) over the group axis
+        t = F.conv1d(t, sd[p + ".0.fn.0.weight"], sd[p + ".0.fn.0.bias"])
+        t = F.conv1d(F.gelu(t), sd[p + ".0.fn.3.weight"], sd[p + ".0.fn.3.bias"])
+        z = z + t
+        t = _ln(z, sd, p + ".1.norm")                                  # channel mixing
+        t = _linear(F.gelu(_linear(t, sd, p + ".1.fn.0")), sd, p + ".1.fn.3")
+        z = z + t
+    z = _ln(z, sd, f"{prefix}.mlp_mixer.{depth}")
+    z = _linear(z, sd, f"{prefix}.mlp_mixer.{depth + 1}")              # [1, G, 768]
+    z = _linear(z.permute(0, 2, 1), sd, f"{prefix}.pathway_compression").permute(0, 2, 1)
+    return z                                                            # [1, final_groups, 768]
+
+
+# ------------------------------------------------------------------------------------------------
+# Positional table (gigapath/pos_embed.py:34-81, slide_encoder.py:198-211)
+# ------------------------------------------------------------------------------------------------
+def pos_embed_rows(coords, embed_dim, ngrids, dtype):
+    import numpy as np
+    half = embed_dim // 2
+    omega = np.arange(half // 2, dtype=float)
+    omega /= half / 2.0
+    omega = 1.0 / 10000 ** omega
+    grid = torch.floor(coords / 256.0)
+    row, col = grid[..., 0].long(), grid[..., 1].long()
+    assert int(row.max()) < ngrids and int(col.max()) < ngrids
+
+    def enc(p):
+        out = np.einsum("m,d->md", p.reshape(-1).numpy().astype(np.float32), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    emb = np.concatenate([enc(col), enc(row)], axis=1)                 # w (col) half first
+    emb = torch.from_numpy(emb).float().to(dtype)                      # table is stored as fp32 (slide_encoder.py:150)
+    return emb.view(*coords.shape[:-1], embed_dim)
+
+
+# ------------------------------------------------------------------------------------------------
+# Full model forward (models/aggregators/longvit_adapter.py:205-347) and train-step loss
+# ------------------------------------------------------------------------------------------------
+def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token, seg_lengths,
+                  taps: Optional[dict] = None):
+    """x [1,L,in], coords [1,L,2], genes list of [1,n_i], task_token [num_tasks] -> [1, output_dim]."""
+    heads = cfg.num_heads
+    ratios = (1, 2, 4, 8, 16)
+    x = F.linear(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"])          # LVA:232
+    x = x + pos_embed_rows(coords, cfg.embed_dim, cfg.slide_ngrids, x.dtype)             # LVA:235-237
+    cls = sd["cls_token"] + 0.0                                                          # + pos_embed[0] == zeros
+    c = gene_encoder(genes, sd, depth=cfg.gene.depth)                                    # LVA:257
+    if cfg.is_multi:                                                                     # LVA:263-266
+        t = _ln(_linear(task_token.unsqueeze(0), sd, "task_weight.0"), sd, "task_weight.1")
+        c = torch.cat((t.unsqueeze(0), c), dim=1)
+    pe = sd["gene_pe"]
+    if taps is not None:
+        taps["x0"] = x.detach().clone(); taps["c0"] = c.detach().clone()
+    for i, (a, b) in enumerate(cfg.interaction_indexes):                                 # LVA:294-307
+        if i > 0 and cfg.use_prompt_sa:
+            c = prompt_self_attention(c, pe, sd, f"prompt_selfattention.{i}", heads)
+        x = injector(x, c, pe, sd, f"interactions.{i}.injector", heads)                  # AM:487-491
+        h = torch.cat((cls, x), dim=1)
+        for l in range(a, b + 1):
+            h = encoder_layer(h, sd, f"encoder.layers.{l}", seg_lengths, ratios)
+        cls, x = h[:, :1], h[:, 1:]
+        c = extractor(c, x, pe, sd, f"interactions.{i}.extractor", heads)                # AM:511-515
+        if i == len(cfg.interaction_indexes) - 1 and cfg.use_extra_extractor:
+            for j in range(2):
+                c = extractor(c, x, pe, sd, f"interactions.{i}.extra_extractors.{j}", heads)
+        if taps is not None:
+            taps[f"cls{i}"] = cls.detach().clone(); taps[f"c{i}"] = c.detach().clone()
+            taps[f"x{i}_head"] = x[:, :8].detach().clone()
+    nt = int(cfg.is_multi)
+    task_out, gene_out = c[:, :nt], c[:, nt:].mean(dim=1, keepdim=True)                  # LVA:321-325
+    if cfg.token_agg == "sum":
+        out = cls + gene_out + (task_out if nt else 0)
+    else:
+        out = torch.cat(((cls, task_out, gene_out) if nt else (cls, gene_out)), dim=-1)
+    out = _ln(out, sd, "final_norm")
+    return _linear(out.squeeze(1), sd, "final_project")
+
+
+def projector_forward(text, psd):
+    """Projection_layer (train_modaltune.py:44-59) on [4,512] + row L2 normalisation (TM:211-213)."""
+    h = F.linear(text, psd["conv1.0.weight"].flatten(1), psd["conv1.0.bias"])
+    h = F.layer_norm(h, (h.shape[-1],), psd["conv1.1.weight"].flatten(), psd["conv1.1.bias"].flatten(), LN_EPS)
+    h = F.linear(F.relu(h), psd["conv1.3.weight"].flatten(1), psd["conv1.3.bias"])
+    return h / h.norm(dim=-1, keepdim=True)
+
+
+def distill_loss(logits, text_proj, temperature=1.0):
+    """train_modaltune.py:225-233: KLDiv(sum) of log_softmax(logit/|logit|) vs softmax(text[[0,1,3]]) * T^2 * 10."""
+    logit = logits / logits.norm(dim=-1, keepdim=True)
+    logp = F.log_softmax(logit / temperature, dim=1)
+    p = F.softmax(text_proj[[0, 1, 3], :] / temperature, dim=1)
+    return F.kl_div(logp, p, reduction="sum") * (temperature ** 2) * 10
+
+
+def multitask_logits(sd, cfg, x, coords, genes, seg_lengths, task_ids=(0, 1, 2), taps=None):
+    """multitask_forward (train_modaltune.py:156-179)."""
+    eye = torch.eye(cfg.multi_task, dtype=x.dtype)
+    outs = []
+    for t in task_ids:
+        tp = {} if taps is not None else None
+        outs.append(model_forward(sd, cfg, x, coords, genes, eye[t], seg_lengths, taps=tp))
+        if taps is not None:
+            taps[t] = tp
+    return torch.cat(outs, dim=0)
+
+
+def train_step_loss_and_grads(sd, cfg, trainable: Sequence[str], x, coords, genes, text, psd, seg_lengths):
+    """Forward x3 + loss + backward (train_modaltune.py:211-235). Returns logits, loss, {key: grad}."""
+    sd = {k: (v.clone().requires_grad_(True) if k in set(trainable) else v) for k, v in sd.items()}
+    logits = multitask_logits(sd, cfg, x, coords, genes, seg_lengths)
+    loss = distill_loss(logits, projector_forward(text, psd))
+    loss.backward()
+    grads = {k: sd[k].grad for k in trainable}
+    return logits.detach(), loss.detach(), grads
+
+
+def adamw_update(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01):
+    """torch.optim.AdamW semantics (decoupled decay; TM:145-149 uses lr/20, wd 0.01, betas (0.9, 0.999))."""
+    p = p * (1 - lr * weight_decay)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    p = p - (lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps)
+    return p, m, v

@@ -1,0 +1,211 @@
+"""Golden-vector generator: runs the REFERENCE (imported read-only from /root/reference) on seeded
+synthetic weights/inputs and stores its outputs as small .npz fixtures next to this script.
+
+Run in the build container only:   python tests/golden/make_golden.py
+Nothing from the reference is copied: the script imports it, loads our synthetic state_dict
+(modaltune_amd/synth.py, strict=True) and records what the reference computes.  Weights and inputs
+are NOT stored -- they are regenerated from (config, seed) -- only reference outputs are.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_shims  # noqa: E402
+import unit_inputs  # noqa: E402
+
+ref_shims.install()
+
+from models.aggregators import Aggregator  # noqa: E402  (reference)
+from models.vitadapter.adapter_modules import Injector, Extractor, SelfAttentionLayer  # noqa: E402
+from models.genomic_utils import GeneBaseClass  # noqa: E402
+from models.prov_gigapath.gigapath.torchscale.model.LongNet import make_longnet_from_name  # noqa: E402
+import train_modaltune as TM  # noqa: E402  (reference trainer module: Projection_layer)
+
+from modaltune_amd.config import ModelConfig  # noqa: E402
+from modaltune_amd import synth  # noqa: E402
+
+REF_CFG = json.load(open("/root/reference/model_configs/modaltune_gigapath_config.json"))
+
+
+def tt(a, dtype):
+    return torch.from_numpy(np.asarray(a)).to(dtype)
+
+
+def sub_state(sd, prefix, dtype):
+    return {k[len(prefix):]: tt(v, dtype) for k, v in sd.items() if k.startswith(prefix)}
+
+
+def unit_adapter(seed=1):
+    """Injector / Extractor / SelfAttentionLayer at L=37 with T=65 and T=7 (float64)."""
+    cfg = ModelConfig.from_json(REF_CFG, depth=3, interaction_indexes=[[0, 0], [1, 1], [2, 2]])
+    sd = synth.synth_state_dict(cfg, synth.toy_group_sizes(), seed)
+    out = {}
+    dt = torch.float64
+    for T in (65, 7):
+        x, c, pe = unit_inputs.adapter_inputs(seed, T)
+        inj = Injector(dim=768, num_heads=12, init_values=0.0, with_cffn=True, cffn_ratio=0.25).double()
+        inj.load_state_dict(sub_state(sd, "interactions.0.injector.", dt), strict=True)
+        out[f"T{T}_injector"] = inj(query=tt(x, dt), feat=tt(c, dt), pos=tt(pe, dt)).detach().numpy()
+        ext = Extractor(dim=768, num_heads=12, with_cffn=True, cffn_ratio=0.25, drop=0.0, drop_path=0.0).double()
+        ext.load_state_dict(sub_state(sd, "interactions.0.extractor.", dt), strict=True)
+        out[f"T{T}_extractor"] = ext(query=tt(c, dt), feat=tt(x, dt), pos=tt(pe, dt)).detach().numpy()
+        sa = SelfAttentionLayer(d_model=768, nheads=12, dropout=0.0, normalize_before=True, with_cffn=True,
+                                cffn_ratio=0.25).double()
+        sa.load_state_dict(sub_state(sd, "prompt_selfattention.1.", dt), strict=True)
+        out[f"T{T}_selfattn"] = sa(tt(c, dt), tt(pe, dt)).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "unit_adapter.npz"), seed=seed, **out)
+
+
+def unit_layer(seed=2):
+    """One LongNet EncoderLayer (768-d, 16 heads) with small custom segments so that several segments,
+    a ragged last segment and non-multiple-of-ratio lengths (zero-pad keys) are all exercised."""
+    cfg = ModelConfig.from_json(REF_CFG, depth=3, interaction_indexes=[[0, 0], [1, 1], [2, 2]])
+    sd = synth.synth_state_dict(cfg, synth.toy_group_sizes(), seed)
+    out = {}
+    dt = torch.float64
+    cases = unit_inputs.LAYER_CASES
+    for name, (N, segs, ratios) in cases.items():
+        enc = make_longnet_from_name("LongNet_3_layers_768_dim", dilated_ratio=str(ratios), segment_length=str(segs),
+                                     drop_path_rate=0.0, dropout=0.0).double()
+        layer = enc.layers[0]
+        layer.load_state_dict(sub_state(sd, "encoder.layers.0.", dt), strict=True)
+        ref_shims.zero_dropout(layer)
+        x = unit_inputs.layer_inputs(seed, N)
+        y, _ = layer(tt(x, dt), encoder_padding_mask=None)
+        out[f"{name}_y"] = y.detach().numpy().astype(np.float64 if N < 64 else np.float32)
+        out[f"{name}_segs"], out[f"{name}_ratios"] = np.array(segs), np.array(ratios)
+        # raw dilated attention (before inner LN / out_proj) on q=k=v projections of a scaled input, so the
+        # softmax is far from uniform
+        at = layer.self_attn
+        h = tt(x, dt) * unit_inputs.ATTN_INPUT_SCALE
+        q, k, v = at.q_proj(h), at.k_proj(h), at.v_proj(h)
+        from einops import rearrange
+        qh, kh, vh = (rearrange(t, "b l (h d) -> b l h d", h=16) for t in (q, k, v))
+        outs, lses = [], []
+        for sl, dr in zip(segs, ratios):
+            ki = at.gathering(rearrange(kh, "b l h d -> b l h d"), dr, sl, is_causal=False, offset=0, is_kv=True, seq_parall=False)
+            vi = at.gathering(vh, dr, sl, is_causal=False, offset=0, is_kv=True, seq_parall=False)
+            qi = at.gathering(qh, dr, sl, is_causal=False, offset=0, is_kv=False, seq_parall=False)
+            o, lse = at.attention_ops(qi, ki, vi)
+            outs.append(o); lses.append(lse)
+        attn = at.scattering(outs, lses, N, 2, offset=0)
+        out[f"{name}_attn"] = attn.detach().numpy().astype(np.float64 if N < 64 else np.float32)
+    np.savez_compressed(os.path.join(HERE, "unit_layer.npz"), seed=seed, **out)
+
+
+def unit_gene(seed=3):
+    cfg = ModelConfig.from_json(REF_CFG, depth=3, interaction_indexes=[[0, 0], [1, 1], [2, 2]])
+    out = {}
+    dt = torch.float64
+    for name, sizes in {"toy6": synth.toy_group_sizes(6), "g21": [3 + (7 * i) % 11 for i in range(21)]}.items():
+        sd = synth.synth_state_dict(cfg, sizes, seed)
+        groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+        ge = GeneBaseClass.create("gene_mixer_group", latent_dim=256, depth=3, expansion_groups=0.5, expansion_dim=0.5,
+                                  dropout=0.25, cls_token=False, n_classes=2, final_groups=64, output_dim=768,
+                                  mode="feature", group_sizes=groups, n_groups=len(groups)).double()
+        ge.load_state_dict(sub_state(sd, "gene_encoder.", dt), strict=True)
+        ref_shims.zero_dropout(ge)
+        ge.eval()
+        genes = synth.synth_inputs(8, sizes, seed)["genes"]
+        y = ge({i: tt(g, dt) for i, g in enumerate(genes)})
+        out[f"{name}_sizes"] = np.array(sizes)
+        out[f"{name}_y"] = y.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "unit_gene.npz"), seed=seed, **out)
+
+
+GRAD_KEYS_FULL = ["interactions.0.injector.gamma", "interactions.1.injector.gamma", "final_project.bias",
+                  "interactions.0.injector.attn.q_proj.bias", "task_weight.0.weight",
+                  "gene_encoder.pathway_compression.weight", "interactions.2.extractor.ffn.linear1.bias"]
+
+
+def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32), ngrids=128, time_it=False):
+    cfg_kw = dict(REF_CFG)
+    cfg_kw.update(depth=depth, interaction_indexes=inter, slide_ngrids=ngrids, pretrained=False)
+    cfg = ModelConfig.from_json(cfg_kw)
+    sizes = synth.toy_group_sizes(6)
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    sd = synth.synth_state_dict(cfg, sizes, seed)
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    psd = synth.projector_state(seed)
+    out = {"L": L, "depth": depth, "inter": np.array(inter), "seed": seed, "ngrids": ngrids, "sizes": np.array(sizes)}
+    for dt in dtypes:
+        tag = "f64" if dt == torch.float64 else "f32"
+        model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, **cfg_kw, multi_task=3)
+        model.load_state_dict({k: tt(v, torch.float32) for k, v in sd.items()}, strict=True)
+        model = model.to(dt)
+        ref_shims.zero_dropout(model)
+        model.train()
+        proj = TM.Projection_layer(512, 256)
+        proj.load_state_dict({k: tt(v, torch.float32) for k, v in psd.items()}, strict=True)
+        proj = proj.to(dt)
+        taps = {}
+
+        def hook(i):
+            def f(mod, args, res):
+                x, c, cls = res
+                taps.setdefault(i, []).append((cls.detach().numpy().copy(), c.detach().numpy().copy(),
+                                               x[:, :8].detach().numpy().copy()))
+            return f
+        hs = [m.register_forward_hook(hook(i)) for i, m in enumerate(model.interactions)]
+        x, coords = tt(inp["x"], dt), tt(inp["coords"], dt)
+        genes = {i: tt(g, dt) for i, g in enumerate(inp["genes"])}
+        t0 = time.time()
+        text = proj(tt(inp["text"], dt)); text = text / text.norm(dim=-1, keepdim=True)
+        logits = torch.cat([model(x=x, coords=coords, genes=genes, clinical=[], task_token=torch.eye(3, dtype=dt)[t])
+                            for t in (0, 1, 2)], dim=0)
+        t1 = time.time()
+        logit = logits / logits.norm(dim=-1, keepdim=True)
+        loss = torch.nn.KLDivLoss(reduction="sum")(torch.nn.functional.log_softmax(logit / 1.0, dim=1),
+                                                  torch.nn.functional.softmax(text[[0, 1, 3], :] / 1.0, dim=1)) * 10
+        loss.backward()
+        t2 = time.time()
+        for h in hs:
+            h.remove()
+        out[f"{tag}_logits"] = logits.detach().numpy()
+        out[f"{tag}_loss"] = loss.detach().numpy()
+        out[f"{tag}_text"] = text.detach().numpy()
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            if p.requires_grad:
+                names.append(k); norms.append(float(p.grad.double().norm()))
+        out[f"{tag}_grad_names"] = np.array(names)
+        out[f"{tag}_grad_norms"] = np.array(norms)
+        if dt == torch.float64:
+            for k in GRAD_KEYS_FULL:
+                kk = k.replace("interactions.2.", f"interactions.{len(inter) - 1}.")
+                out["f64_grad/" + kk] = dict(model.named_parameters())[kk].grad.numpy()
+            for i, lst in taps.items():
+                for t, (cls, c, xh) in enumerate(lst):
+                    out[f"f64_tap/task{t}/cls{i}"] = cls
+                    out[f"f64_tap/task{t}/c{i}"] = c.astype(np.float32)
+                    out[f"f64_tap/task{t}/x{i}_head"] = xh
+        if time_it:
+            out[f"{tag}_time_fwd_bwd"] = np.array([t1 - t0, t2 - t1])
+        print(name, tag, "loss", float(loss), "fwd %.2fs bwd %.2fs" % (t1 - t0, t2 - t1), flush=True)
+    np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["adapter", "layer", "gene", "m37", "m1500", "m512"]
+    if "adapter" in which:
+        unit_adapter()
+    if "layer" in which:
+        unit_layer()
+    if "gene" in which:
+        unit_gene()
+    if "m37" in which:
+        model_case("L37_d3", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=11)
+    if "m1500" in which:
+        model_case("L1500_d3", 1500, 3, [[0, 0], [1, 1], [2, 2]], seed=12)
+    if "m512" in which:   # BASELINE config 1 shape: 512 patches, full 12-layer Prov-GigaPath geometry
+        model_case("L512_d12", 512, 12, [[0, 3], [4, 7], [8, 11]], seed=13, time_it=True)

@@ -1,0 +1,132 @@
+"""Pins the CPU oracle (oracle/modaltune_oracle.py) against golden vectors produced by running the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import unit_inputs
+from modaltune_amd import synth
+from modaltune_amd.config import ModelConfig, segment_lengths
+from oracle import modaltune_oracle as O
+
+F64 = torch.float64
+
+
+def _sd(cfg, sizes, seed, dtype=F64):
+    return {k: torch.from_numpy(v).to(dtype) for k, v in synth.synth_state_dict(cfg, sizes, seed).items()}
+
+
+def _small_cfg(**kw):
+    base = dict(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)))
+    base.update(kw)
+    return ModelConfig(**base)
+
+
+def _maxrel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+@pytest.mark.parametrize("T", [65, 7])
+def test_adapter_units(golden_dir, T):
+    g = np.load(os.path.join(golden_dir, "unit_adapter.npz"))
+    seed = int(g["seed"])
+    sd = _sd(_small_cfg(), synth.toy_group_sizes(), seed)
+    x, c, pe = (torch.from_numpy(a) for a in unit_inputs.adapter_inputs(seed, T))
+    assert _maxrel(O.injector(x, c, pe, sd, "interactions.0.injector", 12), g[f"T{T}_injector"]) < 1e-12
+    assert _maxrel(O.extractor(c, x, pe, sd, "interactions.0.extractor", 12), g[f"T{T}_extractor"]) < 1e-12
+    assert _maxrel(O.prompt_self_attention(c, pe, sd, "prompt_selfattention.1", 12), g[f"T{T}_selfattn"]) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_encoder_layer_and_dilated_attention(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "unit_layer.npz"))
+    seed = int(g["seed"])
+    N, segs, ratios = unit_inputs.LAYER_CASES[case]
+    sd = _sd(_small_cfg(), synth.toy_group_sizes(), seed)
+    x = torch.from_numpy(unit_inputs.layer_inputs(seed, N))
+    tol = 1e-11 if N < 64 else 3e-7      # big cases are stored as float32
+    y = O.encoder_layer(x, sd, "encoder.layers.0", segs, ratios)
+    assert _maxrel(y, g[f"{case}_y"]) < tol
+    h = x * unit_inputs.ATTN_INPUT_SCALE
+    p = "encoder.layers.0.self_attn."
+    q, k, v = (torch.nn.functional.linear(h, sd[p + f"{n}_proj.weight"], sd[p + f"{n}_proj.bias"]).view(2, N, 16, 48)
+               for n in "qkv")
+    a = O.dilated_attention_core(q, k, v, segs, ratios)
+    assert _maxrel(a, g[f"{case}_attn"]) < tol
+
+
+@pytest.mark.parametrize("name", ["toy6", "g21"])
+def test_gene_encoder(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "unit_gene.npz"))
+    seed = int(g["seed"])
+    sizes = [int(s) for s in g[f"{name}_sizes"]]
+    sd = _sd(_small_cfg(), sizes, seed)
+    genes = [torch.from_numpy(a).double() for a in synth.synth_inputs(8, sizes, seed)["genes"]]
+    assert _maxrel(O.gene_encoder(genes, sd), g[f"{name}_y"]) < 1e-12
+
+
+def _run_model_case(path, dtype):
+    g = np.load(path)
+    L, depth, seed, ngrids = int(g["L"]), int(g["depth"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    cfg = ModelConfig(depth=depth, interaction_indexes=tuple(tuple(int(i) for i in p) for p in g["inter"]),
+                      slide_ngrids=ngrids)
+    cfg.validate()
+    sd = _sd(cfg, sizes, seed, dtype)
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    psd = {k: torch.from_numpy(v).to(dtype) for k, v in synth.projector_state(seed).items()}
+    x, coords = torch.from_numpy(inp["x"]).to(dtype), torch.from_numpy(inp["coords"]).to(dtype)
+    genes = [torch.from_numpy(a).to(dtype) for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"]).to(dtype)
+    trainable = synth.trainable_keys(cfg, sizes)
+    logits, loss, grads = O.train_step_loss_and_grads(sd, cfg, trainable, x, coords, genes, text, psd, segment_lengths())
+    return g, cfg, logits, loss, grads
+
+
+@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12"])
+def test_full_train_step_f64(golden_dir, name):
+    path = os.path.join(golden_dir, f"model_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g, cfg, logits, loss, grads = _run_model_case(path, F64)
+    assert _maxrel(logits, g["f64_logits"]) < 1e-9
+    assert abs(float(loss) - float(g["f64_loss"])) < 1e-9 * abs(float(g["f64_loss"]))
+    names = [str(n) for n in g["f64_grad_names"]]
+    assert sorted(names) == sorted(grads.keys())        # same trainable set as the reference (244 tensors)
+    ours = np.array([float(grads[n].norm()) for n in names])
+    ref = g["f64_grad_norms"]
+    assert np.abs(ours - ref).max() <= 1e-8 * ref.max()
+    for k in g.files:
+        if k.startswith("f64_grad/"):
+            assert _maxrel(grads[k[len("f64_grad/"):]], g[k]) < 1e-8
+
+
+def test_full_train_step_f32_matches_reference_f32(golden_dir):
+    """The reference's own CPU path is fp32: the fp32 oracle must sit within fp32 rounding of it."""
+    g, cfg, logits, loss, grads = _run_model_case(os.path.join(golden_dir, "model_L37_d3.npz"), torch.float32)
+    assert _maxrel(logits, g["f32_logits"]) < 2e-5
+    assert abs(float(loss) - float(g["f32_loss"])) < 1e-4 * abs(float(g["f32_loss"]))
+    # fp32-vs-fp64 reference drift, for scale: the parity budget of the HIP path is 1e-3
+    assert _maxrel(g["f32_logits"], g["f64_logits"]) < 1e-4
+
+
+def test_segment_rule_and_branch_table():
+    from modaltune_amd.config import branch_table
+    assert segment_lengths() == [1024, 5792, 32768, 185363, 1048576]
+    bt = branch_table(10001, segment_lengths())
+    assert [(b.seg, b.nseg, b.n) for b in bt] == [(1024, 10, 1024), (5792, 2, 2896), (10001, 1, 2501),
+                                                  (10001, 1, 1251), (10001, 1, 626)]
+    assert [b.n for b in branch_table(513, segment_lengths())] == [513, 257, 129, 65, 33]
+
+
+def test_param_inventory_matches_reference_counts():
+    # 9 229 831 trainable / 86 330 880 frozen params with the 6-pathway toy grouping
+    cfg = ModelConfig()
+    specs = synth.param_specs(cfg, synth.toy_group_sizes())
+    tr = sum(int(np.prod(s)) for _, s, _, t in specs if t)
+    fr = sum(int(np.prod(s)) for _, s, _, t in specs if not t)
+    assert tr == 9229831 and fr == 86330880
+    assert sum(1 for *_, t in specs if t) == 244
