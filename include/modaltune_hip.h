@@ -1,0 +1,199 @@
+/* modaltune_hip — C ABI of the MI355X-native Modal-Adapter hot path.
+ *
+ * The reference (martellab-sri/ModalTune) is pure Python/PyTorch and has no FFI layer; its drop-in
+ * boundary is the nn.Module surface.  This header is the native boundary underneath
+ * that surface: one `extern "C"` launcher per fused op and direction, plain device pointers and sizes,
+ * no torch types.  Each entry cites the reference code whose arithmetic it replaces
+ * (paths relative to the reference root; abbreviations as in SURVEY.md).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless stated; the caller owns every buffer (no hidden hipMalloc)
+ *   - `mt_half` = IEEE fp16 storage (the reference's AMP dtype, TM:216); accumulation is fp32 everywhere
+ *   - activations are row-major [rows, cols]; token buffers are [B*N, C] with pass b at rows [b*N, (b+1)*N)
+ *   - every launcher enqueues on `stream` (a hipStream_t) and returns immediately: 0 or a negative MtStatus
+ *   - no exception crosses this boundary; nothing here synchronises the device
+ */
+#ifndef MODALTUNE_HIP_H
+#define MODALTUNE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mt_stream_t;     /* hipStream_t */
+typedef uint16_t mt_half;      /* IEEE binary16 bit pattern */
+
+typedef enum {
+  MT_OK = 0,
+  MT_ERR_BAD_ARG = -1,         /* shape/alignment the kernels do not support */
+  MT_ERR_LAUNCH = -2,          /* hipGetLastError() != hipSuccess after the launch */
+  MT_ERR_UNSUPPORTED = -3
+} MtStatus;
+
+/* logical row m -> physical row (m / seg_rows) * seg_stride + row0 + m % seg_rows; seg_rows <= 0: identity.
+ * Lets the adapter ops address "the patch rows of a [B, N, C] token buffer" without the torch.cat / slice
+ * copies of AM:492,501-510, and broadcast one slide to the 3 task passes (seg_stride = 0). */
+typedef struct { int seg_rows, seg_stride, row0; } MtRowMap;
+
+int mt_version(void);
+const char* mt_status_string(int status);
+
+/* ---------------------------------------------------------------- GEMMs ---------------------------- */
+enum { MT_EPI_BIAS = 0,        /* C = acc + bias                                   (nn.Linear)            */
+       MT_EPI_BIAS_RESID = 1,  /* C = resid + acc + bias                           (ENC:149-154,169-172)  */
+       MT_EPI_INJECT = 2,      /* C = (1+g[n]) * resid + g[n] * (acc + bias)       (AM:231,362; A.1)      */
+       MT_EPI_POSEMB = 3 };    /* C = acc + bias + sincos(col|row)                 (LVA:232-237)          */
+enum { MT_OUT_F16 = 0, MT_OUT_F32 = 1 };
+
+typedef struct {
+  const float* bias;           /* [N] or NULL */
+  const float* resid;          /* fp32 [*, ldr] (BIAS_RESID, INJECT) */
+  long ldr;
+  MtRowMap rmap;
+  const float* colscale;       /* gamma [N] (INJECT) */
+  const float* pos_table;      /* [ngrids, N/2] 1-D sin-cos table (POSEMB), pos_embed.py:62-81 */
+  const int* pos_row;          /* [M] grid row index  floor(coords[:,0]/256), SE:209-211 */
+  const int* pos_col;          /* [M] grid col index */
+} MtGemmEpilogue;
+
+/* C[M,N] = epilogue(A[M,K] @ W[N,K]^T); A, W fp16; fp32 accumulate on MFMA.  K % 64 == 0, lda % 8 == 0.
+ * Replaces every big-M nn.Linear on the path: PatchEmbed.proj (SE:52-56), q/k/v/out_proj (DA:169-171,260),
+ * fc1/fc2 (FFN:134,140), adapter q_proj/output_proj/k|v projections (AM:154-164,221-231), and — with a
+ * pre-transposed weight — the activation-gradient (dX) GEMMs of the frozen backbone. */
+int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* W, int M, int N, int K,
+                   int epilogue, const MtGemmEpilogue* epi, void* C, long ldc, const MtRowMap* cmap, int out_dtype,
+                   mt_stream_t stream);
+
+/* C[N1,N2] (fp32) += sum_m A[m,N1] * B[m,N2] over M rows (split over workgroups, fp32 atomics): the weight
+ * gradient of a big-M nn.Linear (autograd of AM:154-164 etc.).  N1 % 64 == 0, N2 % 64 == 0. */
+int mt_gemm_tn_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* B, long ldb, const MtRowMap* bmap,
+                   int M, int N1, int N2, float* C, long ldc, mt_stream_t stream);
+
+/* out[n] (fp32) += sum_m A[m,n]: bias gradient of a big-M nn.Linear */
+int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, int M, int N, float* out, mt_stream_t stream);
+
+/* Generic small strided fp32 GEMM for the token-side ops (T <= 66 rows; gene encoder GE:194-223, prompt
+ * self-attention projections AM:81-94, extractor FFN AM:284-287, fusion head LVA:343-347), forward and
+ * backward:  C(m,n) = act(sum_k A(m,k) B(n,k) + bias[n]) [+ C(m,n) if accumulate].
+ * Element (i,j) of X is X[i*xs0 + j*xs1].  batch: pointer offsets a_bs/b_bs/c_bs per batch index. */
+enum { MT_ACT_NONE = 0, MT_ACT_RELU = 1, MT_ACT_GELU = 2, MT_ACT_ELU = 3 };
+int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B, long bs0, long bs1, long b_bs,
+                   const float* bias, int bias_on_m, float* C, long cs0, long cs1, long c_bs, int M, int N, int K,
+                   int batch, int act, int accumulate, mt_stream_t stream);
+
+/* ------------------------------------------------------------- LayerNorm --------------------------- */
+/* y = LN(f(x)) * w + b over the last dim D (eps 1e-5), one wave per row; stats (mean, rstd) saved per row.
+ * f = identity or erf-GELU computed in fp32 (FFN:136 forces the activation to fp32, then FFN:138 ffn_layernorm).
+ * in_dtype/out_dtype: MT_OUT_F16 / MT_OUT_F32.  D in {256, 768, 2304, 3072}.  `add_rows` (fp32 [add_period, D],
+ * or NULL) is added AFTER the affine: LN(c) + pe as in AM:218,227 (with_pos_embed on normed memory). */
+int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w,
+                     const float* b, const float* add_rows, int add_period, void* y, long ldy, const MtRowMap* ymap,
+                     int out_dtype, float* stats, int M, int D, mt_stream_t stream);
+
+/* dx (+)= LN backward.  dy fp16 or fp32 [M,D]; x as in forward (gelu_in: also backprop through the GELU).
+ * dx_dtype F32 with accumulate=1 adds into the fp32 residual-gradient stream (ENC:137-154 backward);
+ * dw/db (fp32 [D], atomically accumulated) may be NULL for frozen norms (selective backward). */
+int mt_layernorm_bwd(const void* dy, long lddy, const MtRowMap* dymap, int dy_dtype, const void* x, long ldx,
+                     const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w, const float* stats, void* dx,
+                     long lddx, const MtRowMap* dxmap, int dx_dtype, int accumulate, float* dw, float* db, int M, int D,
+                     mt_stream_t stream);
+
+/* ------------------------------------------------------- dilated attention ------------------------- */
+#define MT_MAX_BRANCHES 8
+typedef struct {
+  int nbranch;
+  int N;                              /* tokens per pass (L + 1) */
+  int B;                              /* task passes batched */
+  int seg[MT_MAX_BRANCHES];           /* s = min(segment_length, N)                  DA:96-98   */
+  int ratio[MT_MAX_BRANCHES];         /* dilation r                                  DA:213     */
+  int nseg[MT_MAX_BRANCHES];          /* ceil(N / s)                                            */
+  int n[MT_MAX_BRANCHES];             /* sparse length ceil(s / r) incl. zero padding DA:22-37  */
+} MtDilatedPlan;
+
+/* qkv: fp16 [B*N, 3*768] (q | k | v, 16 heads x 48 each).  For every branch, every (segment, head):
+ * O_b = softmax(Q K^T / sqrt(48)) V over the head's dilated positions, zero-padded rows acting as keys with
+ * logit 0 / value 0 (DA:98-101,24-28).  o_br: fp16 [nbranch][B*N, 768]; lse_br: fp32 [nbranch][B*N, 16]
+ * (natural log).  (position, head) pairs a branch does not visit are left untouched.  DA:212-253, MHA:109-119. */
+int mt_dilated_attn_fwd(const mt_half* qkv, const MtDilatedPlan* plan, mt_half* o_br, float* lse_br,
+                        mt_stream_t stream);
+
+/* Branch mix + inner_attn_ln: w_b = softmax_b(lse_b) per (position, head) (constant in backward, DA:132-137),
+ * mixed = sum_b w_b O_b, y = LN(mixed) (DA:257-258).  Writes y fp16 [B*N,768], LN stats, and
+ * lse_tot = logsumexp_b(lse_b) fp32 [B*N,16] for the backward. */
+int mt_dilated_mix_ln_fwd(const mt_half* o_br, const float* lse_br, const MtDilatedPlan* plan, const float* ln_w,
+                          const float* ln_b, mt_half* y, float* stats, float* lse_tot, mt_stream_t stream);
+
+/* Backward of mix + inner_attn_ln: given dy (fp16, gradient wrt the LN output) recomputes mixed, writes
+ * dmixed fp16 [B*N,768] and delta_br[b][row][head] = sum_d dmixed * O_b (fp32). */
+int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, const float* lse_br, const float* lse_tot,
+                          const MtDilatedPlan* plan, const float* ln_w, const float* stats, mt_half* dmixed,
+                          float* delta_br, mt_stream_t stream);
+
+/* Flash-style backward of all branches: dqkv fp32 [B*N, 2304] (overwritten) from qkv, dmixed, lse_tot, delta_br.
+ * P~ = exp(s - lse_tot) (= w_b P_b), dS = P~ (dmixed V^T - delta_b), dQ = dS K, dK = dS^T Q, dV = P~^T dmixed. */
+int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot, const float* delta_br,
+                        const MtDilatedPlan* plan, float* dqkv, mt_stream_t stream);
+
+/* ------------------------------------------------------------ adapter ops -------------------------- */
+/* Injector attention core (AM:225-229 inside AM:359-369): for each of M patch rows and 12 heads (dim 16):
+ * a = softmax(q k^T / 4) v over the T modal tokens of the row's pass.  q fp16 [M,192]; k,v fp32 [B,T,192]. */
+int mt_inject_attn_fwd(const mt_half* q, int M, int rows_per_pass, const float* k, const float* v, int T,
+                       mt_half* a, mt_stream_t stream);
+/* backward: dq fp16 [M,192]; dk, dv fp32 [B,T,192] accumulated with atomics (pre-zeroed by the caller) */
+int mt_inject_attn_bwd(const mt_half* q, const mt_half* da, int M, int rows_per_pass, const float* k, const float* v,
+                       int T, mt_half* dq, float* dk, float* dv, mt_stream_t stream);
+
+/* Extractor attention core (AM:225-229 inside AM:321-335): T token queries attend over the L patch rows of their
+ * pass.  q fp32 [B,T,192]; kv fp16 [B*L, 384] (k | v).  Split over L (flash-decoding style): part_* are
+ * workspaces of nsplit partials; out fp32 [B,T,192]; lse fp32 [B,T,12]. */
+int mt_extract_attn_fwd(const float* q, const mt_half* kv, int B, int T, int L, float* out, float* lse,
+                        float* part_acc, float* part_ml, int nsplit, mt_stream_t stream);
+/* backward: dq fp32 [B,T,192] (atomics, pre-zeroed), dkv fp16 [B*L,384] */
+int mt_extract_attn_bwd(const float* q, const mt_half* kv, const float* out, const float* lse, const float* dout,
+                        int B, int T, int L, float* dq, mt_half* dkv, mt_stream_t stream);
+
+/* Small dense multi-head attention over tokens (prompt self-attention AM:87): q,k,v fp32 [B,T,E], heads h. */
+int mt_token_mha_fwd(const float* q, const float* k, const float* v, int B, int T, int E, int heads, float* out,
+                     float* probs, mt_stream_t stream);
+int mt_token_mha_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout, int B,
+                     int T, int E, int heads, float* dq, float* dk, float* dv, mt_stream_t stream);
+
+/* ------------------------------------------------------------ elementwise -------------------------- */
+int mt_cast_f32_to_f16(const float* x, mt_half* y, long n, mt_stream_t stream);
+int mt_cast_f16_to_f32(const mt_half* x, float* y, long n, mt_stream_t stream);
+/* y = act(x) / dx = dy * act'(x) on fp32 vectors (ELU GE:178, GELU GE:187, ReLU AM:286) */
+int mt_act_fwd(const float* x, float* y, long n, int act, mt_stream_t stream);
+int mt_act_bwd(const float* x, const float* dy, float* dx, long n, int act, mt_stream_t stream);
+/* y[i] = a[i] + alpha * b[i] */
+int mt_axpy(const float* a, const float* b, float alpha, float* y, long n, mt_stream_t stream);
+/* strided row copies between fp32 buffers: dst(map(m), :) (+)= src(map(m), :) */
+int mt_copy_rows_f32(const float* src, long lds, const MtRowMap* smap, float* dst, long ldd, const MtRowMap* dmap,
+                     int M, int D, int accumulate, mt_stream_t stream);
+/* Injector residual-path backward (A.1): dres(m,:) += (1 + g) * dy(m,:) for the patch rows; also reduces
+ * dgamma[n] += sum_m dy(m,n) * (x(m,n) + proj(m,n)) where proj = a @ Wo^T + bo is recomputed by the caller as
+ * fp16 `proj`.  */
+int mt_inject_resid_bwd(const float* dy, long lddy, const MtRowMap* dymap, const float* x, long ldx,
+                        const MtRowMap* xmap, const mt_half* proj, const float* gamma, float* dx, long lddx,
+                        const MtRowMap* dxmap, int dx_accumulate, mt_half* dproj, float* dgamma, int M, int D,
+                        mt_stream_t stream);
+
+/* ---------------------------------------------------------- head, loss, optimiser ------------------ */
+/* logits [R,O] -> L2-normalise rows, log_softmax, KL(sum) against softmax(target rows) * 10 (TM:225-233).
+ * Writes loss (1 float) and dlogits [R,O] scaled by `loss_scale` (GradScaler semantics, TM:107,235). */
+int mt_distill_loss(const float* logits, const float* target, int R, int O, float loss_scale, float* loss,
+                    float* dlogits, mt_stream_t stream);
+
+/* Fused multi-tensor AdamW over one flat fp32 parameter/gradient buffer (torch.optim.AdamW, TM:145-149) with
+ * GradScaler.step semantics (TM:235-237): grads are divided by *scale; if any is non-finite the update is
+ * skipped and *found_inf is set.  step_count is 1-based. */
+int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step_count, const float* scale, int* found_inf,
+                  mt_stream_t stream);
+int mt_check_finite(const float* g, long n, int* found_inf, mt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODALTUNE_HIP_H */

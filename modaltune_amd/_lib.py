@@ -1,0 +1,102 @@
+"""ctypes binding of the C-ABI library (include/modaltune_hip.h).
+
+The product path has NO fallback: if libmodaltune_hip.so is missing or a launcher returns a negative
+MtStatus, a RuntimeError is raised (the reference's error convention is Python exceptions).
+torch is imported first so that the HIP runtime already mapped by PyTorch-ROCm (soname libamdhip64.so.7)
+is the one the library binds to -- streams and device pointers are then shared with torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_C", "libmodaltune_hip.so")
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class MtRowMap(C.Structure):
+    _fields_ = [("seg_rows", I), ("seg_stride", I), ("row0", I)]
+
+
+class MtGemmEpilogue(C.Structure):
+    _fields_ = [("bias", P), ("resid", P), ("ldr", L), ("rmap", MtRowMap), ("colscale", P),
+                ("pos_table", P), ("pos_row", P), ("pos_col", P)]
+
+
+MT_MAX_BRANCHES = 8
+
+
+class MtDilatedPlan(C.Structure):
+    _fields_ = [("nbranch", I), ("N", I), ("B", I), ("seg", I * MT_MAX_BRANCHES), ("ratio", I * MT_MAX_BRANCHES),
+                ("nseg", I * MT_MAX_BRANCHES), ("n", I * MT_MAX_BRANCHES)]
+
+
+RM = C.POINTER(MtRowMap)
+EP = C.POINTER(MtGemmEpilogue)
+PL = C.POINTER(MtDilatedPlan)
+
+# name -> argtypes (restype int unless listed in _RESTYPE)
+SIGNATURES = {
+    "mt_version": [],
+    "mt_status_string": [I],
+    "mt_gemm_nt_f16": [P, L, RM, P, I, I, I, I, EP, P, L, RM, I, P],
+    "mt_gemm_tn_f16": [P, L, RM, P, L, RM, I, I, I, P, L, P],
+    "mt_colsum_f16": [P, L, RM, I, I, P, P],
+    "mt_sgemm_small": [P, L, L, L, P, L, L, L, P, I, P, L, L, L, I, I, I, I, I, I, P],
+    "mt_layernorm_fwd": [P, L, RM, I, I, P, P, P, I, P, L, RM, I, P, I, I, P],
+    "mt_layernorm_bwd": [P, L, RM, I, P, L, RM, I, I, P, P, P, L, RM, I, I, P, P, I, I, P],
+    "mt_dilated_attn_fwd": [P, PL, P, P, P],
+    "mt_dilated_mix_ln_fwd": [P, P, PL, P, P, P, P, P, P],
+    "mt_dilated_mix_ln_bwd": [P, P, P, P, PL, P, P, P, P, P],
+    "mt_dilated_attn_bwd": [P, P, P, P, PL, P, P],
+    "mt_inject_attn_fwd": [P, I, I, P, P, I, P, P],
+    "mt_inject_attn_bwd": [P, P, I, I, P, P, I, P, P, P, P],
+    "mt_extract_attn_fwd": [P, P, I, I, I, P, P, P, P, I, P],
+    "mt_extract_attn_bwd": [P, P, P, P, P, I, I, I, P, P, P],
+    "mt_token_mha_fwd": [P, P, P, I, I, I, I, P, P, P],
+    "mt_token_mha_bwd": [P, P, P, P, P, I, I, I, I, P, P, P, P],
+    "mt_cast_f32_to_f16": [P, P, L, P],
+    "mt_cast_f16_to_f32": [P, P, L, P],
+    "mt_act_fwd": [P, P, L, I, P],
+    "mt_act_bwd": [P, P, P, L, I, P],
+    "mt_axpy": [P, P, F, P, L, P],
+    "mt_copy_rows_f32": [P, L, RM, P, L, RM, I, I, I, P],
+    "mt_inject_resid_bwd": [P, L, RM, P, L, RM, P, P, P, L, RM, I, P, P, I, I, P],
+    "mt_distill_loss": [P, P, I, I, F, P, P, P],
+    "mt_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, P, P, P],
+    "mt_check_finite": [P, L, P, P],
+}
+_RESTYPE = {"mt_status_string": C.c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load the library and bind every declared entry point; raises if the build is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps PyTorch-ROCm's HIP runtime first)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"modaltune_amd: {LIB_PATH} is missing -- run `python __graft_entry__.py` (hipcc, gfx950) first; "
+            "there is no CPU/PyTorch fallback for the hot path")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, I)
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().mt_status_string(status).decode()
+        raise RuntimeError(f"modaltune_hip {what} failed: {msg} ({status})")
+
+
+def rowmap(seg_rows=0, seg_stride=0, row0=0):
+    return MtRowMap(seg_rows, seg_stride, row0)

@@ -1,0 +1,450 @@
+// Modal-Adapter attention cores (12 heads x 16, E = 192):
+//   inject  : every patch row attends over the T <= 128 modal tokens of its pass       (AM:225-229 in AM:359-369)
+//   extract : the T modal tokens attend over the L patch rows of their pass (split-L)   (AM:225-229 in AM:321-335)
+//   token   : T x T self-attention among the modal tokens                               (AM:87)
+// These are tiny-FLOP, HBM/latency-bound ops; they run on the VALU in fp32 with the small operand (the token
+// side) resident in LDS, one streaming pass over the patch-side operand.
+#include "common.h"
+
+namespace {
+
+constexpr int AH = 12, AD = 16, AE = 192, TMAX = 128;
+constexpr float ASCALE = 0.25f;   // 1/sqrt(16)
+
+MT_DEVINL void load16(const h16* p, float* out) {
+  const h16x8 a = ldg8(p), b = ldg8(p + 8);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { out[i] = (float)a[i]; out[8 + i] = (float)b[i]; }
+}
+MT_DEVINL void store16(h16* p, const float* v) {
+  h16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (h16)v[i]; b[i] = (h16)v[8 + i]; }
+  stg8(p, a); stg8(p + 8, b);
+}
+
+// ---------------------------------------------------------------- injector -----------------------
+// grid (ceil(rows/256), 12 heads, B passes); thread = one patch row of the pass, K/V of (pass, head) in LDS.
+__global__ __launch_bounds__(256) void inject_attn_fwd_kernel(const h16* __restrict__ q, int rows_per_pass, const float* __restrict__ k,
+                                                              const float* __restrict__ v, int T, h16* __restrict__ a) {
+  __shared__ __attribute__((aligned(16))) float ks[TMAX * AD], vs[TMAX * AD];
+  const int h = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < T * AD; i += 256) {
+    const int t = i / AD, d = i % AD;
+    ks[i] = k[((long)b * T + t) * AE + h * AD + d];
+    vs[i] = v[((long)b * T + t) * AE + h * AD + d];
+  }
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows_per_pass) return;
+  const long m = (long)b * rows_per_pass + r;
+  float qv[AD], acc[AD];
+  load16(q + m * AE + h * AD, qv);
+#pragma unroll
+  for (int d = 0; d < AD; ++d) { qv[d] *= ASCALE; acc[d] = 0.f; }
+  float mx = -1.0e30f, l = 0.f;
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[t * AD + d], s);
+    const float mn = fmaxf(mx, s);
+    const float al = __expf(mx - mn), p = __expf(s - mn);
+    l = l * al + p;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) acc[d] = fmaf(acc[d], al, p * vs[t * AD + d]);
+    mx = mn;
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int d = 0; d < AD; ++d) acc[d] *= inv;
+  store16(a + m * AE + h * AD, acc);
+}
+
+// backward: workgroup = 128 rows x one head.  Phase 1 (thread = row): recompute p, dp = da . v, delta, ds and
+// dq; stage p / ds in LDS.  Phase 2 (thread = (token, dim)): dk[t,d] = sum_rows ds q, dv[t,d] = sum_rows p da,
+// one atomic per (token, dim) per workgroup.
+constexpr int IBR = 128;
+__global__ __launch_bounds__(IBR) void inject_attn_bwd_kernel(const h16* __restrict__ q, const h16* __restrict__ da, int rows_per_pass,
+                                                              const float* __restrict__ k, const float* __restrict__ v, int T,
+                                                              h16* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ks = smem;                       // [T][16]
+  float* vs = ks + TMAX * AD;             // [T][16]
+  float* qs = vs + TMAX * AD;             // [IBR][17]
+  float* das = qs + IBR * 17;             // [IBR][17]
+  float* ps = das + IBR * 17;             // [IBR][T+1]
+  float* dss = ps + IBR * (T + 1);        // [IBR][T+1]
+  const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  for (int i = tid; i < T * AD; i += IBR) {
+    const int t = i / AD, d = i % AD;
+    ks[i] = k[((long)b * T + t) * AE + h * AD + d];
+    vs[i] = v[((long)b * T + t) * AE + h * AD + d];
+  }
+  __syncthreads();
+  const int r = blockIdx.x * IBR + tid;
+  const bool valid = r < rows_per_pass;
+  const long m = (long)b * rows_per_pass + (valid ? r : 0);
+  float qv[AD], dav[AD];
+  if (valid) { load16(q + m * AE + h * AD, qv); load16(da + m * AE + h * AD, dav); }
+  else {
+#pragma unroll
+    for (int d = 0; d < AD; ++d) { qv[d] = 0.f; dav[d] = 0.f; }
+  }
+#pragma unroll
+  for (int d = 0; d < AD; ++d) { qs[tid * 17 + d] = qv[d]; das[tid * 17 + d] = dav[d]; }
+  // pass 1: max and sum
+  float mx = -1.0e30f;
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[t * AD + d], s);
+    s *= ASCALE;
+    ps[tid * (T + 1) + t] = s;
+    mx = fmaxf(mx, s);
+  }
+  float l = 0.f;
+  for (int t = 0; t < T; ++t) { const float p = __expf(ps[tid * (T + 1) + t] - mx); ps[tid * (T + 1) + t] = p; l += p; }
+  const float inv = 1.0f / l;
+  float delta = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float p = ps[tid * (T + 1) + t] * inv;
+    float dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) dp = fmaf(dav[d], vs[t * AD + d], dp);
+    ps[tid * (T + 1) + t] = valid ? p : 0.f;
+    dss[tid * (T + 1) + t] = dp;
+    delta = fmaf(p, dp, delta);
+  }
+  float dqv[AD];
+#pragma unroll
+  for (int d = 0; d < AD; ++d) dqv[d] = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float ds = valid ? ps[tid * (T + 1) + t] * (dss[tid * (T + 1) + t] - delta) * ASCALE : 0.f;
+    dss[tid * (T + 1) + t] = ds;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) dqv[d] = fmaf(ds, ks[t * AD + d], dqv[d]);
+  }
+  if (valid) store16(dq + m * AE + h * AD, dqv);
+  __syncthreads();
+  for (int i = tid; i < T * AD; i += IBR) {
+    const int t = i / AD, d = i % AD;
+    float sk = 0.f, sv = 0.f;
+    for (int rr = 0; rr < IBR; ++rr) {
+      sk = fmaf(dss[rr * (T + 1) + t], qs[rr * 17 + d], sk);
+      sv = fmaf(ps[rr * (T + 1) + t], das[rr * 17 + d], sv);
+    }
+    atomicAdd(&dk[((long)b * T + t) * AE + h * AD + d], sk);
+    atomicAdd(&dv[((long)b * T + t) * AE + h * AD + d], sv);
+  }
+}
+
+// ---------------------------------------------------------------- extractor ----------------------
+// forward: grid (nsplit, 12, B); thread = modal token t; the split's keys are streamed through LDS in tiles of 64.
+constexpr int EKT = 64;
+__global__ __launch_bounds__(128) void extract_attn_fwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv, int T, int L,
+                                                               int keys_per_split, float* __restrict__ part_acc, float* __restrict__ part_ml) {
+  __shared__ __attribute__((aligned(16))) float ks[EKT * AD], vs[EKT * AD];
+  const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int nsplit = gridDim.x;
+  float qv[AD], acc[AD];
+  const bool tv = tid < T;
+#pragma unroll
+  for (int d = 0; d < AD; ++d) { qv[d] = tv ? q[((long)b * T + tid) * AE + h * AD + d] * ASCALE : 0.f; acc[d] = 0.f; }
+  float mx = -1.0e30f, l = 0.f;
+  const int kbeg = sp * keys_per_split, kend = min(L, kbeg + keys_per_split);
+  for (int k0 = kbeg; k0 < kend; k0 += EKT) {
+    __syncthreads();
+    {   // 64 keys x (16 k + 16 v) halves: 128 threads, thread -> (key, k|v)
+      const int key = tid >> 1, which = tid & 1;
+      float tmp[AD];
+      if (k0 + key < kend) load16(kv + ((long)b * L + k0 + key) * (2 * AE) + which * AE + h * AD, tmp);
+      else {
+#pragma unroll
+        for (int d = 0; d < AD; ++d) tmp[d] = 0.f;
+      }
+      float* dst = (which ? vs : ks) + key * AD;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) dst[d] = tmp[d];
+    }
+    __syncthreads();
+    const int nk = min(EKT, kend - k0);
+    for (int j = 0; j < nk; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[j * AD + d], s);
+      const float mn = fmaxf(mx, s);
+      const float al = __expf(mx - mn), p = __expf(s - mn);
+      l = l * al + p;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) acc[d] = fmaf(acc[d], al, p * vs[j * AD + d]);
+      mx = mn;
+    }
+  }
+  if (tv) {
+    const long o = (((long)b * AH + h) * nsplit + sp) * T + tid;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) part_acc[o * AD + d] = acc[d];
+    part_ml[o * 2] = mx; part_ml[o * 2 + 1] = l;
+  }
+}
+
+__global__ void extract_attn_reduce_kernel(const float* __restrict__ part_acc, const float* __restrict__ part_ml, int T, int nsplit,
+                                           float* __restrict__ out, float* __restrict__ lse) {
+  // grid (B*12), block T threads (<=128): thread = token
+  const int bh = blockIdx.x, b = bh / AH, h = bh % AH, t = threadIdx.x;
+  if (t >= T) return;
+  float mx = -1.0e30f;
+  for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, part_ml[(((long)bh * nsplit + s) * T + t) * 2]);
+  float l = 0.f, acc[AD];
+#pragma unroll
+  for (int d = 0; d < AD; ++d) acc[d] = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const long o = ((long)bh * nsplit + s) * T + t;
+    const float w = __expf(part_ml[o * 2] - mx);
+    l += w * part_ml[o * 2 + 1];
+#pragma unroll
+    for (int d = 0; d < AD; ++d) acc[d] = fmaf(w, part_acc[o * AD + d], acc[d]);
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int d = 0; d < AD; ++d) out[((long)b * T + t) * AE + h * AD + d] = acc[d] * inv;
+  lse[((long)b * T + t) * AH + h] = mx + __logf(l);
+}
+
+// backward: grid (ceil(L/128), 12, B); thread = key.  q, dout, lse, delta of the (pass, head) live in LDS.
+// Phase 1: per key loop over tokens -> dk, dv (written as fp16 rows), stage ds[key][t].  Phase 2: thread = (t, d):
+// dq[t,d] += sum_keys ds[key][t] * k[key][d] (one atomic per (t,d) per workgroup).
+constexpr int EBK = 128;
+__global__ __launch_bounds__(EBK) void extract_attn_bwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv,
+                                                               const float* __restrict__ out, const float* __restrict__ lse,
+                                                               const float* __restrict__ dout, int T, int L, float* __restrict__ dq,
+                                                               h16* __restrict__ dkv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* qs = smem;                 // [T][16] (pre-scaled)
+  float* dos = qs + TMAX * AD;      // [T][16]
+  float* ls = dos + TMAX * AD;      // [T]
+  float* dl = ls + TMAX;            // [T]
+  float* kk = dl + TMAX;            // [EBK][17]
+  float* dss = kk + EBK * 17;       // [EBK][T+1]
+  const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  for (int i = tid; i < T * AD; i += EBK) {
+    const int t = i / AD, d = i % AD;
+    qs[i] = q[((long)b * T + t) * AE + h * AD + d] * ASCALE;
+    dos[i] = dout[((long)b * T + t) * AE + h * AD + d];
+  }
+  for (int t = tid; t < T; t += EBK) {
+    ls[t] = lse[((long)b * T + t) * AH + h];
+    float d = 0.f;
+    for (int e = 0; e < AD; ++e) d = fmaf(dout[((long)b * T + t) * AE + h * AD + e], out[((long)b * T + t) * AE + h * AD + e], d);
+    dl[t] = d;
+  }
+  __syncthreads();
+  const int key = blockIdx.x * EBK + tid;
+  const bool valid = key < L;
+  float kvv[AD], vv[AD], dkv_[AD], dvv[AD];
+  if (valid) {
+    load16(kv + ((long)b * L + key) * (2 * AE) + h * AD, kvv);
+    load16(kv + ((long)b * L + key) * (2 * AE) + AE + h * AD, vv);
+  } else {
+#pragma unroll
+    for (int d = 0; d < AD; ++d) { kvv[d] = 0.f; vv[d] = 0.f; }
+  }
+#pragma unroll
+  for (int d = 0; d < AD; ++d) { kk[tid * 17 + d] = kvv[d]; dkv_[d] = 0.f; dvv[d] = 0.f; }
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) { s = fmaf(qs[t * AD + d], kvv[d], s); dp = fmaf(dos[t * AD + d], vv[d], dp); }
+    const float p = valid ? __expf(s - ls[t]) : 0.f;
+    const float ds = p * (dp - dl[t]);
+    dss[tid * (T + 1) + t] = ds * ASCALE;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) { dkv_[d] = fmaf(ds, qs[t * AD + d], dkv_[d]); dvv[d] = fmaf(p, dos[t * AD + d], dvv[d]); }
+  }
+  if (valid) {
+    store16(dkv + ((long)b * L + key) * (2 * AE) + h * AD, dkv_);        // qs already carries the 1/4 scale
+    store16(dkv + ((long)b * L + key) * (2 * AE) + AE + h * AD, dvv);
+  }
+  __syncthreads();
+  for (int i = tid; i < T * AD; i += EBK) {
+    const int t = i / AD, d = i % AD;
+    float s = 0.f;
+    for (int kx = 0; kx < EBK; ++kx) s = fmaf(dss[kx * (T + 1) + t], kk[kx * 17 + d], s);
+    atomicAdd(&dq[((long)b * T + t) * AE + h * AD + d], s);
+  }
+}
+
+// ---------------------------------------------------------------- token self-attention -----------
+// grid (heads, B); thread = query token.  probs [B, heads, T, T] saved for the backward.
+__global__ __launch_bounds__(128) void token_mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                            int T, int E, int heads, float* __restrict__ out, float* __restrict__ probs) {
+  __shared__ float ks[TMAX * AD], vs[TMAX * AD];
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  for (int i = t; i < T * AD; i += 128) {
+    const int tt = i / AD, d = i % AD;
+    ks[i] = k[((long)b * T + tt) * E + h * AD + d];
+    vs[i] = v[((long)b * T + tt) * E + h * AD + d];
+  }
+  __syncthreads();
+  if (t >= T) return;
+  float qv[AD], acc[AD];
+#pragma unroll
+  for (int d = 0; d < AD; ++d) { qv[d] = q[((long)b * T + t) * E + h * AD + d] * ASCALE; acc[d] = 0.f; }
+  float* pr = probs + (((long)b * heads + h) * T + t) * T;
+  float mx = -1.0e30f;
+  for (int j = 0; j < T; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[j * AD + d], s);
+    pr[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  float l = 0.f;
+  for (int j = 0; j < T; ++j) { const float p = __expf(pr[j] - mx); pr[j] = p; l += p; }
+  const float inv = 1.0f / l;
+  for (int j = 0; j < T; ++j) {
+    const float p = pr[j] * inv;
+    pr[j] = p;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) acc[d] = fmaf(p, vs[j * AD + d], acc[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < AD; ++d) out[((long)b * T + t) * E + h * AD + d] = acc[d];
+}
+
+__global__ __launch_bounds__(128) void token_mha_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                            const float* __restrict__ probs, const float* __restrict__ dout, int T, int E,
+                                                            int heads, float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* qs = smem;                 // [T][16]
+  float* ks = qs + TMAX * AD;
+  float* vs = ks + TMAX * AD;
+  float* dos = vs + TMAX * AD;
+  float* dss = dos + TMAX * AD;     // [T][T+1]  dS (already scaled)
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  for (int i = t; i < T * AD; i += 128) {
+    const int tt = i / AD, d = i % AD;
+    const long o = ((long)b * T + tt) * E + h * AD + d;
+    qs[i] = q[o]; ks[i] = k[o]; vs[i] = v[o]; dos[i] = dout[o];
+  }
+  __syncthreads();
+  const float* pbase = probs + ((long)b * heads + h) * T * T;
+  if (t < T) {
+    const float* pr = pbase + (long)t * T;
+    float delta = 0.f;
+    for (int j = 0; j < T; ++j) {
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) dp = fmaf(dos[t * AD + d], vs[j * AD + d], dp);
+      dss[t * (T + 1) + j] = dp;
+      delta = fmaf(pr[j], dp, delta);
+    }
+    float dqv[AD];
+#pragma unroll
+    for (int d = 0; d < AD; ++d) dqv[d] = 0.f;
+    for (int j = 0; j < T; ++j) {
+      const float ds = pr[j] * (dss[t * (T + 1) + j] - delta) * ASCALE;
+      dss[t * (T + 1) + j] = ds;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) dqv[d] = fmaf(ds, ks[j * AD + d], dqv[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < AD; ++d) dq[((long)b * T + t) * E + h * AD + d] = dqv[d];
+  }
+  __syncthreads();
+  if (t < T) {   // thread = key j = t
+    float dkv_[AD], dvv[AD];
+#pragma unroll
+    for (int d = 0; d < AD; ++d) { dkv_[d] = 0.f; dvv[d] = 0.f; }
+    for (int i = 0; i < T; ++i) {
+      const float ds = dss[i * (T + 1) + t], p = pbase[(long)i * T + t];
+#pragma unroll
+      for (int d = 0; d < AD; ++d) { dkv_[d] = fmaf(ds, qs[i * AD + d], dkv_[d]); dvv[d] = fmaf(p, dos[i * AD + d], dvv[d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < AD; ++d) {
+      dk[((long)b * T + t) * E + h * AD + d] = dkv_[d];
+      dv[((long)b * T + t) * E + h * AD + d] = dvv[d];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_inject_attn_fwd(const mt_half* q, int M, int rows_per_pass, const float* k, const float* v, int T,
+                                  mt_half* a, mt_stream_t stream) {
+  if (!q || !k || !v || !a || M <= 0 || rows_per_pass <= 0 || M % rows_per_pass || T < 1 || T > TMAX) return MT_ERR_BAD_ARG;
+  const int B = M / rows_per_pass;
+  hipLaunchKernelGGL(inject_attn_fwd_kernel, dim3(cdiv(rows_per_pass, 256), AH, B), dim3(256), 0, (hipStream_t)stream,
+                     (const h16*)q, rows_per_pass, k, v, T, (h16*)a);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_inject_attn_bwd(const mt_half* q, const mt_half* da, int M, int rows_per_pass, const float* k,
+                                  const float* v, int T, mt_half* dq, float* dk, float* dv, mt_stream_t stream) {
+  if (!q || !da || !k || !v || !dq || !dk || !dv || M <= 0 || rows_per_pass <= 0 || M % rows_per_pass || T < 1 || T > TMAX)
+    return MT_ERR_BAD_ARG;
+  const int B = M / rows_per_pass;
+  const size_t shm = sizeof(float) * (2 * TMAX * AD + 2 * IBR * 17 + 2 * IBR * (T + 1));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)inject_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(inject_attn_bwd_kernel, dim3(cdiv(rows_per_pass, IBR), AH, B), dim3(IBR), shm, (hipStream_t)stream,
+                     (const h16*)q, (const h16*)da, rows_per_pass, k, v, T, (h16*)dq, dk, dv);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_extract_attn_fwd(const float* q, const mt_half* kv, int B, int T, int L, float* out, float* lse,
+                                   float* part_acc, float* part_ml, int nsplit, mt_stream_t stream) {
+  if (!q || !kv || !out || !lse || !part_acc || !part_ml || B < 1 || T < 1 || T > TMAX || L < 1 || nsplit < 1) return MT_ERR_BAD_ARG;
+  const int kps = cdiv(cdiv(L, nsplit), EKT) * EKT;
+  if ((long)kps * (nsplit - 1) >= L && nsplit > 1) return MT_ERR_BAD_ARG;   // every split must own >= 1 key
+  hipLaunchKernelGGL(extract_attn_fwd_kernel, dim3(nsplit, AH, B), dim3(128), 0, (hipStream_t)stream, q, (const h16*)kv, T, L,
+                     kps, part_acc, part_ml);
+  hipLaunchKernelGGL(extract_attn_reduce_kernel, dim3(B * AH), dim3(TMAX), 0, (hipStream_t)stream, part_acc, part_ml, T,
+                     nsplit, out, lse);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_extract_attn_bwd(const float* q, const mt_half* kv, const float* out, const float* lse,
+                                   const float* dout, int B, int T, int L, float* dq, mt_half* dkv, mt_stream_t stream) {
+  if (!q || !kv || !out || !lse || !dout || !dq || !dkv || B < 1 || T < 1 || T > TMAX || L < 1) return MT_ERR_BAD_ARG;
+  const size_t shm = sizeof(float) * (2 * TMAX * AD + 2 * TMAX + EBK * 17 + EBK * (T + 1));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)extract_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(extract_attn_bwd_kernel, dim3(cdiv(L, EBK), AH, B), dim3(EBK), shm, (hipStream_t)stream, q,
+                     (const h16*)kv, out, lse, dout, T, L, dq, (h16*)dkv);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_token_mha_fwd(const float* q, const float* k, const float* v, int B, int T, int E, int heads,
+                                float* out, float* probs, mt_stream_t stream) {
+  if (!q || !k || !v || !out || !probs || B < 1 || T < 1 || T > TMAX || E != heads * AD) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(token_mha_fwd_kernel, dim3(heads, B), dim3(128), 0, (hipStream_t)stream, q, k, v, T, E, heads, out, probs);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_token_mha_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
+                                int B, int T, int E, int heads, float* dq, float* dk, float* dv, mt_stream_t stream) {
+  if (!q || !k || !v || !probs || !dout || !dq || !dk || !dv || B < 1 || T < 1 || T > TMAX || E != heads * AD) return MT_ERR_BAD_ARG;
+  const size_t shm = sizeof(float) * (4 * TMAX * AD + T * (T + 1));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)token_mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(token_mha_bwd_kernel, dim3(heads, B), dim3(128), shm, (hipStream_t)stream, q, k, v, probs, dout, T, E,
+                     heads, dq, dk, dv);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}

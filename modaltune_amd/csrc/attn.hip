@@ -1,0 +1,767 @@
+// Dilated attention (LongNet) for the frozen Prov-GigaPath backbone: 16 heads x 48, five branches.
+//
+// Reference semantics (torchscale/component/dilated_attention.py:22-59,82-144,212-255):
+//   branch (s, r): the sequence is cut in segments of s tokens; head h (group g = h / (16/r)) attends, inside
+//   each segment, over the positions g, g+r, g+2r, ... (n = ceil(s/r) entries).  Entries past the segment end
+//   or past N are ALL-ZERO rows that still act as keys (logit 0, value 0).  Branch outputs are mixed with
+//   softmax-over-branches of the per-(position, head) LSE, treated as constants in backward.
+//
+// Forward kernel: one workgroup = 128 queries (4 waves x 32) of one (pass, branch, segment, head); K/V tiles of
+// 64 keys are gathered in place from the fused qkv activation (no diag_embed / pad copies) into LDS.
+// Per wave, "swapped" products keep the softmax lane-local (query = lane, keys = registers):
+//   S^T[key, q] = K . Q^T           v_mfma_f32_32x32x16_f16, K rows from LDS (ds_read_b128), Q^T in registers
+//   O^T[d, q]  += V^T[d, key] . P^T  P^T taken straight from the S accumulators (no LDS round trip),
+//                                    V^T via ds_read_b64_tr_b16; V carries a ones column so O^T row 48 = sum(P)
+#include "common.h"
+
+namespace {
+
+constexpr int H = 16, HD = 48, DM = 768, QKV_LD = 2304;
+constexpr int KSTR = 56;    // halves per K-layout LDS row (112 B: conflict-free ds_read_b128 row reads)
+constexpr int VSTR = 96;    // halves per V-layout LDS row (192 B: conflict-free ds_read_b64_tr_b16)
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr float NEG_BIG = -1.0e30f;
+
+struct Plan {
+  int nbranch, N, B;
+  int seg[MT_MAX_BRANCHES], ratio[MT_MAX_BRANCHES], nseg[MT_MAX_BRANCHES], n[MT_MAX_BRANCHES];
+  int order[MT_MAX_BRANCHES], qtiles[MT_MAX_BRANCHES], blk_off[MT_MAX_BRANCHES + 1];
+};
+
+Plan make_plan(const MtDilatedPlan* p, int qtile) {
+  Plan d;
+  d.nbranch = p->nbranch; d.N = p->N; d.B = p->B;
+  for (int i = 0; i < p->nbranch; ++i) {
+    d.seg[i] = p->seg[i]; d.ratio[i] = p->ratio[i]; d.nseg[i] = p->nseg[i]; d.n[i] = p->n[i];
+    d.order[i] = i;
+    d.qtiles[i] = cdiv(p->n[i], qtile);
+  }
+  // longest sparse sequences first (their workgroups run longest)
+  for (int i = 0; i < d.nbranch; ++i)
+    for (int j = i + 1; j < d.nbranch; ++j)
+      if (d.n[d.order[j]] > d.n[d.order[i]]) { int t = d.order[i]; d.order[i] = d.order[j]; d.order[j] = t; }
+  d.blk_off[0] = 0;
+  for (int i = 0; i < d.nbranch; ++i) {
+    const int b = d.order[i];
+    d.blk_off[i + 1] = d.blk_off[i] + d.B * d.nseg[b] * H * d.qtiles[b];
+  }
+  return d;
+}
+
+bool plan_ok(const MtDilatedPlan* p) {
+  if (!p || p->nbranch < 1 || p->nbranch > MT_MAX_BRANCHES || p->N < 1 || p->B < 1) return false;
+  for (int i = 0; i < p->nbranch; ++i) {
+    const int r = p->ratio[i], s = p->seg[i];
+    if (r < 1 || r > H || (H % r) != 0 || s < 1 || s > p->N) return false;
+    if (p->nseg[i] != cdiv(p->N, s) || p->n[i] != cdiv(s, r)) return false;
+  }
+  return true;
+}
+
+struct WorkItem { int br, b, j, h, qt; };
+
+MT_DEVINL int xcd_remap(int bid, int nwg) {
+  const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+}
+
+MT_DEVINL WorkItem decode(const Plan& p, int bid) {
+  int oi = 0;
+#pragma unroll
+  for (int i = 1; i < MT_MAX_BRANCHES; ++i)
+    if (i < p.nbranch && bid >= p.blk_off[i]) oi = i;
+  WorkItem w;
+  w.br = p.order[oi];
+  int local = bid - p.blk_off[oi];
+  w.qt = local % p.qtiles[w.br]; local /= p.qtiles[w.br];
+  w.h = local % H; local /= H;
+  w.j = local % p.nseg[w.br];
+  w.b = local / p.nseg[w.br];
+  return w;
+}
+
+MT_DEVINL h16x4 lds_tr4(const h16* p) {
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)p);
+  return __builtin_bit_cast(h16x4, r);
+}
+MT_DEVINL h16x8 cat8(h16x4 lo, h16x4 hi) { return (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+
+// geometry of one (branch, segment, head) sparse sequence
+struct Seq {
+  int n, s, dr, r, seg_base, N;
+  long row_base;   // b * N
+  MT_DEVINL bool valid(int i) const {
+    const int loc = r + i * dr;
+    return i < n && loc < s && seg_base + loc < N;
+  }
+  MT_DEVINL long row(int i) const { return row_base + seg_base + r + (long)i * dr; }
+};
+
+MT_DEVINL Seq make_seq(const Plan& p, const WorkItem& w) {
+  Seq q;
+  q.n = p.n[w.br]; q.s = p.seg[w.br]; q.dr = p.ratio[w.br];
+  q.r = w.h / (H / q.dr);
+  q.seg_base = w.j * q.s; q.N = p.N; q.row_base = (long)w.b * p.N;
+  return q;
+}
+
+// Per-thread staging slots for a 64-row x 48-col fp16 tile = 384 chunks of 16 B: chunk tid, and (tid < 128) chunk 256+tid.
+struct StageIdx {
+  int row0, part0, row1, part1; bool has1;
+  MT_DEVINL StageIdx(int tid) {
+    row0 = tid / 6; part0 = tid - row0 * 6;
+    const int c = 256 + tid;
+    row1 = c / 6; part1 = c - row1 * 6; has1 = tid < 128;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __restrict__ qkv, Plan p, h16* __restrict__ o_br,
+                                                               float* __restrict__ lse_br) {
+  __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];
+  __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * VSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const WorkItem w = decode(p, xcd_remap(blockIdx.x, gridDim.x));
+  const Seq sq = make_seq(p, w);
+  const long M = (long)p.B * p.N;
+  const float c = 0.14433756729740643f * LOG2E;   // 48^-1/2 * log2(e)
+
+  // ones columns (d = 48 and 52) so that O^T row 48 (both lane halves) accumulates sum(P); written once
+  if (tid < 128) {
+    const int buf = tid >> 6, row = tid & 63;
+    h16x8 one = {(h16)1.f, 0, 0, 0, (h16)1.f, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<h16x8*>(&Vs[buf][row * VSTR + 48]) = one;
+    *reinterpret_cast<h16x8*>(&Vs[buf][row * VSTR + 56]) = zero;
+  }
+
+  // Q^T fragments (B operand): lane = query, element j of k-step ks = Q[q][16 ks + 8 hh + j]
+  const int iq = w.qt * 128 + wave * 32 + l31;
+  const bool qvalid = sq.valid(iq);
+  const long qrow = qvalid ? sq.row(iq) : 0;
+  h16x8 qf[3];
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+    qf[ks] = qvalid ? ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8) : zero8;
+
+  const StageIdx st(tid);
+  h16x8 rk0, rk1, rv0, rv1;
+  auto gload = [&](int kb) {
+    const int i0 = kb + st.row0;
+    if (sq.valid(i0)) {
+      const h16* base = qkv + sq.row(i0) * QKV_LD + w.h * HD + st.part0 * 8;
+      rk0 = ldg8(base + DM); rv0 = ldg8(base + 2 * DM);
+    } else { rk0 = zero8; rv0 = zero8; }
+    if (st.has1) {
+      const int i1 = kb + st.row1;
+      if (sq.valid(i1)) {
+        const h16* base = qkv + sq.row(i1) * QKV_LD + w.h * HD + st.part1 * 8;
+        rk1 = ldg8(base + DM); rv1 = ldg8(base + 2 * DM);
+      } else { rk1 = zero8; rv1 = zero8; }
+    }
+  };
+  auto lstore = [&](int buf) {
+    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = rk0;
+    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = rv0;
+    if (st.has1) {
+      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = rk1;
+      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = rv1;
+    }
+  };
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+  float m_run = NEG_BIG;
+
+  const int ntile = (sq.n + 63) / 64;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int t = 0; t < ntile; ++t) {
+    const int buf = t & 1, kb = t * 64;
+    if (t + 1 < ntile) gload(kb + 64);
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Ks[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
+      }
+    }
+    // scaled logits (log2 domain); keys >= n are tile padding (excluded); zero-padded keys keep logit 0
+    float mx = NEG_BIG;
+    const bool tail = kb + 64 > sq.n;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = s[sub][i] * c;
+        if (tail) {
+          const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kidx >= sq.n) v = NEG_BIG;
+        }
+        s[sub][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+    }
+    m_run = m_new;
+    h16x8 pf[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[sub][s2][e] = (h16)__builtin_amdgcn_exp2f(s[sub][8 * s2 + e] - m_new);
+    // O^T += V^T . P^T ; A fragment element e of lane half hh = V[key 16 s2 + 8 (e>>2) + 4 hh + (e&3)][d = lane & 31]
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const h16* vrow = &Vs[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
+        const h16x8 v0 = cat8(lds_tr4(vrow), lds_tr4(vrow + 8 * VSTR));
+        const h16x8 v1 = cat8(lds_tr4(vrow + 32), lds_tr4(vrow + 8 * VSTR + 32));
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[sub][s2], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[sub][s2], o1, 0, 0, 0);
+      }
+    if (t + 1 < ntile) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (qvalid) {
+    const float l = o1[8];           // O^T row 48 (lane half 0) / row 52 (lane half 1): both carry sum(P)
+    const float inv = 1.0f / l;
+    h16* orow = o_br + ((long)w.br * M + qrow) * DM + w.h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      h16x4 v = {(h16)(o0[4 * gq] * inv), (h16)(o0[4 * gq + 1] * inv), (h16)(o0[4 * gq + 2] * inv), (h16)(o0[4 * gq + 3] * inv)};
+      *reinterpret_cast<h16x4*>(orow + 8 * gq + 4 * hh) = v;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      h16x4 v = {(h16)(o1[4 * gq] * inv), (h16)(o1[4 * gq + 1] * inv), (h16)(o1[4 * gq + 2] * inv), (h16)(o1[4 * gq + 3] * inv)};
+      *reinterpret_cast<h16x4*>(orow + 32 + 8 * gq + 4 * hh) = v;
+    }
+    if (hh == 0) lse_br[((long)w.br * M + qrow) * H + w.h] = (m_run + __log2f(l)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// branch mix + inner_attn_ln (forward) : one wave per token row (16 heads x 48)
+// lane handles 12 consecutive columns -> exactly one head (4 lanes per head)
+// ------------------------------------------------------------------------------------------------
+MT_DEVINL bool covers(const Plan& p, int br, int pos, int h) {
+  const int dr = p.ratio[br];
+  const int loc = pos % p.seg[br];
+  return (loc % dr) == h / (H / dr);
+}
+
+__global__ __launch_bounds__(256) void mix_ln_fwd_kernel(const h16* __restrict__ o_br, const float* __restrict__ lse_br, Plan p,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                         h16* __restrict__ y, float* __restrict__ stats, float* __restrict__ lse_tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long M = (long)p.B * p.N;
+  const int h = lane >> 2, c0 = lane * 12;
+  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+    const int pos = (int)(m % p.N);
+    float lse[MT_MAX_BRANCHES];
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int b = 0; b < MT_MAX_BRANCHES; ++b) {
+      lse[b] = NEG_BIG;
+      if (b < p.nbranch && covers(p, b, pos, h)) lse[b] = lse_br[((long)b * M + m) * H + h];
+      mx = fmaxf(mx, lse[b]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int b = 0; b < MT_MAX_BRANCHES; ++b) den += (lse[b] > -1.0e29f) ? __expf(lse[b] - mx) : 0.f;
+    const float tot = mx + __logf(den);
+    float v[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < MT_MAX_BRANCHES; ++b) {
+      if (b < p.nbranch && lse[b] > -1.0e29f) {
+        const float wgt = __expf(lse[b] - tot);
+        const h16* src = o_br + ((long)b * M + m) * DM + c0;
+        const h16x4 a0 = *reinterpret_cast<const h16x4*>(src), a1 = *reinterpret_cast<const h16x4*>(src + 4),
+                    a2 = *reinterpret_cast<const h16x4*>(src + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += wgt * (float)a0[e]; v[4 + e] += wgt * (float)a1[e]; v[8 + e] += wgt * (float)a2[e]; }
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) s += v[e];
+    const float mean = wave_sum(s) * (1.0f / DM);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) { const float d = v[e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / DM) + 1e-5f);
+    h16* dst = y + m * DM + c0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      h16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (h16)((v[4 * k + e] - mean) * rstd * ln_w[c0 + 4 * k + e] + ln_b[c0 + 4 * k + e]);
+      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
+    }
+    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+    if ((lane & 3) == 0) lse_tot[m * H + h] = tot;
+  }
+}
+
+// backward of mix + LN: recompute mixed from the branch outputs, LayerNorm backward (frozen affine: no dw/db),
+// dmixed (fp16) and delta_b = sum_d dmixed * O_b per (row, head, branch).
+__global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__ dy, const h16* __restrict__ o_br,
+                                                         const float* __restrict__ lse_br, const float* __restrict__ lse_tot, Plan p,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ stats,
+                                                         h16* __restrict__ dmixed, float* __restrict__ delta_br) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long M = (long)p.B * p.N;
+  const int h = lane >> 2, c0 = lane * 12;
+  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+    const int pos = (int)(m % p.N);
+    const float tot = lse_tot[m * H + h];
+    float ob[MT_MAX_BRANCHES][12];
+    bool cov[MT_MAX_BRANCHES];
+    float v[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < MT_MAX_BRANCHES; ++b) {
+      cov[b] = b < p.nbranch && covers(p, b, pos, h);
+      if (cov[b]) {
+        const float wgt = __expf(lse_br[((long)b * M + m) * H + h] - tot);
+        const h16* src = o_br + ((long)b * M + m) * DM + c0;
+        const h16x4 a0 = *reinterpret_cast<const h16x4*>(src), a1 = *reinterpret_cast<const h16x4*>(src + 4),
+                    a2 = *reinterpret_cast<const h16x4*>(src + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ob[b][e] = (float)a0[e]; ob[b][4 + e] = (float)a1[e]; ob[b][8 + e] = (float)a2[e]; }
+#pragma unroll
+        for (int e = 0; e < 12; ++e) v[e] += wgt * ob[b][e];
+      }
+    }
+    const float mean = stats[2 * m], rstd = stats[2 * m + 1];
+    const h16* dyr = dy + m * DM + c0;
+    float g[12], xh[12];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const h16x4 d = *reinterpret_cast<const h16x4*>(dyr + 4 * k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * k + e;
+        xh[i] = (v[i] - mean) * rstd;
+        g[i] = (float)d[e] * ln_w[c0 + i];
+        s1 += g[i]; s2 += g[i] * xh[i];
+      }
+    }
+    const float c1 = wave_sum(s1) * (1.0f / DM), c2 = wave_sum(s2) * (1.0f / DM);
+    float dm[12];
+    h16* dst = dmixed + m * DM + c0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      h16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * k + e;
+        dm[i] = rstd * (g[i] - c1 - xh[i] * c2);
+        o[e] = (h16)dm[i];
+        dm[i] = (float)o[e];          // delta must match the fp16 dmixed the attention backward consumes
+      }
+      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
+    }
+#pragma unroll
+    for (int b = 0; b < MT_MAX_BRANCHES; ++b) {
+      if (b < p.nbranch) {          // uniform over the wave
+        float d = 0.f;
+        if (cov[b]) {
+#pragma unroll
+          for (int e = 0; e < 12; ++e) d += dm[e] * ob[b][e];
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        if ((lane & 3) == 0 && cov[b]) delta_br[((long)b * M + m) * H + h] = d;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, kernel Q: dQ.  Same decomposition as the forward (query = lane).
+//   P~^T = exp2(c S^T - L2[q])            (L2 = lse_tot * log2e; equals w_b * P_b)
+//   dP^T[key,q] = V . dO^T                 V rows from LDS, dO^T in registers
+//   dS^T = P~^T (dP^T - delta_b[q]) / sqrt(48)
+//   dQ^T[d,q] += K^T[d,key] . dS^T         K^T via transposed LDS reads
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
+                                                                 const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
+                                                                 Plan p, int br_only, int accumulate, float* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];   // row-read layout
+  __shared__ __attribute__((aligned(16))) h16 Kt[2][64 * VSTR];   // transposed-read layout
+  __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * KSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  WorkItem w;
+  {
+    int local = blockIdx.x;
+    w.br = br_only;
+    w.qt = local % p.qtiles[w.br]; local /= p.qtiles[w.br];
+    w.h = local % H; local /= H;
+    w.j = local % p.nseg[w.br];
+    w.b = local / p.nseg[w.br];
+  }
+  const Seq sq = make_seq(p, w);
+  const long M = (long)p.B * p.N;
+  const float scale = 0.14433756729740643f, c = scale * LOG2E;
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  if (tid < 128) {   // zero the never-written columns 48..63 of the transposed-layout tile (read as d rows 48..63)
+    const int buf = tid >> 6, row = tid & 63;
+    *reinterpret_cast<h16x8*>(&Kt[buf][row * VSTR + 48]) = zero8;
+    *reinterpret_cast<h16x8*>(&Kt[buf][row * VSTR + 56]) = zero8;
+  }
+
+  const int iq = w.qt * 128 + wave * 32 + l31;
+  const bool qvalid = sq.valid(iq);
+  const long qrow = qvalid ? sq.row(iq) : 0;
+  h16x8 qf[3], dof[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    qf[ks] = qvalid ? ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8) : zero8;
+    dof[ks] = qvalid ? ldg8(dmixed + qrow * DM + w.h * HD + ks * 16 + hh * 8) : zero8;
+  }
+  // invalid queries: L2 = +big -> P~ = 0
+  const float L2 = qvalid ? lse_tot[qrow * H + w.h] * LOG2E : 1.0e30f;
+  const float delta = qvalid ? delta_br[((long)w.br * M + qrow) * H + w.h] : 0.f;
+
+  const StageIdx st(tid);
+  h16x8 rk0, rk1, rv0, rv1;
+  auto gload = [&](int kb) {
+    const int i0 = kb + st.row0;
+    if (sq.valid(i0)) {
+      const h16* base = qkv + sq.row(i0) * QKV_LD + w.h * HD + st.part0 * 8;
+      rk0 = ldg8(base + DM); rv0 = ldg8(base + 2 * DM);
+    } else { rk0 = zero8; rv0 = zero8; }
+    if (st.has1) {
+      const int i1 = kb + st.row1;
+      if (sq.valid(i1)) {
+        const h16* base = qkv + sq.row(i1) * QKV_LD + w.h * HD + st.part1 * 8;
+        rk1 = ldg8(base + DM); rv1 = ldg8(base + 2 * DM);
+      } else { rk1 = zero8; rv1 = zero8; }
+    }
+  };
+  auto lstore = [&](int buf) {
+    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = rk0;
+    *reinterpret_cast<h16x8*>(&Kt[buf][st.row0 * VSTR + st.part0 * 8]) = rk0;
+    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * KSTR + st.part0 * 8]) = rv0;
+    if (st.has1) {
+      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = rk1;
+      *reinterpret_cast<h16x8*>(&Kt[buf][st.row1 * VSTR + st.part1 * 8]) = rk1;
+      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * KSTR + st.part1 * 8]) = rv1;
+    }
+  };
+
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dq0[i] = 0.f; dq1[i] = 0.f; }
+  const int ntile = (sq.n + 63) / 64;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int t = 0; t < ntile; ++t) {
+    const int buf = t & 1, kb = t * 64;
+    if (t + 1 < ntile) gload(kb + 64);
+    const bool tail = kb + 64 > sq.n;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Ks[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        const h16x8 vf = *reinterpret_cast<const h16x8*>(&Vs[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
+      }
+      h16x8 dsf[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float pt = __builtin_amdgcn_exp2f(s[i] * c - L2);
+        if (tail) {
+          const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kidx >= sq.n) pt = 0.f;
+        }
+        dsf[i >> 3][i & 7] = (h16)(pt * (dp[i] - delta) * scale);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const h16* krow = &Kt[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
+        const h16x8 k0 = cat8(lds_tr4(krow), lds_tr4(krow + 8 * VSTR));
+        const h16x8 k1 = cat8(lds_tr4(krow + 32), lds_tr4(krow + 8 * VSTR + 32));
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, dsf[s2], dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, dsf[s2], dq1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntile) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (qvalid) {
+    float* out = dqkv + qrow * QKV_LD + w.h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      f32x4 v = {dq0[4 * gq], dq0[4 * gq + 1], dq0[4 * gq + 2], dq0[4 * gq + 3]};
+      f32x4* dst = reinterpret_cast<f32x4*>(out + 8 * gq + 4 * hh);
+      if (accumulate) v += *dst;
+      *dst = v;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      f32x4 v = {dq1[4 * gq], dq1[4 * gq + 1], dq1[4 * gq + 2], dq1[4 * gq + 3]};
+      f32x4* dst = reinterpret_cast<f32x4*>(out + 32 + 8 * gq + 4 * hh);
+      if (accumulate) v += *dst;
+      *dst = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, kernel KV: dK, dV.  One workgroup = 128 keys (key = lane) of one (pass, branch, segment, head),
+// sweeping the queries of the same sparse sequence in tiles of 64.
+//   S[q,key]  = Q . K^T            Q rows from LDS, K^T in registers
+//   dP[q,key] = dO . V^T           dO rows from LDS, V^T in registers
+//   P~ = exp2(c S - L2[q]) ; dS = P~ (dP - delta[q]) / sqrt(48)
+//   dV^T[d,key] += dO^T[d,q] . P~   ; dK^T[d,key] += Q^T[d,q] . dS      (transposed LDS reads of dO / Q)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
+                                                                  const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
+                                                                  Plan p, int br_only, int accumulate, float* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) h16 Qs[64 * KSTR];
+  __shared__ __attribute__((aligned(16))) h16 Qt[64 * VSTR];
+  __shared__ __attribute__((aligned(16))) h16 Ds[64 * KSTR];
+  __shared__ __attribute__((aligned(16))) h16 Dt[64 * VSTR];
+  __shared__ __attribute__((aligned(16))) float L2s[64];
+  __shared__ __attribute__((aligned(16))) float Dls[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  WorkItem w;
+  {
+    int local = blockIdx.x;
+    w.br = br_only;
+    w.qt = local % p.qtiles[w.br]; local /= p.qtiles[w.br];
+    w.h = local % H; local /= H;
+    w.j = local % p.nseg[w.br];
+    w.b = local / p.nseg[w.br];
+  }
+  const Seq sq = make_seq(p, w);
+  const long M = (long)p.B * p.N;
+  const float scale = 0.14433756729740643f, c = scale * LOG2E;
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  if (tid < 64) {
+    *reinterpret_cast<h16x8*>(&Qt[tid * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Qt[tid * VSTR + 56]) = zero8;
+    *reinterpret_cast<h16x8*>(&Dt[tid * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Dt[tid * VSTR + 56]) = zero8;
+  }
+
+  // this lane's key: K^T / V^T fragments (B operands), element j of k-step ks = K[key][16 ks + 8 hh + j]
+  const int ik = w.qt * 128 + wave * 32 + l31;
+  const bool kvalid = sq.valid(ik);
+  const long krow = kvalid ? sq.row(ik) : 0;
+  h16x8 kf[3], vf[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    kf[ks] = kvalid ? ldg8(qkv + krow * QKV_LD + DM + w.h * HD + ks * 16 + hh * 8) : zero8;
+    vf[ks] = kvalid ? ldg8(qkv + krow * QKV_LD + 2 * DM + w.h * HD + ks * 16 + hh * 8) : zero8;
+  }
+
+  const StageIdx st(tid);
+  h16x8 rq0, rq1, rd0, rd1;
+  float rl2 = 0.f, rdl = 0.f;
+  auto gload = [&](int qb) {
+    const int i0 = qb + st.row0;
+    if (sq.valid(i0)) {
+      const long r = sq.row(i0);
+      rq0 = ldg8(qkv + r * QKV_LD + w.h * HD + st.part0 * 8);
+      rd0 = ldg8(dmixed + r * DM + w.h * HD + st.part0 * 8);
+    } else { rq0 = zero8; rd0 = zero8; }
+    if (st.has1) {
+      const int i1 = qb + st.row1;
+      if (sq.valid(i1)) {
+        const long r = sq.row(i1);
+        rq1 = ldg8(qkv + r * QKV_LD + w.h * HD + st.part1 * 8);
+        rd1 = ldg8(dmixed + r * DM + w.h * HD + st.part1 * 8);
+      } else { rq1 = zero8; rd1 = zero8; }
+    }
+    if (tid < 64) {
+      const int i = qb + tid;
+      if (sq.valid(i)) {
+        const long r = sq.row(i);
+        rl2 = lse_tot[r * H + w.h] * LOG2E;
+        rdl = delta_br[((long)w.br * M + r) * H + w.h];
+      } else { rl2 = 1.0e30f; rdl = 0.f; }     // padded / out-of-range queries contribute nothing
+    }
+  };
+  auto lstore = [&]() {
+    *reinterpret_cast<h16x8*>(&Qs[st.row0 * KSTR + st.part0 * 8]) = rq0;
+    *reinterpret_cast<h16x8*>(&Qt[st.row0 * VSTR + st.part0 * 8]) = rq0;
+    *reinterpret_cast<h16x8*>(&Ds[st.row0 * KSTR + st.part0 * 8]) = rd0;
+    *reinterpret_cast<h16x8*>(&Dt[st.row0 * VSTR + st.part0 * 8]) = rd0;
+    if (st.has1) {
+      *reinterpret_cast<h16x8*>(&Qs[st.row1 * KSTR + st.part1 * 8]) = rq1;
+      *reinterpret_cast<h16x8*>(&Qt[st.row1 * VSTR + st.part1 * 8]) = rq1;
+      *reinterpret_cast<h16x8*>(&Ds[st.row1 * KSTR + st.part1 * 8]) = rd1;
+      *reinterpret_cast<h16x8*>(&Dt[st.row1 * VSTR + st.part1 * 8]) = rd1;
+    }
+    if (tid < 64) { L2s[tid] = rl2; Dls[tid] = rdl; }
+  };
+
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
+  const int ntile = (sq.n + 63) / 64;
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  gload(0);
+  for (int t = 0; t < ntile; ++t) {
+    __syncthreads();            // previous tile fully consumed
+    lstore();
+    __syncthreads();
+    if (t + 1 < ntile) gload((t + 1) * 64);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qs[(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s, 0, 0, 0);
+        const h16x8 da = *reinterpret_cast<const h16x8*>(&Ds[(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp, 0, 0, 0);
+      }
+      // rows of the accumulators are queries: row(i) = (i&3) + 8 (i>>2) + 4 hh
+      h16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(&L2s[sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(&Dls[sub * 32 + 8 * g4 + 4 * hh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g4 + e;
+          const float pt = __builtin_amdgcn_exp2f(s[i] * c - l2[e]);
+          pf[i >> 3][i & 7] = (h16)pt;
+          dsf[i >> 3][i & 7] = (h16)(pt * (dp[i] - dl[e]) * scale);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int roff = (sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp;
+        const h16x8 d0 = cat8(lds_tr4(&Dt[roff]), lds_tr4(&Dt[roff + 8 * VSTR]));
+        const h16x8 d1 = cat8(lds_tr4(&Dt[roff + 32]), lds_tr4(&Dt[roff + 8 * VSTR + 32]));
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, pf[s2], dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, pf[s2], dv1, 0, 0, 0);
+        const h16x8 q0 = cat8(lds_tr4(&Qt[roff]), lds_tr4(&Qt[roff + 8 * VSTR]));
+        const h16x8 q1 = cat8(lds_tr4(&Qt[roff + 32]), lds_tr4(&Qt[roff + 8 * VSTR + 32]));
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, dsf[s2], dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, dsf[s2], dk1, 0, 0, 0);
+      }
+    }
+  }
+  if (kvalid) {
+    float* outk = dqkv + krow * QKV_LD + DM + w.h * HD;
+    float* outv = outk + DM;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      f32x4 a = {dk0[4 * gq], dk0[4 * gq + 1], dk0[4 * gq + 2], dk0[4 * gq + 3]};
+      f32x4 b = {dv0[4 * gq], dv0[4 * gq + 1], dv0[4 * gq + 2], dv0[4 * gq + 3]};
+      f32x4* pk = reinterpret_cast<f32x4*>(outk + 8 * gq + 4 * hh);
+      f32x4* pv = reinterpret_cast<f32x4*>(outv + 8 * gq + 4 * hh);
+      if (accumulate) { a += *pk; b += *pv; }
+      *pk = a; *pv = b;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      f32x4 a = {dk1[4 * gq], dk1[4 * gq + 1], dk1[4 * gq + 2], dk1[4 * gq + 3]};
+      f32x4 b = {dv1[4 * gq], dv1[4 * gq + 1], dv1[4 * gq + 2], dv1[4 * gq + 3]};
+      f32x4* pk = reinterpret_cast<f32x4*>(outk + 32 + 8 * gq + 4 * hh);
+      f32x4* pv = reinterpret_cast<f32x4*>(outv + 32 + 8 * gq + 4 * hh);
+      if (accumulate) { a += *pk; b += *pv; }
+      *pk = a; *pv = b;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_dilated_attn_fwd(const mt_half* qkv, const MtDilatedPlan* plan, mt_half* o_br, float* lse_br,
+                                   mt_stream_t stream) {
+  if (!qkv || !o_br || !lse_br || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  const int nblk = p.blk_off[p.nbranch];
+  hipLaunchKernelGGL(dilated_attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv, p,
+                     (h16*)o_br, lse_br);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_dilated_mix_ln_fwd(const mt_half* o_br, const float* lse_br, const MtDilatedPlan* plan,
+                                     const float* ln_w, const float* ln_b, mt_half* y, float* stats, float* lse_tot,
+                                     mt_stream_t stream) {
+  if (!o_br || !lse_br || !ln_w || !ln_b || !y || !stats || !lse_tot || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  const long M = (long)p.B * p.N;
+  hipLaunchKernelGGL(mix_ln_fwd_kernel, dim3((int)min((M + 3) / 4, 8192L)), dim3(256), 0, (hipStream_t)stream,
+                     (const h16*)o_br, lse_br, p, ln_w, ln_b, (h16*)y, stats, lse_tot);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, const float* lse_br, const float* lse_tot,
+                                     const MtDilatedPlan* plan, const float* ln_w, const float* stats, mt_half* dmixed,
+                                     float* delta_br, mt_stream_t stream) {
+  if (!dy || !o_br || !lse_br || !lse_tot || !ln_w || !stats || !dmixed || !delta_br || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  const long M = (long)p.B * p.N;
+  hipLaunchKernelGGL(mix_ln_bwd_kernel, dim3((int)min((M + 3) / 4, 8192L)), dim3(256), 0, (hipStream_t)stream,
+                     (const h16*)dy, (const h16*)o_br, lse_br, lse_tot, p, ln_w, stats, (h16*)dmixed, delta_br);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot,
+                                   const float* delta_br, const MtDilatedPlan* plan, float* dqkv, mt_stream_t stream) {
+  if (!qkv || !dmixed || !lse_tot || !delta_br || !dqkv || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  // branch with ratio 1 visits every (position, head): run it first in store mode, the others accumulate.
+  int first = -1;
+  for (int b = 0; b < p.nbranch; ++b) if (p.ratio[b] == 1) { first = b; break; }
+  if (first < 0) return MT_ERR_UNSUPPORTED;
+  for (int k = 0; k < p.nbranch; ++k) {
+    const int b = k == 0 ? first : (k <= first ? k - 1 : k);
+    const int nblk = p.B * p.nseg[b] * H * p.qtiles[b];
+    const int acc = k == 0 ? 0 : 1;
+    hipLaunchKernelGGL(dilated_attn_bwd_q_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv,
+                       (const h16*)dmixed, lse_tot, delta_br, p, b, acc, dqkv);
+    hipLaunchKernelGGL(dilated_attn_bwd_kv_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv,
+                       (const h16*)dmixed, lse_tot, delta_br, p, b, acc, dqkv);
+    MT_CHECK_LAUNCH();
+  }
+  return MT_OK;
+}

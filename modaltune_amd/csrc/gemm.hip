@@ -1,0 +1,396 @@
+// GEMM kernels of the Modal-Adapter hot path (gfx950, fp16 operands, fp32 MFMA accumulation).
+//
+//   gemm_nt : C[M,N] = epi(A[M,K] . W[N,K]^T)      every big-M nn.Linear forward and every dX GEMM
+//   gemm_tn : C[N1,N2] += A[M,N1]^T . B[M,N2]      weight gradients of the trainable big-M linears
+//   colsum  : out[N]  += sum_m A[m,N]              bias gradients
+//   sgemm_small : strided fp32 GEMM for the token-side (T <= 66 rows) ops
+//
+// gemm_nt structure: 128 x BN x 64 tiles, 4 waves, v_mfma_f32_16x16x32_f16, register-staged double-buffered
+// LDS (issue the next tile's global loads before the MFMAs, write them to the other buffer after: one barrier
+// per K-tile), LDS rows padded to 144 B so the ds_read_b128 fragment reads are bank-conflict free.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int LDS_STRIDE = 72;  // halves per LDS row (64 + 8 pad = 144 B: conflict-free ds_read_b128)
+
+struct GemmNtArgs {
+  const h16* A; long lda; RowMap amap;
+  const h16* W;
+  int M, N, K;
+  const float* bias;
+  const float* resid; long ldr; RowMap rmap;
+  const float* colscale;
+  const float* pos_table; const int* pos_row; const int* pos_col;
+  void* C; long ldc; RowMap cmap;
+};
+
+template <int BM, int BN, int WM, int WN, int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
+  constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
+  constexpr int MI = TM / 16, NI = TN / 16;     // 16x16 MFMA tiles per wave
+  constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;  // 16-B chunks per thread per K-tile
+  __shared__ __attribute__((aligned(16))) h16 As[2][BM * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) h16 Bs[2][BN * LDS_STRIDE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  // XCD-aware tile order: consecutive logical tiles share an A row-panel; keep them on one XCD (T1).
+  const int nbn = (g.N + BN - 1) / BN;
+  const int nbm = (g.M + BM - 1) / BM;
+  const int nwg = nbn * nbm;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+
+  const h16* aptr[ACH];
+  const h16* bptr[BCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    int c = tid + i * 256, row = c >> 3, kc = c & 7;
+    int m = min(m0 + row, g.M - 1);
+    aptr[i] = g.A + g.amap.map(m) * g.lda + kc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    int c = tid + i * 256, row = c >> 3, kc = c & 7;
+    int n = min(n0 + row, g.N - 1);
+    bptr[i] = g.W + (long)n * g.K + kc * 8;
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  h16x8 ra[ACH], rb[BCH];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) ra[i] = ldg8(aptr[i] + k0);
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) rb[i] = ldg8(bptr[i] + k0);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      int c = tid + i * 256, row = c >> 3, kc = c & 7;
+      *reinterpret_cast<h16x8*>(&As[buf][row * LDS_STRIDE + kc * 8]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      int c = tid + i * 256, row = c >> 3, kc = c & 7;
+      *reinterpret_cast<h16x8*>(&Bs[buf][row * LDS_STRIDE + kc * 8]) = rb[i];
+    }
+  };
+
+  const int nk = g.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) gload((t + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      h16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const h16x8*>(&As[buf][(wm * TM + i * 16 + fr) * LDS_STRIDE + kk * 32 + fq * 8]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bf[j] = *reinterpret_cast<const h16x8*>(&Bs[buf][(wn * TN + j * 16 + fr) * LDS_STRIDE + kk * 32 + fq * 8]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  OutT* C = reinterpret_cast<OutT*>(g.C);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * TM + i * 16 + fq * 4 + r;
+      if (m >= g.M) continue;
+      const long crow = g.cmap.map(m) * g.ldc;
+      long rrow = 0;
+      if (EPI == MT_EPI_BIAS_RESID || EPI == MT_EPI_INJECT) rrow = g.rmap.map(m) * g.ldr;
+      int prow = 0, pcol = 0;
+      if (EPI == MT_EPI_POSEMB) { prow = g.pos_row[m]; pcol = g.pos_col[m]; }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * TN + j * 16 + fr;
+        if (n >= g.N) continue;
+        float v = acc[i][j][r];
+        if (g.bias) v += g.bias[n];
+        if (EPI == MT_EPI_BIAS_RESID) v += g.resid[rrow + n];
+        if (EPI == MT_EPI_INJECT) {
+          const float gm = g.colscale[n];
+          v = (1.0f + gm) * g.resid[rrow + n] + gm * v;
+        }
+        if (EPI == MT_EPI_POSEMB) {
+          const int half = g.N >> 1;   // first half encodes the grid column, second half the row (A.8)
+          v += (n < half) ? g.pos_table[(long)pcol * half + n] : g.pos_table[(long)prow * half + (n - half)];
+        }
+        C[crow + n] = (OutT)v;
+      }
+    }
+  }
+}
+
+template <int BN, int EPI, typename OutT>
+int launch_nt(const GemmNtArgs& a, hipStream_t s) {
+  constexpr int BM = 128;
+  const int nwg = cdiv(a.M, BM) * cdiv(a.N, BN);
+  if (BN == 128)
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, 128, 2, 2, EPI, OutT>), dim3(nwg), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, 64, 4, 1, EPI, OutT>), dim3(nwg), dim3(256), 0, s, a);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+template <int EPI, typename OutT>
+int launch_nt_bn(const GemmNtArgs& a, hipStream_t s) {
+  // N = 192 / 384 / 576 (adapter projections) tile exactly with BN = 64; everything else uses 128
+  if (a.N % 128 != 0) return launch_nt<64, EPI, OutT>(a, s);
+  return launch_nt<128, EPI, OutT>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn: C[N1,N2] += sum_m A[m,n1] B[m,n2].  64x64 output tile per workgroup, 32 rows of m per step,
+// split over M (grid.z) with fp32 atomics.  Both operands are "k-strided" in memory, so the tiles are staged
+// as they lie ([m][n]) and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transposed read).
+// ------------------------------------------------------------------------------------------------
+constexpr int TN_STRIDE = 72;   // halves per LDS row: 64 + 8 (144 B; 8-byte aligned tr reads, 16-B aligned writes)
+
+MT_DEVINL h16x4 lds_tr4(const h16* p) {
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)p);
+  return __builtin_bit_cast(h16x4, r);
+}
+
+struct GemmTnArgs {
+  const h16* A; long lda; RowMap amap;
+  const h16* B; long ldb; RowMap bmap;
+  int M, N1, N2, rows_per_split;
+  float* C; long ldc;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
+  __shared__ __attribute__((aligned(16))) h16 As[2][32 * TN_STRIDE];
+  __shared__ __attribute__((aligned(16))) h16 Bs[2][32 * TN_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;      // wave tile 32(n1) x 32(n2)
+  const int n1_0 = blockIdx.x * 64, n2_0 = blockIdx.y * 64;
+  const int mbeg = blockIdx.z * g.rows_per_split;
+  const int mend = min(g.M, mbeg + g.rows_per_split);
+  if (mbeg >= mend) return;
+  // staging: tile 32 rows x 64 cols = 256 chunks of 16 B: one chunk per thread per operand
+  const int srow = tid >> 3, skc = tid & 7;
+  h16x8 ra, rb;
+  const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto gload = [&](int mt) {
+    const int m = mt + srow;
+    if (m < mend) {
+      ra = ldg8(g.A + g.amap.map(m) * g.lda + n1_0 + skc * 8);
+      rb = ldg8(g.B + g.bmap.map(m) * g.ldb + n2_0 + skc * 8);
+    } else { ra = zero; rb = zero; }
+  };
+  auto lstore = [&](int buf) {
+    *reinterpret_cast<h16x8*>(&As[buf][srow * TN_STRIDE + skc * 8]) = ra;
+    *reinterpret_cast<h16x8*>(&Bs[buf][srow * TN_STRIDE + skc * 8]) = rb;
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (mend - mbeg + 31) / 32;
+  gload(mbeg);
+  lstore(0);
+  __syncthreads();
+  // transposed-read addressing (T10): 16-lane group grp covers k rows 8*grp + {0..3} (+4 for the second read);
+  // lane 4q+p of the group supplies the address of row q, columns 4p..4p+3 of the 16-column block.
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) gload(mbeg + (t + 1) * 32);
+    h16x8 af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const h16* pa = &As[buf][(8 * grp + tq) * TN_STRIDE + wm * 32 + i * 16 + 4 * tp];
+      h16x4 lo = lds_tr4(pa), hi = lds_tr4(pa + 4 * TN_STRIDE);
+      af[i] = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const h16* pb = &Bs[buf][(8 * grp + tq) * TN_STRIDE + wn * 32 + i * 16 + 4 * tp];
+      lo = lds_tr4(pb); hi = lds_tr4(pb + 4 * TN_STRIDE);
+      bf[i] = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    if (t + 1 < nt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n1 = n1_0 + wm * 32 + i * 16 + fq * 4 + r;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n2 = n2_0 + wn * 32 + j * 16 + fr;
+        atomicAdd(&g.C[(long)n1 * g.ldc + n2], acc[i][j][r]);
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const h16* A, long lda, RowMap amap, int M, int N,
+                                                     int rows_per_block, float* out) {
+  // block = 64 columns x 4 row-lanes; each thread strides rows
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
+  float s = 0.f;
+  if (col < N)
+    for (int m = mbeg + rl; m < mend; m += 4) s += (float)A[amap.map(m) * lda + col];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && col < N) atomicAdd(&out[col], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small strided fp32 GEMM (token side).  16x16 outputs per workgroup, K walked in 16-wide LDS tiles.
+// ------------------------------------------------------------------------------------------------
+struct SgemmArgs {
+  const float* A; long as0, as1, a_bs;
+  const float* B; long bs0, bs1, b_bs;
+  const float* bias; int bias_on_m;
+  float* C; long cs0, cs1, c_bs;
+  int M, N, K, act, accumulate;
+};
+
+MT_DEVINL float apply_act(float v, int act) {
+  switch (act) {
+    case MT_ACT_RELU: return fmaxf(v, 0.f);
+    case MT_ACT_GELU: return gelu_erf(v);
+    case MT_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+
+__global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
+  __shared__ float As[16][17], Bs[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, bz = blockIdx.z;
+  const float* A = g.A + (long)bz * g.a_bs;
+  const float* B = g.B + (long)bz * g.b_bs;
+  float* C = g.C + (long)bz * g.c_bs;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const int am = m0 + ty, ak = k0 + tx;
+    As[ty][tx] = (am < g.M && ak < g.K) ? A[am * g.as0 + ak * g.as1] : 0.f;
+    const int bn = n0 + ty;
+    Bs[ty][tx] = (bn < g.N && ak < g.K) ? B[bn * g.bs0 + ak * g.bs1] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
+    __syncthreads();
+  }
+  const int m = m0 + ty, n = n0 + tx;
+  if (m < g.M && n < g.N) {
+    if (g.bias) acc += g.bias[g.bias_on_m ? m : n];
+    acc = apply_act(acc, g.act);
+    float* c = &C[m * g.cs0 + n * g.cs1];
+    *c = g.accumulate ? *c + acc : acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* W, int M, int N, int K,
+                              int epilogue, const MtGemmEpilogue* epi, void* C, long ldc, const MtRowMap* cmap,
+                              int out_dtype, mt_stream_t stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return MT_ERR_BAD_ARG;
+  if (K % BK != 0 || lda % 8 != 0 || (N % 64) != 0) return MT_ERR_BAD_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return MT_ERR_BAD_ARG;
+  GemmNtArgs a;
+  a.A = (const h16*)A; a.lda = lda; a.amap = make_rowmap(amap);
+  a.W = (const h16*)W; a.M = M; a.N = N; a.K = K;
+  a.bias = epi ? epi->bias : nullptr;
+  a.resid = epi ? epi->resid : nullptr; a.ldr = epi ? epi->ldr : 0;
+  a.rmap = make_rowmap(epi ? &epi->rmap : nullptr);
+  a.colscale = epi ? epi->colscale : nullptr;
+  a.pos_table = epi ? epi->pos_table : nullptr;
+  a.pos_row = epi ? epi->pos_row : nullptr; a.pos_col = epi ? epi->pos_col : nullptr;
+  a.C = C; a.ldc = ldc; a.cmap = make_rowmap(cmap);
+  hipStream_t s = (hipStream_t)stream;
+  const bool f32 = out_dtype == MT_OUT_F32;
+  switch (epilogue) {
+    case MT_EPI_BIAS:
+      return f32 ? launch_nt_bn<MT_EPI_BIAS, float>(a, s) : launch_nt_bn<MT_EPI_BIAS, h16>(a, s);
+    case MT_EPI_BIAS_RESID:
+      if (!a.resid) return MT_ERR_BAD_ARG;
+      return f32 ? launch_nt_bn<MT_EPI_BIAS_RESID, float>(a, s) : launch_nt_bn<MT_EPI_BIAS_RESID, h16>(a, s);
+    case MT_EPI_INJECT:
+      if (!a.resid || !a.colscale || !f32) return MT_ERR_BAD_ARG;
+      return launch_nt_bn<MT_EPI_INJECT, float>(a, s);
+    case MT_EPI_POSEMB:
+      if (!a.pos_table || !a.pos_row || !a.pos_col || !f32) return MT_ERR_BAD_ARG;
+      return launch_nt_bn<MT_EPI_POSEMB, float>(a, s);
+    default:
+      return MT_ERR_BAD_ARG;
+  }
+}
+
+extern "C" int mt_gemm_tn_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* B, long ldb,
+                              const MtRowMap* bmap, int M, int N1, int N2, float* C, long ldc, mt_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N1 % 64 || N2 % 64 || lda % 8 || ldb % 8) return MT_ERR_BAD_ARG;
+  GemmTnArgs g;
+  g.A = (const h16*)A; g.lda = lda; g.amap = make_rowmap(amap);
+  g.B = (const h16*)B; g.ldb = ldb; g.bmap = make_rowmap(bmap);
+  g.M = M; g.N1 = N1; g.N2 = N2; g.C = C; g.ldc = ldc;
+  const int tiles = (N1 / 64) * (N2 / 64);
+  int split = max(1, min(cdiv(M, 256), cdiv(2048, tiles)));   // ~2k workgroups, >= 256 rows each
+  g.rows_per_split = cdiv(cdiv(M, split), 32) * 32;
+  split = cdiv(M, g.rows_per_split);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(N1 / 64, N2 / 64, split), dim3(256), 0, (hipStream_t)stream, g);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, int M, int N, float* out,
+                             mt_stream_t stream) {
+  if (!A || !out || M <= 0 || N <= 0) return MT_ERR_BAD_ARG;
+  const int rows_per_block = 512;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream,
+                     (const h16*)A, lda, make_rowmap(amap), M, N, rows_per_block, out);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B, long bs0, long bs1,
+                              long b_bs, const float* bias, int bias_on_m, float* C, long cs0, long cs1, long c_bs,
+                              int M, int N, int K, int batch, int act, int accumulate, mt_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return MT_ERR_BAD_ARG;
+  SgemmArgs g{A, as0, as1, a_bs, B, bs0, bs1, b_bs, bias, bias_on_m, C, cs0, cs1, c_bs, M, N, K, act, accumulate};
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16), batch), dim3(256), 0, (hipStream_t)stream, g);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}

@@ -1,0 +1,368 @@
+// LayerNorm forward/backward (one wave per row, fp32 statistics) and the elementwise helpers.
+// HBM-bound: every row is read once with 8/16-byte vector loads and written once.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static MT_DEVINL f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static MT_DEVINL void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<h16> {
+  static MT_DEVINL f32x4 load(const h16* p) {
+    h16x4 v = *reinterpret_cast<const h16x4*>(p);
+    return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  static MT_DEVINL void store(h16* p, f32x4 v) {
+    *reinterpret_cast<h16x4*>(p) = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+  }
+};
+
+struct LnFwdArgs {
+  const void* x; long ldx; RowMap xmap;
+  const float* w; const float* b; const float* add_rows; int add_period;
+  void* y; long ldy; RowMap ymap;
+  float* stats; int M;
+};
+
+template <int D, typename InT, typename OutT, bool GELU>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+  constexpr int NC = D / 256;   // 4-element chunks per lane
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = blockIdx.x * 4 + wave; m < a.M; m += gridDim.x * 4) {
+    const InT* x = reinterpret_cast<const InT*>(a.x) + a.xmap.map(m) * a.ldx;
+    f32x4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      v[c] = Vec4<InT>::load(x + c * 256 + lane * 4);
+      if (GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] = gelu_erf(v[c][e]);
+      }
+      s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+    OutT* y = reinterpret_cast<OutT*>(a.y) + a.ymap.map(m) * a.ldy;
+    const float* add = a.add_rows ? a.add_rows + (long)(m % a.add_period) * D : nullptr;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = c * 256 + lane * 4;
+      const f32x4 w = Vec4<float>::load(a.w + col), b = Vec4<float>::load(a.b + col);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * w[e] + b[e];
+      if (add) { const f32x4 p = Vec4<float>::load(add + col); o += p; }
+      Vec4<OutT>::store(y + col, o);
+    }
+    if (a.stats && lane == 0) { a.stats[2 * (long)m] = mean; a.stats[2 * (long)m + 1] = rstd; }
+  }
+}
+
+struct LnBwdArgs {
+  const void* dy; long lddy; RowMap dymap;
+  const void* x; long ldx; RowMap xmap;
+  const float* w; const float* stats;
+  void* dx; long lddx; RowMap dxmap; int accumulate;
+  float* dw; float* db; int M;
+};
+
+template <int D, typename DyT, typename InT, typename DxT, bool GELU, bool PARAM>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+  constexpr int NC = D / 256;
+  constexpr int NP = PARAM ? NC : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gw[NP], gb[NP];
+#pragma unroll
+  for (int c = 0; c < NP; ++c) { gw[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; gb[c] = gw[c]; }
+  for (int m = blockIdx.x * 4 + wave; m < a.M; m += gridDim.x * 4) {
+    const DyT* dy = reinterpret_cast<const DyT*>(a.dy) + a.dymap.map(m) * a.lddy;
+    const InT* x = reinterpret_cast<const InT*>(a.x) + a.xmap.map(m) * a.ldx;
+    const float mean = a.stats[2 * (long)m], rstd = a.stats[2 * (long)m + 1];
+    f32x4 xh[NC], g[NC], raw[GELU ? NC : 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = c * 256 + lane * 4;
+      f32x4 xv = Vec4<InT>::load(x + col);
+      if (GELU) {
+        raw[c] = xv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = gelu_erf(xv[e]);
+      }
+      const f32x4 d = Vec4<DyT>::load(dy + col);
+      const f32x4 w = Vec4<float>::load(a.w + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[c][e] = (xv[e] - mean) * rstd;
+        g[c][e] = d[e] * w[e];
+        s1 += g[c][e];
+        s2 += g[c][e] * xh[c][e];
+      }
+      if (PARAM) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gw[c][e] += d[e] * xh[c][e]; gb[c][e] += d[e]; }
+      }
+    }
+    const float c1 = wave_sum(s1) * (1.0f / D), c2 = wave_sum(s2) * (1.0f / D);
+    DxT* dx = reinterpret_cast<DxT*>(a.dx) + a.dxmap.map(m) * a.lddx;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = c * 256 + lane * 4;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = rstd * (g[c][e] - c1 - xh[c][e] * c2);
+        if (GELU) o[e] *= gelu_erf_grad(raw[c][e]);
+      }
+      if (a.accumulate) { const f32x4 old = Vec4<DxT>::load(dx + col); o += old; }
+      Vec4<DxT>::store(dx + col, o);
+    }
+  }
+  if (PARAM) {
+    __shared__ float red[2][4][D];
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[0][wave][c * 256 + lane * 4 + e] = gw[c][e];
+        red[1][wave][c * 256 + lane * 4 + e] = gb[c][e];
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) {
+      atomicAdd(&a.dw[i], red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
+      atomicAdd(&a.db[i], red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+    }
+  }
+}
+
+int ln_grid(int M) { return max(1, min(cdiv(M, 4), 4096)); }
+
+template <int D, typename InT, typename OutT>
+int ln_fwd_dispatch(const LnFwdArgs& a, int gelu, hipStream_t s) {
+  if (gelu) hipLaunchKernelGGL((ln_fwd_kernel<D, InT, OutT, true>), dim3(ln_grid(a.M)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((ln_fwd_kernel<D, InT, OutT, false>), dim3(ln_grid(a.M)), dim3(256), 0, s, a);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+template <int D>
+int ln_fwd_types(const LnFwdArgs& a, int in_dt, int out_dt, int gelu, hipStream_t s) {
+  if (in_dt == MT_OUT_F32 && out_dt == MT_OUT_F16) return ln_fwd_dispatch<D, float, h16>(a, gelu, s);
+  if (in_dt == MT_OUT_F32 && out_dt == MT_OUT_F32) return ln_fwd_dispatch<D, float, float>(a, gelu, s);
+  if (in_dt == MT_OUT_F16 && out_dt == MT_OUT_F16) return ln_fwd_dispatch<D, h16, h16>(a, gelu, s);
+  return MT_ERR_UNSUPPORTED;
+}
+
+template <int D, typename DyT, typename InT, typename DxT, bool GELU>
+int ln_bwd_launch(const LnBwdArgs& a, hipStream_t s) {
+  if (a.dw) {
+    if constexpr (D <= 768 && !GELU) {
+      hipLaunchKernelGGL((ln_bwd_kernel<D, DyT, InT, DxT, GELU, true>), dim3(min(ln_grid(a.M), 512)), dim3(256), 0, s, a);
+    } else {
+      return MT_ERR_UNSUPPORTED;
+    }
+  } else {
+    hipLaunchKernelGGL((ln_bwd_kernel<D, DyT, InT, DxT, GELU, false>), dim3(ln_grid(a.M)), dim3(256), 0, s, a);
+  }
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+// ---------------------------------------------------------------- elementwise ---------------------
+__global__ void cast_f32_f16_kernel(const float* x, h16* y, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) Vec4<h16>::store(y + i, Vec4<float>::load(x + i));
+  if (i < n && i + 3 >= n) for (long j = i; j < n; ++j) y[j] = (h16)x[j];
+}
+__global__ void cast_f16_f32_kernel(const h16* x, float* y, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) Vec4<float>::store(y + i, Vec4<h16>::load(x + i));
+  if (i < n && i + 3 >= n) for (long j = i; j < n; ++j) y[j] = (float)x[j];
+}
+__global__ void act_fwd_kernel(const float* x, float* y, long n, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = act == MT_ACT_RELU ? fmaxf(v, 0.f) : act == MT_ACT_GELU ? gelu_erf(v) : act == MT_ACT_ELU ? (v > 0.f ? v : expm1f(v)) : v;
+  }
+}
+__global__ void act_bwd_kernel(const float* x, const float* dy, float* dx, long n, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    float d = 1.f;
+    if (act == MT_ACT_RELU) d = v > 0.f ? 1.f : 0.f;
+    else if (act == MT_ACT_GELU) d = gelu_erf_grad(v);
+    else if (act == MT_ACT_ELU) d = v > 0.f ? 1.f : __expf(v);
+    dx[i] = dy[i] * d;
+  }
+}
+__global__ void axpy_kernel(const float* a, const float* b, float alpha, float* y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = a[i] + alpha * b[i];
+}
+__global__ void copy_rows_kernel(const float* src, long lds, RowMap smap, float* dst, long ldd, RowMap dmap, int M,
+                                 int D, int accumulate) {
+  const int per_row = D / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * per_row; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / per_row), c = (int)(i % per_row) * 4;
+    f32x4 v = Vec4<float>::load(src + smap.map(m) * lds + c);
+    float* d = dst + dmap.map(m) * ldd + c;
+    if (accumulate) v += Vec4<float>::load(d);
+    Vec4<float>::store(d, v);
+  }
+}
+
+// Injector residual path backward.  y = (1+g) x + g * proj  (A.1), with proj = out(a) recomputed in fp16:
+//   dx (+)= (1+g) dy ; dproj = g * dy (fp16, feeds the dX/dW GEMMs) ; dgamma += sum_m dy * (x + proj)
+struct InjBwdArgs {
+  const float* dy; long lddy; RowMap dymap;
+  const float* x; long ldx; RowMap xmap;
+  const h16* proj; const float* gamma;
+  float* dx; long lddx; RowMap dxmap; int dx_accumulate;
+  h16* dproj; float* dgamma; int M;
+};
+template <int D>
+__global__ __launch_bounds__(256) void inject_resid_bwd_kernel(InjBwdArgs a) {
+  constexpr int NC = D / 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gg[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) gg[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int m = blockIdx.x * 4 + wave; m < a.M; m += gridDim.x * 4) {
+    const float* dy = a.dy + a.dymap.map(m) * a.lddy;
+    const float* x = a.x + a.xmap.map(m) * a.ldx;
+    const h16* pr = a.proj + (long)m * D;
+    float* dx = a.dx + a.dxmap.map(m) * a.lddx;
+    h16* dp = a.dproj + (long)m * D;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = c * 256 + lane * 4;
+      const f32x4 d = Vec4<float>::load(dy + col), xv = Vec4<float>::load(x + col), p = Vec4<h16>::load(pr + col);
+      const f32x4 gm = Vec4<float>::load(a.gamma + col);
+      f32x4 o, q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (1.0f + gm[e]) * d[e];
+        q[e] = gm[e] * d[e];
+        gg[c][e] += d[e] * (xv[e] + p[e]);
+      }
+      if (a.dx_accumulate) o += Vec4<float>::load(dx + col);
+      Vec4<float>::store(dx + col, o);
+      Vec4<h16>::store(dp + col, q);
+    }
+  }
+  __shared__ float red[4][D];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][c * 256 + lane * 4 + e] = gg[c][e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) atomicAdd(&a.dgamma[i], red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+}
+
+int ew_grid(long n) { return (int)max(1L, min((n + 1023) / 1024, 4096L)); }
+
+}  // namespace
+
+extern "C" int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in,
+                                const float* w, const float* b, const float* add_rows, int add_period, void* y,
+                                long ldy, const MtRowMap* ymap, int out_dtype, float* stats, int M, int D,
+                                mt_stream_t stream) {
+  if (!x || !y || !w || !b || M <= 0 || (ldx & 3) || (ldy & 3)) return MT_ERR_BAD_ARG;
+  LnFwdArgs a{x, ldx, make_rowmap(xmap), w, b, add_rows, add_period > 0 ? add_period : 1, y, ldy, make_rowmap(ymap), stats, M};
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 256: return ln_fwd_types<256>(a, in_dtype, out_dtype, gelu_in, s);
+    case 768: return ln_fwd_types<768>(a, in_dtype, out_dtype, gelu_in, s);
+    case 2304: return ln_fwd_types<2304>(a, in_dtype, out_dtype, gelu_in, s);
+    case 3072: return ln_fwd_types<3072>(a, in_dtype, out_dtype, gelu_in, s);
+    default: return MT_ERR_UNSUPPORTED;
+  }
+}
+
+template <int D>
+static int ln_bwd_types(const LnBwdArgs& a, int dy_dt, int in_dt, int dx_dt, int gelu, hipStream_t s) {
+  const bool dyh = dy_dt == MT_OUT_F16, inh = in_dt == MT_OUT_F16, dxh = dx_dt == MT_OUT_F16;
+  if (gelu) {
+    if (dyh && inh && dxh) return ln_bwd_launch<D, h16, h16, h16, true>(a, s);
+    return MT_ERR_UNSUPPORTED;
+  }
+  if (dyh && !inh && !dxh) return ln_bwd_launch<D, h16, float, float, false>(a, s);
+  if (dyh && !inh && dxh) return ln_bwd_launch<D, h16, float, h16, false>(a, s);
+  if (!dyh && !inh && !dxh) return ln_bwd_launch<D, float, float, float, false>(a, s);
+  return MT_ERR_UNSUPPORTED;
+}
+
+extern "C" int mt_layernorm_bwd(const void* dy, long lddy, const MtRowMap* dymap, int dy_dtype, const void* x,
+                                long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w,
+                                const float* stats, void* dx, long lddx, const MtRowMap* dxmap, int dx_dtype,
+                                int accumulate, float* dw, float* db, int M, int D, mt_stream_t stream) {
+  if (!dy || !x || !w || !stats || !dx || M <= 0 || (!dw) != (!db)) return MT_ERR_BAD_ARG;
+  LnBwdArgs a{dy, lddy, make_rowmap(dymap), x, ldx, make_rowmap(xmap), w, stats, dx, lddx, make_rowmap(dxmap), accumulate, dw, db, M};
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 256: return ln_bwd_types<256>(a, dy_dtype, in_dtype, dx_dtype, gelu_in, s);
+    case 768: return ln_bwd_types<768>(a, dy_dtype, in_dtype, dx_dtype, gelu_in, s);
+    case 2304: return ln_bwd_types<2304>(a, dy_dtype, in_dtype, dx_dtype, gelu_in, s);
+    case 3072: return ln_bwd_types<3072>(a, dy_dtype, in_dtype, dx_dtype, gelu_in, s);
+    default: return MT_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" int mt_cast_f32_to_f16(const float* x, mt_half* y, long n, mt_stream_t stream) {
+  if (!x || !y || n <= 0) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (h16*)y, n);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_cast_f16_to_f32(const mt_half* x, float* y, long n, mt_stream_t stream) {
+  if (!x || !y || n <= 0) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, (const h16*)x, y, n);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_act_fwd(const float* x, float* y, long n, int act, mt_stream_t stream) {
+  if (!x || !y || n <= 0) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_act_bwd(const float* x, const float* dy, float* dx, long n, int act, mt_stream_t stream) {
+  if (!x || !dy || !dx || n <= 0) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, act);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_axpy(const float* a, const float* b, float alpha, float* y, long n, mt_stream_t stream) {
+  if (!a || !b || !y || n <= 0) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, y, n);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_copy_rows_f32(const float* src, long lds, const MtRowMap* smap, float* dst, long ldd,
+                                const MtRowMap* dmap, int M, int D, int accumulate, mt_stream_t stream) {
+  if (!src || !dst || M <= 0 || D <= 0 || (D & 3) || (lds & 3) || (ldd & 3)) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid((long)M * D / 4)), dim3(256), 0, (hipStream_t)stream, src, lds,
+                     make_rowmap(smap), dst, ldd, make_rowmap(dmap), M, D, accumulate);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_inject_resid_bwd(const float* dy, long lddy, const MtRowMap* dymap, const float* x, long ldx,
+                                   const MtRowMap* xmap, const mt_half* proj, const float* gamma, float* dx, long lddx,
+                                   const MtRowMap* dxmap, int dx_accumulate, mt_half* dproj, float* dgamma, int M,
+                                   int D, mt_stream_t stream) {
+  if (!dy || !x || !proj || !gamma || !dx || !dproj || !dgamma || M <= 0 || D != 768) return MT_ERR_BAD_ARG;
+  InjBwdArgs a{dy, lddy, make_rowmap(dymap), x, ldx, make_rowmap(xmap), (const h16*)proj, gamma, dx, lddx,
+               make_rowmap(dxmap), dx_accumulate, (h16*)dproj, dgamma, M};
+  hipLaunchKernelGGL(inject_resid_bwd_kernel<768>, dim3(min(cdiv(M, 4), 512)), dim3(256), 0, (hipStream_t)stream, a);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}

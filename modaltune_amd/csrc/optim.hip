@@ -1,0 +1,121 @@
+// Distillation loss head, fused AdamW with GradScaler semantics, and library metadata.
+#include "common.h"
+
+namespace {
+
+// One workgroup: R <= 8 rows of O <= 1024 logits.  train_modaltune.py:225-233:
+//   z = logit / ||logit||; loss = 10 * sum_r sum_j p_rj (log p_rj - log_softmax(z_r)_j), p = softmax(target_r)
+// d loss / d z_rj = 10 * (softmax(z_r)_j - p_rj)   (sum_j p_rj = 1);  d/d logit = (dz - z (z . dz)) / ||logit||
+__global__ __launch_bounds__(256) void distill_loss_kernel(const float* __restrict__ logits, const float* __restrict__ target, int R, int O,
+                                                           float loss_scale, float* __restrict__ loss, float* __restrict__ dlogits) {
+  __shared__ float red[256];
+  __shared__ float bc[4];
+  const int tid = threadIdx.x;
+  auto block_sum = [&](float v) {
+    red[tid] = v; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const float r = red[0]; __syncthreads(); return r;
+  };
+  auto block_max = [&](float v) {
+    red[tid] = v; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    const float r = red[0]; __syncthreads(); return r;
+  };
+  float total = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float* lg = logits + (long)r * O;
+    const float* tg = target + (long)r * O;
+    float ss = 0.f;
+    for (int j = tid; j < O; j += 256) ss += lg[j] * lg[j];
+    const float nrm = sqrtf(block_sum(ss));
+    float zm = -1.0e30f, tm = -1.0e30f;
+    for (int j = tid; j < O; j += 256) { zm = fmaxf(zm, lg[j] / nrm); tm = fmaxf(tm, tg[j]); }
+    zm = block_max(zm); tm = block_max(tm);
+    float ze = 0.f, te = 0.f;
+    for (int j = tid; j < O; j += 256) { ze += expf(lg[j] / nrm - zm); te += expf(tg[j] - tm); }
+    ze = block_sum(ze); te = block_sum(te);
+    const float zl = zm + logf(ze), tl = tm + logf(te);
+    float part = 0.f, zdz = 0.f;
+    for (int j = tid; j < O; j += 256) {
+      const float z = lg[j] / nrm;
+      const float logq = z - zl, logp = tg[j] - tl, p = expf(logp);
+      part += p * (logp - logq);
+      const float dz = 10.0f * (expf(logq) - p);
+      zdz += z * dz;
+    }
+    part = block_sum(part); zdz = block_sum(zdz);
+    total += 10.0f * part;
+    for (int j = tid; j < O; j += 256) {
+      const float z = lg[j] / nrm;
+      const float dz = 10.0f * (expf(z - zl) - expf(tg[j] - tl));
+      dlogits[(long)r * O + j] = loss_scale * (dz - z * zdz) / nrm;
+    }
+  }
+  if (tid == 0) *loss = total;
+  (void)bc;
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                             const float* __restrict__ scale, const int* __restrict__ found_inf) {
+  if (found_inf && *found_inf) return;       // GradScaler.step: skip the whole update when a grad is inf/nan
+  const float inv_scale = scale ? 1.0f / *scale : 1.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * inv_scale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+__global__ void check_finite_kernel(const float* __restrict__ g, long n, int* __restrict__ found_inf) {
+  bool bad = false;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    bad |= !isfinite(g[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
+}
+
+}  // namespace
+
+extern "C" int mt_distill_loss(const float* logits, const float* target, int R, int O, float loss_scale, float* loss,
+                               float* dlogits, mt_stream_t stream) {
+  if (!logits || !target || !loss || !dlogits || R < 1 || O < 1) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(distill_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, R, O, loss_scale, loss, dlogits);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step_count, const float* scale, int* found_inf,
+                             mt_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || step_count < 1) return MT_ERR_BAD_ARG;
+  const float bc1 = 1.0f - powf(beta1, (float)step_count);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step_count));
+  const int grid = (int)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2s, scale, (const int*)found_inf);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_check_finite(const float* g, long n, int* found_inf, mt_stream_t stream) {
+  if (!g || !found_inf || n <= 0) return MT_ERR_BAD_ARG;
+  const int grid = (int)((n + 1023) / 1024 > 2048 ? 2048 : (n + 1023) / 1024);
+  hipLaunchKernelGGL(check_finite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, found_inf);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_version(void) { return 100; }
+
+extern "C" const char* mt_status_string(int status) {
+  switch (status) {
+    case MT_OK: return "ok";
+    case MT_ERR_BAD_ARG: return "bad argument (shape / alignment / null pointer)";
+    case MT_ERR_LAUNCH: return "kernel launch failed";
+    case MT_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}

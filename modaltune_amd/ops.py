@@ -1,0 +1,195 @@
+"""Thin torch-tensor front end over the C-ABI launchers (device pointers in, status checked).
+
+Each function maps 1:1 to an entry of include/modaltune_hip.h; PyTorch only supplies device memory and
+the current HIP stream.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import MtDilatedPlan, MtGemmEpilogue, MtRowMap, check, rowmap
+
+F16, F32 = 0, 1
+EPI_BIAS, EPI_BIAS_RESID, EPI_INJECT, EPI_POSEMB = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU = 0, 1, 2, 3
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return F16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _rm(m):
+    return None if m is None else C.byref(m)
+
+
+def _need(t, dtype, name):
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f"{name}: expected contiguous cuda {dtype}, got {t.dtype} cuda={t.is_cuda} contig={t.is_contiguous()}")
+
+
+def make_plan(branches, N: int, B: int) -> MtDilatedPlan:
+    p = MtDilatedPlan()
+    p.nbranch, p.N, p.B = len(branches), N, B
+    for i, b in enumerate(branches):
+        p.seg[i], p.ratio[i], p.nseg[i], p.n[i] = b.seg, b.ratio, b.nseg, b.n
+    return p
+
+
+def gemm_nt(A, W, out, M, N, K, *, lda=None, amap=None, ldc=None, cmap=None, epilogue=EPI_BIAS, bias=None, resid=None,
+            ldr=0, rmap=None, colscale=None, pos_table=None, pos_row=None, pos_col=None):
+    """out = epilogue(A[M,K] @ W[N,K]^T) (include/modaltune_hip.h: mt_gemm_nt_f16)."""
+    epi = MtGemmEpilogue()
+    epi.bias, epi.resid, epi.ldr = (bias.data_ptr() if bias is not None else None,
+                                    resid.data_ptr() if resid is not None else None, ldr)
+    if rmap is not None:
+        epi.rmap = rmap
+    epi.colscale = colscale.data_ptr() if colscale is not None else None
+    epi.pos_table = pos_table.data_ptr() if pos_table is not None else None
+    epi.pos_row = pos_row.data_ptr() if pos_row is not None else None
+    epi.pos_col = pos_col.data_ptr() if pos_col is not None else None
+    check(_lib.load().mt_gemm_nt_f16(_p(A), lda if lda is not None else K, _rm(amap), _p(W), M, N, K, epilogue,
+                                     C.byref(epi), _p(out), ldc if ldc is not None else N, _rm(cmap), _dt(out), _s()),
+          "gemm_nt")
+
+
+def gemm_tn(A, B, out, M, N1, N2, *, lda=None, amap=None, ldb=None, bmap=None, ldc=None):
+    """out[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics)."""
+    check(_lib.load().mt_gemm_tn_f16(_p(A), lda if lda is not None else N1, _rm(amap), _p(B), ldb if ldb is not None else N2,
+                                     _rm(bmap), M, N1, N2, _p(out), ldc if ldc is not None else N2, _s()), "gemm_tn")
+
+
+def colsum(A, out, M, N, *, lda=None, amap=None):
+    check(_lib.load().mt_colsum_f16(_p(A), lda if lda is not None else N, _rm(amap), M, N, _p(out), _s()), "colsum")
+
+
+def sgemm(A, a_str, B, b_str, Cm, c_str, M, N, K, *, bias=None, bias_on_m=False, act=ACT_NONE, accumulate=False,
+          batch=1, a_bs=0, b_bs=0, c_bs=0):
+    """C(m,n) = act(sum_k A(m,k) B(n,k) + bias) with explicit (row, col) element strides."""
+    check(_lib.load().mt_sgemm_small(_p(A), a_str[0], a_str[1], a_bs, _p(B), b_str[0], b_str[1], b_bs, _p(bias),
+                                     int(bias_on_m), _p(Cm), c_str[0], c_str[1], c_bs, M, N, K, batch, act,
+                                     int(accumulate), _s()), "sgemm_small")
+
+
+def layernorm_fwd(x, w, b, y, stats, M, D, *, ldx=None, xmap=None, ldy=None, ymap=None, gelu_in=False, add_rows=None,
+                  add_period=0):
+    check(_lib.load().mt_layernorm_fwd(_p(x), ldx if ldx is not None else D, _rm(xmap), _dt(x), int(gelu_in), _p(w), _p(b),
+                                       _p(add_rows), add_period, _p(y), ldy if ldy is not None else D, _rm(ymap), _dt(y),
+                                       _p(stats), M, D, _s()), "layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, w, stats, dx, M, D, *, lddy=None, dymap=None, ldx=None, xmap=None, lddx=None, dxmap=None,
+                  gelu_in=False, accumulate=False, dw=None, db=None):
+    check(_lib.load().mt_layernorm_bwd(_p(dy), lddy if lddy is not None else D, _rm(dymap), _dt(dy), _p(x),
+                                       ldx if ldx is not None else D, _rm(xmap), _dt(x), int(gelu_in), _p(w), _p(stats),
+                                       _p(dx), lddx if lddx is not None else D, _rm(dxmap), _dt(dx), int(accumulate),
+                                       _p(dw), _p(db), M, D, _s()), "layernorm_bwd")
+
+
+def dilated_attn_fwd(qkv, plan, o_br, lse_br):
+    check(_lib.load().mt_dilated_attn_fwd(_p(qkv), C.byref(plan), _p(o_br), _p(lse_br), _s()), "dilated_attn_fwd")
+
+
+def dilated_mix_ln_fwd(o_br, lse_br, plan, ln_w, ln_b, y, stats, lse_tot):
+    check(_lib.load().mt_dilated_mix_ln_fwd(_p(o_br), _p(lse_br), C.byref(plan), _p(ln_w), _p(ln_b), _p(y), _p(stats),
+                                            _p(lse_tot), _s()), "dilated_mix_ln_fwd")
+
+
+def dilated_mix_ln_bwd(dy, o_br, lse_br, lse_tot, plan, ln_w, stats, dmixed, delta_br):
+    check(_lib.load().mt_dilated_mix_ln_bwd(_p(dy), _p(o_br), _p(lse_br), _p(lse_tot), C.byref(plan), _p(ln_w), _p(stats),
+                                            _p(dmixed), _p(delta_br), _s()), "dilated_mix_ln_bwd")
+
+
+def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, dqkv):
+    check(_lib.load().mt_dilated_attn_bwd(_p(qkv), _p(dmixed), _p(lse_tot), _p(delta_br), C.byref(plan), _p(dqkv), _s()),
+          "dilated_attn_bwd")
+
+
+def inject_attn_fwd(q, k, v, a, M, rows_per_pass, T):
+    check(_lib.load().mt_inject_attn_fwd(_p(q), M, rows_per_pass, _p(k), _p(v), T, _p(a), _s()), "inject_attn_fwd")
+
+
+def inject_attn_bwd(q, da, k, v, dq, dk, dv, M, rows_per_pass, T):
+    check(_lib.load().mt_inject_attn_bwd(_p(q), _p(da), M, rows_per_pass, _p(k), _p(v), T, _p(dq), _p(dk), _p(dv), _s()),
+          "inject_attn_bwd")
+
+
+def extract_attn_fwd(q, kv, out, lse, part_acc, part_ml, B, T, L, nsplit):
+    check(_lib.load().mt_extract_attn_fwd(_p(q), _p(kv), B, T, L, _p(out), _p(lse), _p(part_acc), _p(part_ml), nsplit,
+                                          _s()), "extract_attn_fwd")
+
+
+def extract_attn_bwd(q, kv, out, lse, dout, dq, dkv, B, T, L):
+    check(_lib.load().mt_extract_attn_bwd(_p(q), _p(kv), _p(out), _p(lse), _p(dout), B, T, L, _p(dq), _p(dkv), _s()),
+          "extract_attn_bwd")
+
+
+def token_mha_fwd(q, k, v, out, probs, B, T, E, heads):
+    check(_lib.load().mt_token_mha_fwd(_p(q), _p(k), _p(v), B, T, E, heads, _p(out), _p(probs), _s()), "token_mha_fwd")
+
+
+def token_mha_bwd(q, k, v, probs, dout, dq, dk, dv, B, T, E, heads):
+    check(_lib.load().mt_token_mha_bwd(_p(q), _p(k), _p(v), _p(probs), _p(dout), B, T, E, heads, _p(dq), _p(dk), _p(dv),
+                                       _s()), "token_mha_bwd")
+
+
+def cast_f32_to_f16(x, y, n=None):
+    check(_lib.load().mt_cast_f32_to_f16(_p(x), _p(y), n if n is not None else x.numel(), _s()), "cast")
+
+
+def cast_f16_to_f32(x, y, n=None):
+    check(_lib.load().mt_cast_f16_to_f32(_p(x), _p(y), n if n is not None else x.numel(), _s()), "cast")
+
+
+def act_fwd(x, y, act, n=None):
+    check(_lib.load().mt_act_fwd(_p(x), _p(y), n if n is not None else x.numel(), act, _s()), "act_fwd")
+
+
+def act_bwd(x, dy, dx, act, n=None):
+    check(_lib.load().mt_act_bwd(_p(x), _p(dy), _p(dx), n if n is not None else x.numel(), act, _s()), "act_bwd")
+
+
+def axpy(a, b, alpha, y, n=None):
+    check(_lib.load().mt_axpy(_p(a), _p(b), float(alpha), _p(y), n if n is not None else a.numel(), _s()), "axpy")
+
+
+def copy_rows(src, dst, M, D, *, lds=None, smap=None, ldd=None, dmap=None, accumulate=False):
+    check(_lib.load().mt_copy_rows_f32(_p(src), lds if lds is not None else D, _rm(smap), _p(dst),
+                                       ldd if ldd is not None else D, _rm(dmap), M, D, int(accumulate), _s()), "copy_rows")
+
+
+def inject_resid_bwd(dy, x, proj, gamma, dx, dproj, dgamma, M, D, *, lddy=None, dymap=None, ldx=None, xmap=None, lddx=None,
+                     dxmap=None, dx_accumulate=False):
+    check(_lib.load().mt_inject_resid_bwd(_p(dy), lddy if lddy is not None else D, _rm(dymap), _p(x),
+                                          ldx if ldx is not None else D, _rm(xmap), _p(proj), _p(gamma), _p(dx),
+                                          lddx if lddx is not None else D, _rm(dxmap), int(dx_accumulate), _p(dproj),
+                                          _p(dgamma), M, D, _s()), "inject_resid_bwd")
+
+
+def distill_loss(logits, target, loss, dlogits, R, O, loss_scale=1.0):
+    check(_lib.load().mt_distill_loss(_p(logits), _p(target), R, O, float(loss_scale), _p(loss), _p(dlogits), _s()),
+          "distill_loss")
+
+
+def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_count, scale=None, found_inf=None):
+    check(_lib.load().mt_adamw_step(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, step_count,
+                                    _p(scale), _p(found_inf), _s()), "adamw_step")
+
+
+def check_finite(g, n, found_inf):
+    check(_lib.load().mt_check_finite(_p(g), n, _p(found_inf), _s()), "check_finite")

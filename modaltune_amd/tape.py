@@ -1,0 +1,210 @@
+"""A minimal reverse-mode tape over the C-ABI kernels for the token-side (T <= 66 rows) fp32 ops.
+
+Every op launches hand-written HIP kernels (modaltune_amd.ops) for both directions and records a
+closure that the engine replays in reverse; torch is only the allocator.  Gradients accumulate
+(+=) into `Var.grad`; parameter gradients accumulate straight into the flat gradient buffer views.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+class Var:
+    """A contiguous fp32 activation [..., C] with an optional (lazily zero-allocated) gradient."""
+    __slots__ = ("data", "grad", "needs_grad")
+
+    def __init__(self, data: torch.Tensor, needs_grad: bool = True):
+        self.data = data
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = needs_grad
+
+    def g(self) -> torch.Tensor:
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.data)
+        return self.grad
+
+    @property
+    def rows(self) -> int:
+        return self.data.numel() // self.data.shape[-1]
+
+    @property
+    def cols(self) -> int:
+        return self.data.shape[-1]
+
+
+class Param:
+    """A trainable fp32 tensor + the view of the flat gradient buffer that belongs to it."""
+    __slots__ = ("data", "grad")
+
+    def __init__(self, data: torch.Tensor, grad: Optional[torch.Tensor]):
+        self.data = data
+        self.grad = grad          # None for frozen tensors (selective backward: no dW is ever computed)
+
+
+class Tape:
+    def __init__(self, device):
+        self.device = device
+        self.back: List[Callable[[], None]] = []
+        self._ones = torch.ones(4096, device=device)
+        self.grad_enabled = True
+
+    def reset(self):
+        self.back.clear()
+
+    def record(self, fn: Callable[[], None]):
+        if self.grad_enabled:
+            self.back.append(fn)
+
+    def run_backward(self):
+        for fn in reversed(self.back):
+            fn()
+        self.back.clear()
+
+    def new(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, device=self.device, dtype=torch.float32)
+
+    # ------------------------------------------------------------------ ops
+    def linear(self, x: Var, W: Param, b: Optional[Param], act: int = ops.ACT_NONE) -> Var:
+        """y = act(x @ W^T + b) over the last dim (nn.Linear)."""
+        K, N, R = x.cols, W.data.shape[0], x.rows
+        pre = self.new(*x.data.shape[:-1], N)
+        ops.sgemm(x.data, (K, 1), W.data, (K, 1), pre, (N, 1), R, N, K, bias=None if b is None else b.data)
+        if act != ops.ACT_NONE:
+            y = Var(self.new(*pre.shape))
+            ops.act_fwd(pre, y.data, act)
+        else:
+            y = Var(pre)
+
+        def bwd():
+            if y.grad is None:
+                return
+            dy = y.grad
+            if act != ops.ACT_NONE:
+                dpre = self.new(*pre.shape)
+                ops.act_bwd(pre, dy, dpre, act)
+                dy = dpre
+            if x.needs_grad:   # dx += dy @ W
+                ops.sgemm(dy, (N, 1), W.data, (1, K), x.g(), (K, 1), R, K, N, accumulate=True)
+            if W.grad is not None:   # dW += dy^T @ x
+                ops.sgemm(dy, (1, N), x.data, (1, K), W.grad, (K, 1), N, K, R, accumulate=True)
+            if b is not None and b.grad is not None:
+                self._colsum(dy, R, N, b.grad)
+        self.record(bwd)
+        return y
+
+    def _colsum(self, dy, R, N, out):
+        assert R <= self._ones.numel()
+        ops.sgemm(dy, (1, N), self._ones, (0, 1), out, (1, 1), N, 1, R, accumulate=True)
+
+    def axis_linear(self, x: Var, W: Param, b: Param, act: int = ops.ACT_NONE) -> Var:
+        """y[b, go, c] = act(sum_g W[go, g] x[b, g, c] + bias[go]): Conv1d(kernel 1) over the group axis
+        (gene_encoder.py:140-158) and pathway_compression (gene_encoder.py:212)."""
+        Bb, G, Cc = x.data.shape
+        assert Bb == 1, "the gene encoder runs once per slide (shared by the task passes)"
+        Go = W.data.shape[0]
+        Wm = W.data.view(Go, G)
+        pre = self.new(Bb, Go, Cc)
+        ops.sgemm(Wm, (G, 1), x.data, (1, Cc), pre, (Cc, 1), Go, Cc, G, bias=b.data, bias_on_m=True, batch=Bb,
+                  b_bs=G * Cc, c_bs=Go * Cc)
+        if act != ops.ACT_NONE:
+            y = Var(self.new(Bb, Go, Cc))
+            ops.act_fwd(pre, y.data, act)
+        else:
+            y = Var(pre)
+
+        def bwd():
+            if y.grad is None:
+                return
+            dy = y.grad
+            if act != ops.ACT_NONE:
+                dpre = self.new(Bb, Go, Cc)
+                ops.act_bwd(pre, dy, dpre, act)
+                dy = dpre
+            if x.needs_grad:   # dx[b,g,c] += sum_go W[go,g] dy[b,go,c]
+                ops.sgemm(Wm, (1, G), dy, (1, Cc), x.g(), (Cc, 1), G, Cc, Go, accumulate=True, batch=Bb,
+                          b_bs=Go * Cc, c_bs=G * Cc)
+            if W.grad is not None:   # dW[go,g] += sum_{b,c} dy[b,go,c] x[b,g,c]
+                for bi in range(Bb):
+                    ops.sgemm(dy[bi], (Cc, 1), x.data[bi], (Cc, 1), W.grad.view(Go, G), (G, 1), Go, G, Cc, accumulate=True)
+            if b.grad is not None:   # db[go] += sum_{b,c} dy
+                ops.sgemm(dy.view(Go, Cc), (Cc, 1), self._ones, (0, 1), b.grad, (1, 1), Go, 1, Cc, accumulate=True)
+        self.record(bwd)
+        return y
+
+    def layernorm(self, x: Var, w: Param, b: Param, add_rows: Optional[Param] = None) -> Var:
+        """y = LN(x) * w + b (+ add_rows[row % period])."""
+        D, R = x.cols, x.rows
+        y = Var(self.new(*x.data.shape))
+        stats = self.new(R, 2)
+        period = add_rows.data.shape[0] if add_rows is not None else 0
+        ops.layernorm_fwd(x.data, w.data, b.data, y.data, stats, R, D,
+                          add_rows=None if add_rows is None else add_rows.data, add_period=period)
+
+        def bwd():
+            if y.grad is None:
+                return
+            if add_rows is not None and add_rows.grad is not None:   # d pe[t] += sum over the batch of dy
+                reps = R // period
+                for r in range(reps):
+                    ops.axpy(add_rows.grad, y.grad.view(reps, period * D)[r], 1.0, add_rows.grad, period * D)
+            train = w.grad is not None
+            dx = x.g() if x.needs_grad else self.new(*x.data.shape)
+            ops.layernorm_bwd(y.grad, x.data, w.data, stats, dx, R, D, accumulate=x.needs_grad,
+                              dw=w.grad if train else None, db=b.grad if train else None)
+        self.record(bwd)
+        return y
+
+    def add(self, a: Var, b: Var) -> Var:
+        y = Var(self.new(*a.data.shape))
+        ops.axpy(a.data, b.data, 1.0, y.data)
+
+        def bwd():
+            if y.grad is None:
+                return
+            for v in (a, b):
+                if v.needs_grad:
+                    g = v.g()
+                    ops.axpy(g, y.grad, 1.0, g)
+        self.record(bwd)
+        return y
+
+    def add_rows_param(self, a: Var, p: Param) -> Var:
+        """y[b, t, :] = a[b, t, :] + p[t, :]  (with_pos_embed, adapter_modules.py:64-65)."""
+        Bb = a.data.shape[0]
+        per = p.data.numel()
+        y = Var(self.new(*a.data.shape))
+        for bi in range(Bb):
+            ops.axpy(a.data[bi], p.data, 1.0, y.data[bi], per)
+
+        def bwd():
+            if y.grad is None:
+                return
+            if a.needs_grad:
+                g = a.g()
+                ops.axpy(g, y.grad, 1.0, g)
+            if p.grad is not None:
+                for bi in range(Bb):
+                    ops.axpy(p.grad, y.grad[bi], 1.0, p.grad, per)
+        self.record(bwd)
+        return y
+
+    def token_mha(self, q: Var, k: Var, v: Var, heads: int) -> Var:
+        Bb, T, E = q.data.shape
+        out = Var(self.new(Bb, T, E))
+        probs = self.new(Bb, heads, T, T)
+        ops.token_mha_fwd(q.data, k.data, v.data, out.data, probs, Bb, T, E, heads)
+
+        def bwd():
+            if out.grad is None:
+                return
+            dq, dk, dv = self.new(Bb, T, E), self.new(Bb, T, E), self.new(Bb, T, E)
+            ops.token_mha_bwd(q.data, k.data, v.data, probs, out.grad, dq, dk, dv, Bb, T, E, heads)
+            for var, d in ((q, dq), (k, dk), (v, dv)):
+                g = var.g()
+                ops.axpy(g, d, 1.0, g)
+        self.record(bwd)
+        return out

@@ -1,0 +1,444 @@
+"""GPU parity tests of the individual C-ABI kernels against fp64 torch-CPU restatements / the oracle.
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import unit_inputs  # noqa: E402
+from modaltune_amd import synth  # noqa: E402
+from modaltune_amd.config import ModelConfig, branch_table, segment_lengths  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rng(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (1000, 192, 768), (257, 3072, 768), (130, 768, 3072), (515, 384, 768)])
+def test_gemm_nt_bias(ops, M, N, K):
+    g = rng(M + N)
+    A = torch.randn(M, K, generator=g).half()
+    W = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    for dt in (torch.float16, torch.float32):
+        out = torch.zeros(M, N, dtype=dt, device=DEV)
+        ops.gemm_nt(A.to(DEV), W.to(DEV), out, M, N, K, bias=bias.to(DEV))
+        torch.cuda.synchronize()
+        assert rel(out, ref) < (2e-3 if dt == torch.float16 else 2e-5)
+
+
+def test_gemm_nt_rowmaps_resid_inject_posemb(ops):
+    from modaltune_amd._lib import rowmap
+    g = rng(7)
+    B, L, N_, K, Nc = 3, 70, 71, 768, 768
+    # A is a [B*N_, K] token buffer; logical rows = the patch rows (skip row 0 of every pass)
+    Abuf = torch.randn(B * N_, K, generator=g).half()
+    W = (torch.randn(Nc, K, generator=g) * 0.05).half()
+    bias = torch.randn(Nc, generator=g)
+    resid = torch.randn(L, Nc, generator=g)            # one slide broadcast to the B passes
+    gamma = torch.randn(Nc, generator=g) * 0.1
+    M = B * L
+    amap = rowmap(L, N_, 1)
+    cmap = rowmap(L, N_, 1)
+    rmap = rowmap(L, 0, 0)
+    out = torch.zeros(B * N_, Nc, device=DEV)
+    ops.gemm_nt(Abuf.to(DEV), W.to(DEV), out, M, Nc, K, amap=amap, cmap=cmap, epilogue=ops.EPI_INJECT, bias=bias.to(DEV),
+                resid=resid.to(DEV), ldr=Nc, rmap=rmap, colscale=gamma.to(DEV))
+    torch.cuda.synchronize()
+    A3 = Abuf.view(B, N_, K)[:, 1:].double()
+    ref = (1 + gamma.double()) * resid.double() + gamma.double() * (A3 @ W.double().t() + bias.double())
+    got = out.view(B, N_, Nc)[:, 1:]
+    assert rel(got, ref) < 2e-5
+    assert float(out.view(B, N_, Nc)[:, 0].abs().max()) == 0.0      # cls rows untouched
+    # BIAS_RESID accumulate in place (dx += dy @ W)
+    acc = torch.randn(M, Nc, generator=g)
+    acc_d = acc.to(DEV).clone()
+    A2 = torch.randn(M, K, generator=g).half()
+    ops.gemm_nt(A2.to(DEV), W.to(DEV), acc_d, M, Nc, K, epilogue=ops.EPI_BIAS_RESID, resid=acc_d, ldr=Nc)
+    torch.cuda.synchronize()
+    assert rel(acc_d, acc.double() + A2.double() @ W.double().t()) < 2e-5
+    # POSEMB
+    from modaltune_amd.config import sincos_1d_table
+    tab = torch.from_numpy(sincos_1d_table(64, Nc // 2))
+    prow = torch.randint(0, 64, (M,), generator=g, dtype=torch.int32)
+    pcol = torch.randint(0, 64, (M,), generator=g, dtype=torch.int32)
+    out2 = torch.zeros(M, Nc, device=DEV)
+    ops.gemm_nt(A2.to(DEV), W.to(DEV), out2, M, Nc, K, epilogue=ops.EPI_POSEMB, bias=bias.to(DEV), pos_table=tab.to(DEV),
+                pos_row=prow.to(DEV), pos_col=pcol.to(DEV))
+    torch.cuda.synchronize()
+    ref2 = A2.double() @ W.double().t() + bias.double() + torch.cat([tab[pcol.long()], tab[prow.long()]], 1).double()
+    assert rel(out2, ref2) < 2e-5
+
+
+@pytest.mark.parametrize("M,N1,N2", [(1000, 192, 768), (4097, 64, 64), (333, 384, 768), (9000, 768, 192)])
+def test_gemm_tn_and_colsum(ops, M, N1, N2):
+    g = rng(M)
+    A = torch.randn(M, N1, generator=g).half()
+    B = torch.randn(M, N2, generator=g).half()
+    out = torch.zeros(N1, N2, device=DEV)
+    ops.gemm_tn(A.to(DEV), B.to(DEV), out, M, N1, N2)
+    cs = torch.zeros(N1, device=DEV)
+    ops.colsum(A.to(DEV), cs, M, N1)
+    torch.cuda.synchronize()
+    assert rel(out, A.double().t() @ B.double()) < 1e-4
+    assert rel(cs, A.double().sum(0)) < 1e-4
+
+
+def test_sgemm_small(ops):
+    g = rng(3)
+    M, N, K = 65, 50, 77
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    out = torch.zeros(M, N, device=DEV)
+    ops.sgemm(A.to(DEV), (K, 1), Bm.to(DEV), (K, 1), out, (N, 1), M, N, K, bias=bias.to(DEV), act=ops.ACT_GELU)
+    torch.cuda.synchronize()
+    assert rel(out, torch.nn.functional.gelu(A.double() @ Bm.double().t() + bias.double())) < 1e-5
+    # transposed operands + accumulate + batch + bias on rows:  C[b] (n-major) += A[b]^T-strided
+    Bt = 3
+    A2 = torch.randn(Bt, K, M, generator=g)       # element (m,k) at k*M + m
+    C0 = torch.randn(Bt, N, M, generator=g)       # element (m,n) at n*M + m
+    bm = torch.randn(M, generator=g)
+    Cd = C0.to(DEV).clone()
+    ops.sgemm(A2.to(DEV), (1, M), Bm.to(DEV), (K, 1), Cd, (1, M), M, N, K, bias=bm.to(DEV), bias_on_m=True, accumulate=True,
+              batch=Bt, a_bs=K * M, b_bs=0, c_bs=N * M)
+    torch.cuda.synchronize()
+    ref = C0.double() + (A2.double().transpose(1, 2) @ Bm.double().t() + bm.double()[:, None]).transpose(1, 2)
+    assert rel(Cd, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("D", [256, 768, 2304, 3072])
+def test_layernorm_fwd_bwd_f32(ops, D):
+    g = rng(D)
+    M = 67
+    x = torch.randn(M, D, generator=g) * 2 + 0.5
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    b = 0.1 * torch.randn(D, generator=g)
+    add = torch.randn(5, D, generator=g)
+    dy = torch.randn(M, D, generator=g)
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (D,), wd, bd, 1e-5) + add.double()[torch.arange(M) % 5]
+    ref.backward(dy.double())
+    y = torch.zeros(M, D, device=DEV)
+    stats = torch.zeros(M, 2, device=DEV)
+    ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), y, stats, M, D, add_rows=add.to(DEV), add_period=5)
+    dx = torch.zeros(M, D, device=DEV)
+    dw = torch.zeros(D, device=DEV)
+    db = torch.zeros(D, device=DEV)
+    if D <= 768:
+        ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), stats, dx, M, D, dw=dw, db=db)
+    else:
+        ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), stats, dx, M, D)
+    torch.cuda.synchronize()
+    assert rel(y, ref) < 1e-5
+    assert rel(dx, xd.grad) < 1e-4
+    if D <= 768:
+        assert rel(dw, wd.grad) < 1e-4 and rel(db, bd.grad) < 1e-4
+
+
+def test_layernorm_gelu_f16_and_accumulate(ops):
+    g = rng(11)
+    M, D = 130, 3072
+    a = (torch.randn(M, D, generator=g) * 1.5).half()
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    b = 0.1 * torch.randn(D, generator=g)
+    dy = torch.randn(M, D, generator=g).half()
+    ad = a.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(torch.nn.functional.gelu(ad), (D,), w.double(), b.double(), 1e-5)
+    ref.backward(dy.double())
+    y = torch.zeros(M, D, device=DEV, dtype=torch.float16)
+    stats = torch.zeros(M, 2, device=DEV)
+    ops.layernorm_fwd(a.to(DEV), w.to(DEV), b.to(DEV), y, stats, M, D, gelu_in=True)
+    da = torch.zeros(M, D, device=DEV, dtype=torch.float16)
+    ops.layernorm_bwd(dy.to(DEV), a.to(DEV), w.to(DEV), stats, da, M, D, gelu_in=True)
+    torch.cuda.synchronize()
+    assert rel(y, ref) < 2e-3
+    assert rel(da, ad.grad) < 3e-3
+    # fp32 residual stream: dy fp16, x fp32, dx fp32 accumulated, through a row map
+    from modaltune_amd._lib import rowmap
+    D2, B, L, N_ = 768, 2, 33, 34
+    x = torch.randn(B * N_, D2, generator=g)
+    w2 = 1 + 0.1 * torch.randn(D2, generator=g)
+    dyh = torch.randn(B * L, D2, generator=g).half()
+    acc0 = torch.randn(B * N_, D2, generator=g)
+    xd = x.view(B, N_, D2)[:, 1:].double().requires_grad_(True)
+    r2 = torch.nn.functional.layer_norm(xd, (D2,), w2.double(), torch.zeros(D2).double(), 1e-5)
+    r2.backward(dyh.double().view(B, L, D2))
+    yy = torch.zeros(B * L, D2, device=DEV, dtype=torch.float16)
+    st = torch.zeros(B * L, 2, device=DEV)
+    xm = rowmap(L, N_, 1)
+    ops.layernorm_fwd(x.to(DEV), w2.to(DEV), torch.zeros(D2, device=DEV), yy, st, B * L, D2, xmap=xm)
+    accd = acc0.to(DEV).clone()
+    ops.layernorm_bwd(dyh.to(DEV), x.to(DEV), w2.to(DEV), st, accd, B * L, D2, xmap=xm, dxmap=xm, accumulate=True)
+    torch.cuda.synchronize()
+    assert rel(yy.view(B, L, D2), r2) < 2e-3
+    want = acc0.double().view(B, N_, D2).clone()
+    want[:, 1:] += xd.grad
+    assert rel(accd, want.view(B * N_, D2)) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ dilated attention
+def _attn_case(case, B=2):
+    N, segs, ratios = unit_inputs.LAYER_CASES[case]
+    return N, segs, ratios
+
+
+def _qkv_for_case(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "unit_layer.npz"))
+    seed = int(g["seed"])
+    N, segs, ratios = unit_inputs.LAYER_CASES[case]
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)))
+    sd = {k: torch.from_numpy(v).double() for k, v in synth.synth_state_dict(cfg, synth.toy_group_sizes(), seed).items()
+          if k.startswith("encoder.layers.0.self_attn.")}
+    x = torch.from_numpy(unit_inputs.layer_inputs(seed, N)) * unit_inputs.ATTN_INPUT_SCALE
+    p = "encoder.layers.0.self_attn."
+    q, k, v = (torch.nn.functional.linear(x, sd[p + f"{n}_proj.weight"], sd[p + f"{n}_proj.bias"]) for n in "qkv")
+    return g, N, segs, ratios, torch.cat([q, k, v], dim=-1)      # [B, N, 2304] float64
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_dilated_attention_fwd_mix_vs_reference_golden(ops, golden_dir, case):
+    from oracle import modaltune_oracle as O
+    g, N, segs, ratios, qkv = _qkv_for_case(golden_dir, case)
+    B = qkv.shape[0]
+    M = B * N
+    qkv16 = qkv.half()
+    bt = branch_table(N, segs, ratios)
+    plan = ops.make_plan(bt, N, B)
+    nb = len(bt)
+    o_br = torch.zeros(nb, M, 768, dtype=torch.float16, device=DEV)
+    lse_br = torch.zeros(nb, M, 16, device=DEV)
+    ops.dilated_attn_fwd(qkv16.to(DEV).view(M, 2304), plan, o_br, lse_br)
+    ln_w = torch.ones(768, device=DEV)
+    ln_b = torch.zeros(768, device=DEV)
+    y = torch.zeros(M, 768, dtype=torch.float16, device=DEV)
+    stats = torch.zeros(M, 2, device=DEV)
+    lse_tot = torch.zeros(M, 16, device=DEV)
+    ops.dilated_mix_ln_fwd(o_br, lse_br, plan, ln_w, ln_b, y, stats, lse_tot)
+    torch.cuda.synchronize()
+    # reference on the SAME fp16-rounded q,k,v (isolates kernel error from input rounding)
+    q, k, v = (t.view(B, N, 16, 48) for t in qkv16.double().split(768, dim=-1))
+    mixed, outs, lses = O.dilated_attention_core(q, k, v, segs, ratios, return_branches=True)
+    for i, b in enumerate(bt):
+        cov = lses[i] > -1e7                                  # [B, N, H]
+        got_o = o_br[i].view(B, N, 16, 48).double().cpu()
+        got_l = lse_br[i].view(B, N, 16).double().cpu()
+        assert float(((got_o - outs[i]).abs() * cov.unsqueeze(-1)).max()) < 3e-3 * float(outs[i].abs().max())
+        assert float(((got_l - lses[i]).abs() * cov).max()) < 2e-3
+    ref_ln = torch.nn.functional.layer_norm(mixed, (768,), None, None, 1e-5)
+    assert rel(y.view(B, N, 768), ref_ln) < 4e-3
+    # and against the golden produced by the reference's own DilatedAttention on fp64 inputs
+    gold = torch.from_numpy(g[f"{case}_attn"]).double()
+    gold_ln = torch.nn.functional.layer_norm(gold, (768,), None, None, 1e-5)
+    assert rel(y.view(B, N, 768), gold_ln) < 6e-3
+    tot = torch.logsumexp(torch.stack(lses, 0), dim=0)
+    assert float((lse_tot.view(B, N, 16).double().cpu() - tot).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_dilated_attention_bwd_vs_oracle_autograd(ops, golden_dir, case):
+    from oracle import modaltune_oracle as O
+    g, N, segs, ratios, qkv = _qkv_for_case(golden_dir, case)
+    B = qkv.shape[0]
+    M = B * N
+    qkv16 = qkv.half()
+    bt = branch_table(N, segs, ratios)
+    plan = ops.make_plan(bt, N, B)
+    nb = len(bt)
+    gen = rng(5)
+    ln_w = (1 + 0.1 * torch.randn(768, generator=gen))
+    ln_b = 0.1 * torch.randn(768, generator=gen)
+    dy = (torch.randn(B, N, 768, generator=gen) * 0.1).half()
+    # oracle: fp64 autograd through dilated attention + inner LN on the fp16-rounded inputs
+    qd = qkv16.double().requires_grad_(True)
+    q, k, v = (t.view(B, N, 16, 48) for t in qd.split(768, dim=-1))
+    mixed = O.dilated_attention_core(q, k, v, segs, ratios)
+    yref = torch.nn.functional.layer_norm(mixed, (768,), ln_w.double(), ln_b.double(), 1e-5)
+    yref.backward(dy.double())
+    # HIP
+    qkv_d = qkv16.to(DEV).view(M, 2304)
+    o_br = torch.zeros(nb, M, 768, dtype=torch.float16, device=DEV)
+    lse_br = torch.zeros(nb, M, 16, device=DEV)
+    ops.dilated_attn_fwd(qkv_d, plan, o_br, lse_br)
+    y = torch.zeros(M, 768, dtype=torch.float16, device=DEV)
+    stats = torch.zeros(M, 2, device=DEV)
+    lse_tot = torch.zeros(M, 16, device=DEV)
+    ops.dilated_mix_ln_fwd(o_br, lse_br, plan, ln_w.to(DEV), ln_b.to(DEV), y, stats, lse_tot)
+    dmixed = torch.zeros(M, 768, dtype=torch.float16, device=DEV)
+    delta = torch.zeros(nb, M, 16, device=DEV)
+    ops.dilated_mix_ln_bwd(dy.to(DEV).view(M, 768), o_br, lse_br, lse_tot, plan, ln_w.to(DEV), stats, dmixed, delta)
+    dqkv = torch.full((M, 2304), float("nan"), device=DEV)
+    ops.dilated_attn_bwd(qkv_d, dmixed, lse_tot, delta, plan, dqkv)
+    torch.cuda.synchronize()
+    assert rel(y.view(B, N, 768), yref) < 4e-3
+    got = dqkv.view(B, N, 2304).double().cpu()
+    assert torch.isfinite(got).all()
+    for name, sl in (("dq", slice(0, 768)), ("dk", slice(768, 1536)), ("dv", slice(1536, 2304))):
+        r = rel(got[..., sl], qd.grad[..., sl])
+        assert r < 2e-2, (name, r)
+
+
+# ------------------------------------------------------------------------------------------ adapter attention
+def _mha_ref(q, k, v, heads):
+    B, Lq, E = q.shape
+    hd = E // heads
+    qh = q.view(B, Lq, heads, hd).transpose(1, 2)
+    kh = k.view(B, -1, heads, hd).transpose(1, 2)
+    vh = v.view(B, -1, heads, hd).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(hd)
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, E)
+
+
+@pytest.mark.parametrize("T", [65, 7])
+def test_inject_attention(ops, T):
+    g = rng(T)
+    B, L = 3, 301
+    q = torch.randn(B, L, 192, generator=g).half()
+    k = torch.randn(B, T, 192, generator=g)
+    v = torch.randn(B, T, 192, generator=g)
+    da = torch.randn(B, L, 192, generator=g).half()
+    qd, kd, vd = q.double().requires_grad_(True), k.double().requires_grad_(True), v.double().requires_grad_(True)
+    ref = _mha_ref(qd, kd, vd, 12)
+    ref.backward(da.double())
+    a = torch.zeros(B * L, 192, dtype=torch.float16, device=DEV)
+    ops.inject_attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), a, B * L, L, T)
+    dq = torch.zeros(B * L, 192, dtype=torch.float16, device=DEV)
+    dk = torch.zeros(B, T, 192, device=DEV)
+    dv = torch.zeros(B, T, 192, device=DEV)
+    ops.inject_attn_bwd(q.to(DEV), da.to(DEV), k.to(DEV), v.to(DEV), dq, dk, dv, B * L, L, T)
+    torch.cuda.synchronize()
+    assert rel(a.view(B, L, 192), ref) < 2e-3
+    assert rel(dq.view(B, L, 192), qd.grad) < 3e-3
+    assert rel(dk, kd.grad) < 1e-4 and rel(dv, vd.grad) < 1e-4
+
+
+@pytest.mark.parametrize("T,L,nsplit", [(65, 700, 4), (7, 129, 1), (66, 1000, 16)])
+def test_extract_attention(ops, T, L, nsplit):
+    g = rng(T + L)
+    B = 2
+    q = torch.randn(B, T, 192, generator=g)
+    kv = torch.randn(B, L, 384, generator=g).half()
+    dout = torch.randn(B, T, 192, generator=g)
+    qd = q.double().requires_grad_(True)
+    kvd = kv.double().requires_grad_(True)
+    ref = _mha_ref(qd, kvd[..., :192], kvd[..., 192:], 12)
+    ref.backward(dout.double())
+    out = torch.zeros(B, T, 192, device=DEV)
+    lse = torch.zeros(B, T, 12, device=DEV)
+    pa = torch.zeros(B * 12 * nsplit * T * 16, device=DEV)
+    pm = torch.zeros(B * 12 * nsplit * T * 2, device=DEV)
+    ops.extract_attn_fwd(q.to(DEV), kv.to(DEV), out, lse, pa, pm, B, T, L, nsplit)
+    dq = torch.zeros(B, T, 192, device=DEV)
+    dkv = torch.zeros(B * L, 384, dtype=torch.float16, device=DEV)
+    ops.extract_attn_bwd(q.to(DEV), kv.to(DEV), out, lse, dout.to(DEV), dq, dkv, B, T, L)
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 1e-5
+    assert rel(dq, qd.grad) < 1e-4
+    assert rel(dkv.view(B, L, 384), kvd.grad) < 3e-3
+
+
+@pytest.mark.parametrize("T", [65, 7])
+def test_token_mha(ops, T):
+    g = rng(T + 100)
+    B, E = 3, 192
+    q, k, v, do = (torch.randn(B, T, E, generator=g) for _ in range(4))
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = _mha_ref(qd, kd, vd, 12)
+    ref.backward(do.double())
+    out = torch.zeros(B, T, E, device=DEV)
+    probs = torch.zeros(B, 12, T, T, device=DEV)
+    ops.token_mha_fwd(q.to(DEV), k.to(DEV), v.to(DEV), out, probs, B, T, E, 12)
+    dq, dk, dv = (torch.zeros(B, T, E, device=DEV) for _ in range(3))
+    ops.token_mha_bwd(q.to(DEV), k.to(DEV), v.to(DEV), probs, do.to(DEV), dq, dk, dv, B, T, E, 12)
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 1e-5
+    assert rel(dq, qd.grad) < 1e-4 and rel(dk, kd.grad) < 1e-4 and rel(dv, vd.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ loss / optimiser / misc
+def test_distill_loss_and_adamw(ops):
+    from oracle import modaltune_oracle as O
+    g = rng(9)
+    logits = torch.randn(3, 256, generator=g)
+    text = torch.randn(4, 256, generator=g)
+    text = text / text.norm(dim=-1, keepdim=True)
+    ld = logits.double().requires_grad_(True)
+    ref = O.distill_loss(ld, text.double())
+    ref.backward()
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.zeros(3, 256, device=DEV)
+    ops.distill_loss(logits.to(DEV), text[[0, 1, 3]].contiguous().to(DEV), loss, dl, 3, 256, loss_scale=4.0)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref.detach())) < 1e-5 * abs(float(ref.detach()))
+    assert rel(dl / 4.0, ld.grad) < 1e-4
+    # AdamW, two steps, with a loss scale
+    n = 10007
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    p, m, v = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    scale = torch.tensor([8.0], device=DEV)
+    found = torch.zeros(1, dtype=torch.int32, device=DEV)
+    pr, mr, vr = p0.double(), torch.zeros(n).double(), torch.zeros(n).double()
+    for step in (1, 2):
+        ops.check_finite(gr.to(DEV) * 8.0, n, found)
+        ops.adamw_step(p, (gr * 8.0).to(DEV), m, v, n, 5e-6, 0.9, 0.999, 1e-8, 0.01, step, scale, found)
+        pr, mr, vr = O.adamw_update(pr, gr.double(), mr, vr, step, 5e-6)
+    torch.cuda.synchronize()
+    assert int(found) == 0
+    assert rel(p, pr) < 1e-6
+    # non-finite gradient -> update skipped
+    bad = (gr * 8.0).to(DEV).clone()
+    bad[5] = float("inf")
+    before = p.clone()
+    ops.check_finite(bad, n, found)
+    ops.adamw_step(p, bad, m, v, n, 5e-6, 0.9, 0.999, 1e-8, 0.01, 3, scale, found)
+    torch.cuda.synchronize()
+    assert int(found) == 1 and torch.equal(p, before)
+
+
+def test_elementwise(ops):
+    g = rng(21)
+    n = 4099
+    x = torch.randn(n, generator=g)
+    dy = torch.randn(n, generator=g)
+    for act, f in ((ops.ACT_RELU, torch.relu), (ops.ACT_GELU, torch.nn.functional.gelu), (ops.ACT_ELU, torch.nn.functional.elu)):
+        xd = x.double().requires_grad_(True)
+        r = f(xd)
+        r.backward(dy.double())
+        y = torch.zeros(n, device=DEV)
+        dx = torch.zeros(n, device=DEV)
+        ops.act_fwd(x.to(DEV), y, act)
+        ops.act_bwd(x.to(DEV), dy.to(DEV), dx, act)
+        torch.cuda.synchronize()
+        assert rel(y, r) < 1e-6 and rel(dx, xd.grad) < 1e-5
+    h = torch.zeros(n, dtype=torch.float16, device=DEV)
+    ops.cast_f32_to_f16(x.to(DEV), h)
+    back = torch.zeros(n, device=DEV)
+    ops.cast_f16_to_f32(h, back)
+    torch.cuda.synchronize()
+    assert torch.equal(h.cpu(), x.half()) and torch.equal(back.cpu(), x.half().float())
