@@ -163,6 +163,9 @@ int mt_token_mha_bwd(const float* q, const float* k, const float* v, const float
 /* ------------------------------------------------------------ elementwise -------------------------- */
 int mt_cast_f32_to_f16(const float* x, mt_half* y, long n, mt_stream_t stream);
 int mt_cast_f16_to_f32(const mt_half* x, float* y, long n, mt_stream_t stream);
+/* Derived fp16 weight cache of an fp32 nn.Linear weight [R, C]: as stored (forward, W[N,K]) or transposed
+ * (the dX GEMM's W^T[K,N]); re-run for trainable weights after every optimiser step (SURVEY §8b ownership). */
+int mt_pack_weight_f16(const float* src, int R, int C, mt_half* dst, int transpose, mt_stream_t stream);
 /* y = act(x) / dx = dy * act'(x) on fp32 vectors (ELU GE:178, GELU GE:187, ReLU AM:286) */
 int mt_act_fwd(const float* x, float* y, long n, int act, mt_stream_t stream);
 int mt_act_bwd(const float* x, const float* dy, float* dx, long n, int act, mt_stream_t stream);
@@ -180,17 +183,24 @@ int mt_inject_resid_bwd(const float* dy, long lddy, const MtRowMap* dymap, const
                         mt_stream_t stream);
 
 /* ---------------------------------------------------------- head, loss, optimiser ------------------ */
+/* y[r,:] = x[r,:] / ||x[r,:]||_2 for R contiguous rows of O (projected text rows, TM:213) */
+int mt_l2norm_rows(const float* x, float* y, int R, int O, mt_stream_t stream);
 /* logits [R,O] -> L2-normalise rows, log_softmax, KL(sum) against softmax(target rows) * 10 (TM:225-233).
  * Writes loss (1 float) and dlogits [R,O] scaled by `loss_scale` (GradScaler semantics, TM:107,235). */
-int mt_distill_loss(const float* logits, const float* target, int R, int O, float loss_scale, float* loss,
+int mt_distill_loss(const float* logits, const float* target, int R, int O, float loss_scale,
+                    const float* scale_dev /* device scalar multiplied into loss_scale, or NULL */, float* loss,
                     float* dlogits, mt_stream_t stream);
 
 /* Fused multi-tensor AdamW over one flat fp32 parameter/gradient buffer (torch.optim.AdamW, TM:145-149) with
  * GradScaler.step semantics (TM:235-237): grads are divided by *scale; if any is non-finite the update is
  * skipped and *found_inf is set.  step_count is 1-based. */
 int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step_count, const float* scale, int* found_inf,
-                  mt_stream_t stream);
+                  float eps, float weight_decay, int step_count, const int* step_dev /* device count of completed
+                  steps (overrides step_count - 1) or NULL */, float grad_mult /* e.g. 1/world_size */,
+                  const float* scale, int* found_inf, mt_stream_t stream);
+/* GradScaler.update on device (TM:237): *found_inf ? scale *= backoff : (every `interval` clean steps scale *= growth) */
+int mt_scaler_update(float* scale, int* growth_tracker, int* found_inf, int* step_dev /* ++ on a clean step, or NULL */,
+                     float growth, float backoff, int interval, mt_stream_t stream);
 int mt_check_finite(const float* g, long n, int* found_inf, mt_stream_t stream);
 
 #ifdef __cplusplus

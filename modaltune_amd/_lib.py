@@ -59,13 +59,16 @@ SIGNATURES = {
     "mt_token_mha_bwd": [P, P, P, P, P, I, I, I, I, P, P, P, P],
     "mt_cast_f32_to_f16": [P, P, L, P],
     "mt_cast_f16_to_f32": [P, P, L, P],
+    "mt_pack_weight_f16": [P, I, I, P, I, P],
     "mt_act_fwd": [P, P, L, I, P],
     "mt_act_bwd": [P, P, P, L, I, P],
     "mt_axpy": [P, P, F, P, L, P],
     "mt_copy_rows_f32": [P, L, RM, P, L, RM, I, I, I, P],
     "mt_inject_resid_bwd": [P, L, RM, P, L, RM, P, P, P, L, RM, I, P, P, I, I, P],
-    "mt_distill_loss": [P, P, I, I, F, P, P, P],
-    "mt_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, P, P, P],
+    "mt_l2norm_rows": [P, P, I, I, P],
+    "mt_distill_loss": [P, P, I, I, F, P, P, P, P],
+    "mt_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, P, F, P, P, P],
+    "mt_scaler_update": [P, P, P, P, F, F, I, P],
     "mt_check_finite": [P, L, P, P],
 }
 _RESTYPE = {"mt_status_string": C.c_char_p}

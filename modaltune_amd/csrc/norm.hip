@@ -268,6 +268,29 @@ __global__ __launch_bounds__(256) void inject_resid_bwd_kernel(InjBwdArgs a) {
   for (int i = threadIdx.x; i < D; i += 256) atomicAdd(&a.dgamma[i], red[0][i] + red[1][i] + red[2][i] + red[3][i]);
 }
 
+// fp32 [R, C] -> fp16 [R, C] (transpose = 0) or fp16 [C, R] (transpose = 1), 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__ src, int R, int C, h16* __restrict__ dst, int transpose) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (transpose) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;
+      if (r < R && c < C) dst[(long)c * R + r] = (h16)tile[tx][ty + 8 * i];
+    } else {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      if (r < R && c < C) dst[(long)r * C + c] = (h16)tile[ty + 8 * i][tx];
+    }
+  }
+}
+
 int ew_grid(long n) { return (int)max(1L, min((n + 1023) / 1024, 4096L)); }
 
 }  // namespace
@@ -326,6 +349,12 @@ extern "C" int mt_cast_f32_to_f16(const float* x, mt_half* y, long n, mt_stream_
 extern "C" int mt_cast_f16_to_f32(const mt_half* x, float* y, long n, mt_stream_t stream) {
   if (!x || !y || n <= 0) return MT_ERR_BAD_ARG;
   hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, (const h16*)x, y, n);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_pack_weight_f16(const float* src, int R, int C, mt_half* dst, int transpose, mt_stream_t stream) {
+  if (!src || !dst || R <= 0 || C <= 0) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pack_f16_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, (hipStream_t)stream, src, R, C, (h16*)dst, transpose);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -7,7 +7,9 @@ namespace {
 //   z = logit / ||logit||; loss = 10 * sum_r sum_j p_rj (log p_rj - log_softmax(z_r)_j), p = softmax(target_r)
 // d loss / d z_rj = 10 * (softmax(z_r)_j - p_rj)   (sum_j p_rj = 1);  d/d logit = (dz - z (z . dz)) / ||logit||
 __global__ __launch_bounds__(256) void distill_loss_kernel(const float* __restrict__ logits, const float* __restrict__ target, int R, int O,
-                                                           float loss_scale, float* __restrict__ loss, float* __restrict__ dlogits) {
+                                                           float loss_scale_host, const float* __restrict__ scale_dev,
+                                                           float* __restrict__ loss, float* __restrict__ dlogits) {
+  const float loss_scale = loss_scale_host * (scale_dev ? *scale_dev : 1.0f);
   __shared__ float red[256];
   __shared__ float bc[4];
   const int tid = threadIdx.x;
@@ -56,10 +58,15 @@ __global__ __launch_bounds__(256) void distill_loss_kernel(const float* __restri
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
-                             const float* __restrict__ scale, const int* __restrict__ found_inf) {
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float grad_mult,
+                             const float* __restrict__ scale, const int* __restrict__ found_inf, const int* __restrict__ step_dev) {
   if (found_inf && *found_inf) return;       // GradScaler.step: skip the whole update when a grad is inf/nan
-  const float inv_scale = scale ? 1.0f / *scale : 1.0f;
+  if (step_dev) {                            // optimiser step count lives on the device (skipped steps do not count)
+    const float st = (float)(*step_dev + 1);
+    bc1 = 1.0f - powf(b1, st);
+    bc2s = sqrtf(1.0f - powf(b2, st));
+  }
+  const float inv_scale = grad_mult * (scale ? 1.0f / *scale : 1.0f);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * inv_scale;
     float pi = p[i] * (1.0f - lr * wd);
@@ -77,25 +84,66 @@ __global__ void check_finite_kernel(const float* __restrict__ g, long n, int* __
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
 }
 
+// y[r] = x[r] / ||x[r]||_2 : one workgroup per row (text / ||text||, TM:213)
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int O) {
+  __shared__ float red[256];
+  const float* xr = x + (long)blockIdx.x * O;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < O; j += 256) s += xr[j] * xr[j];
+  red[threadIdx.x] = s; __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  const float inv = 1.0f / sqrtf(red[0]);
+  for (int j = threadIdx.x; j < O; j += 256) y[(long)blockIdx.x * O + j] = xr[j] * inv;
+}
+
+// torch.cuda.amp.GradScaler.update (TM:107,237): backoff 0.5 on overflow, x2 after `interval` clean steps.
+__global__ void scaler_update_kernel(float* scale, int* tracker, int* found_inf, int* step_dev, float growth, float backoff, int interval) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (*found_inf) { *scale *= backoff; *tracker = 0; }
+  else {
+    if (step_dev) ++(*step_dev);
+    if (++(*tracker) >= interval) { *scale *= growth; *tracker = 0; }
+  }
+  *found_inf = 0;
+}
+
 }  // namespace
 
-extern "C" int mt_distill_loss(const float* logits, const float* target, int R, int O, float loss_scale, float* loss,
-                               float* dlogits, mt_stream_t stream) {
+extern "C" int mt_l2norm_rows(const float* x, float* y, int R, int O, mt_stream_t stream) {
+  if (!x || !y || R < 1 || O < 1) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, x, y, O);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_scaler_update(float* scale, int* growth_tracker, int* found_inf, int* step_dev, float growth,
+                                float backoff, int interval, mt_stream_t stream) {
+  if (!scale || !growth_tracker || !found_inf || interval < 1) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale, growth_tracker, found_inf, step_dev,
+                     growth, backoff, interval);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_distill_loss(const float* logits, const float* target, int R, int O, float loss_scale,
+                               const float* scale_dev, float* loss, float* dlogits, mt_stream_t stream) {
   if (!logits || !target || !loss || !dlogits || R < 1 || O < 1) return MT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(distill_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, R, O, loss_scale, loss, dlogits);
+  hipLaunchKernelGGL(distill_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, R, O, loss_scale, scale_dev,
+                     loss, dlogits);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
 
 extern "C" int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int step_count, const float* scale, int* found_inf,
-                             mt_stream_t stream) {
-  if (!p || !g || !m || !v || n <= 0 || step_count < 1) return MT_ERR_BAD_ARG;
+                             float eps, float weight_decay, int step_count, const int* step_dev, float grad_mult,
+                             const float* scale, int* found_inf, mt_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || (step_count < 1 && !step_dev)) return MT_ERR_BAD_ARG;
+  if (step_count < 1) step_count = 1;
   const float bc1 = 1.0f - powf(beta1, (float)step_count);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step_count));
   const int grid = (int)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2s, scale, (const int*)found_inf);
+                     weight_decay, bc1, bc2s, grad_mult, scale, (const int*)found_inf, step_dev);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

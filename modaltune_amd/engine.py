@@ -1,0 +1,578 @@
+"""Explicit forward / backward schedule of the Modal-Adapter train step over the C-ABI HIP kernels.
+
+Mirrors LongNetGeneAdapter.forward (reference models/aggregators/longvit_adapter.py:205-347) for B task
+passes batched (multitask_forward, train_modaltune.py:156-179, batched as B = 3; mathematically identical
+with dropout off): frozen LongNet backbone (torchscale encoder.py:121-175) interleaved with the Injector /
+Extractor adapters (vitadapter/adapter_modules.py:296-369,459-523), the gene encoder
+(genomic_utils/gene_encoder.py:194-223) and the fusion head (longvit_adapter.py:309-347).
+
+torch is the allocator and the stream owner only: every arithmetic op below is a HIP kernel from
+include/modaltune_hip.h.  The patch side (B*N rows) runs fp16 operands / fp32 accumulation with an fp32
+residual stream; the token side (T <= 66 rows) runs fp32.  Backward is selective: activation gradients flow
+through all frozen layers, weight gradients exist only for adapter / gene / head parameters.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import rowmap
+from .config import ModelConfig, branch_table, coords_to_rowcol, segment_lengths, sincos_1d_table, DILATED_RATIOS
+from .synth import param_specs
+from .tape import Param, Tape, Var
+
+H16 = torch.float16
+F32 = torch.float32
+
+
+class ParamStore:
+    """All model tensors under the reference's state_dict names.  Trainable tensors are views of one flat fp32
+    buffer (16-byte aligned slots, state_dict order) with a matching flat gradient buffer, so AdamW and the
+    data-parallel gradient all-reduce are one launch / one collective each."""
+
+    def __init__(self, cfg: ModelConfig, group_sizes: Sequence[int], device):
+        self.cfg, self.group_sizes, self.device = cfg, list(group_sizes), device
+        self.specs = param_specs(cfg, group_sizes)
+        off = 0
+        self.slots: Dict[str, tuple] = {}
+        for k, shape, kind, train in self.specs:
+            if train:
+                n = int(np.prod(shape))
+                self.slots[k] = (off, n, shape)
+                off += (n + 3) // 4 * 4
+        self.n_flat = off
+        self.flat = torch.zeros(off, dtype=F32, device=device)
+        self.flat_grad = torch.zeros(off, dtype=F32, device=device)
+        self.tensors: Dict[str, torch.Tensor] = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        for k, shape, kind, train in self.specs:
+            if train:
+                o, n, _ = self.slots[k]
+                self.tensors[k] = self.flat[o:o + n].view(shape)
+                self.grads[k] = self.flat_grad[o:o + n].view(shape)
+            else:
+                self.tensors[k] = torch.zeros(shape, dtype=F32, device=device)
+
+    def load(self, state: Dict[str, "np.ndarray | torch.Tensor"], strict: bool = True):
+        missing = [k for k in self.tensors if k not in state]
+        extra = [k for k in state if k not in self.tensors]
+        if strict and (missing or extra):
+            raise KeyError(f"state_dict mismatch: missing {missing[:5]} unexpected {extra[:5]}")
+        for k, t in self.tensors.items():
+            if k in state:
+                v = state[k]
+                v = torch.from_numpy(np.asarray(v)) if not torch.is_tensor(v) else v
+                if tuple(v.shape) != tuple(t.shape):
+                    raise ValueError(f"{k}: shape {tuple(v.shape)} != {tuple(t.shape)}")
+                t.copy_(v.to(device=self.device, dtype=F32))
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach().clone() for k, v in self.tensors.items()}
+
+    def param(self, k: str) -> Param:
+        return Param(self.tensors[k], self.grads.get(k))
+
+
+class _W16:
+    """fp16 caches of one nn.Linear weight: as stored [N,K] (forward) and transposed [K,N] (dX GEMM)."""
+
+    def __init__(self, srcs: Sequence[torch.Tensor], device, need_t: bool = True):
+        self.srcs = list(srcs)
+        self.N = sum(s.shape[0] for s in srcs)
+        self.K = srcs[0].shape[1]
+        self.w = torch.empty(self.N, self.K, dtype=H16, device=device)
+        self.wt = torch.empty(self.K, self.N, dtype=H16, device=device) if need_t else None
+        self.refresh()
+
+    def refresh(self):
+        r = 0
+        for s in self.srcs:
+            n = s.shape[0]
+            ops.pack_weight(s, self.w[r:r + n], n, self.K, transpose=False)
+            r += n
+        if self.wt is not None:
+            if len(self.srcs) == 1:
+                ops.pack_weight(self.srcs[0], self.wt, self.N, self.K, transpose=True)
+            else:   # concatenated rows -> columns of the transposed copy
+                full = torch.empty(self.N, self.K, dtype=F32, device=self.w.device)
+                r = 0
+                for s in self.srcs:
+                    full[r:r + s.shape[0]].copy_(s)
+                    r += s.shape[0]
+                ops.pack_weight(full, self.wt, self.N, self.K, transpose=True)
+
+
+class Engine:
+    def __init__(self, cfg: ModelConfig, group_sizes: Sequence[int], device="cuda"):
+        cfg.validate()
+        self.cfg, self.device = cfg, torch.device(device)
+        self.group_sizes = list(group_sizes)
+        self.store = ParamStore(cfg, group_sizes, self.device)
+        self.tape = Tape(self.device)
+        self.seg_lengths = segment_lengths(cfg.max_wsi_size, cfg.tile_size)
+        self.pos_table = torch.from_numpy(sincos_1d_table(cfg.slide_ngrids, cfg.embed_dim // 2)).to(self.device)
+        self._frozen16: Dict[str, _W16] = {}
+        self._train16: Dict[str, _W16] = {}
+        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self._caches_ready = False
+        self.collect_taps = False      # tests: keep cls / token states after every interaction block
+        self.taps: Dict[str, torch.Tensor] = {}
+        self.T = cfg.num_tokens
+        self._mean_w = torch.full((max(self.T, 2),), 1.0 / max(1, cfg.gene.final_groups), device=self.device)
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state, strict=True):
+        self.store.load(state, strict)
+        self._caches_ready = False
+
+    def _build_caches(self):
+        t, dev, cfg = self.store.tensors, self.device, self.cfg
+        self._frozen16 = {"patch": _W16([t["patch_embed.proj.weight"]], dev, need_t=False)}
+        for l in range(cfg.depth):
+            p = f"encoder.layers.{l}."
+            self._frozen16[p + "qkv"] = _W16([t[p + "self_attn.q_proj.weight"], t[p + "self_attn.k_proj.weight"],
+                                              t[p + "self_attn.v_proj.weight"]], dev)
+            self._frozen16[p + "out"] = _W16([t[p + "self_attn.out_proj.weight"]], dev)
+            self._frozen16[p + "fc1"] = _W16([t[p + "ffn.fc1.weight"]], dev)
+            self._frozen16[p + "fc2"] = _W16([t[p + "ffn.fc2.weight"]], dev)
+            self._frozen16[p + "bqkv"] = torch.cat([t[p + "self_attn.q_proj.bias"], t[p + "self_attn.k_proj.bias"],
+                                                    t[p + "self_attn.v_proj.bias"]]).contiguous()
+        self._train16 = {}
+        for pref in self._cross_attn_prefixes():
+            self._train16[pref + "q_proj"] = _W16([t[pref + "q_proj.weight"]], dev)
+            self._train16[pref + "q_in"] = _W16([t[pref + "multihead_attn.q_proj_weight"]], dev)
+            self._train16[pref + "kv"] = _W16([t[pref + "multihead_attn.k_proj_weight"], t[pref + "multihead_attn.v_proj_weight"]], dev)
+            self._train16[pref + "out_in"] = _W16([t[pref + "multihead_attn.out_proj.weight"]], dev)
+            self._train16[pref + "output_proj"] = _W16([t[pref + "output_proj.weight"]], dev)
+        self._caches_ready = True
+
+    def refresh_trainable_caches(self):
+        """Re-derive the fp16 copies of the trainable big-M weights after an optimiser step."""
+        if not self._caches_ready:
+            self._build_caches()
+            return
+        for w in self._train16.values():
+            w.refresh()
+
+    def _cross_attn_prefixes(self) -> List[str]:
+        out = []
+        nint = len(self.cfg.interaction_indexes)
+        for i in range(nint):
+            out.append(f"interactions.{i}.injector.attn.")
+            out.append(f"interactions.{i}.extractor.attn.")
+            if i == nint - 1 and self.cfg.use_extra_extractor:
+                out += [f"interactions.{i}.extra_extractors.{j}.attn." for j in range(2)]
+        return out
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B: int, L: int) -> Dict[str, torch.Tensor]:
+        key = (B, L)
+        if key in self._ws:
+            return self._ws[key]
+        self._ws.clear()          # one resident geometry at a time
+        cfg, dev = self.cfg, self.device
+        N, D, Fd, E = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim
+        M, Mp = B * N, B * L
+        nb = len(self.seg_lengths)
+        e16 = lambda *s: torch.empty(*s, dtype=H16, device=dev)
+        e32 = lambda *s: torch.empty(*s, dtype=F32, device=dev)
+        w: Dict[str, torch.Tensor] = {}
+        w["x16"] = e16(L, cfg.in_chans)
+        w["x0"] = e32(L, D)
+        w["prow"] = torch.empty(L, dtype=torch.int32, device=dev)
+        w["pcol"] = torch.empty(L, dtype=torch.int32, device=dev)
+        nint = len(cfg.interaction_indexes)
+        for l in range(cfg.depth):
+            w[f"hin{l}"] = e32(M, D)
+            w[f"hmid{l}"] = e32(M, D)
+            w[f"qkv{l}"] = e16(M, 3 * D)
+            w[f"obr{l}"] = e16(nb, M, D)
+            w[f"lsebr{l}"] = e32(nb, M, 16)
+            w[f"lsetot{l}"] = e32(M, 16)
+            w[f"a1_{l}"] = e16(M, Fd)
+            for s in ("st1", "stin", "st2", "stf"):
+                w[f"{s}_{l}"] = e32(M, 2)
+        for i in range(nint):
+            w[f"hout{i}"] = e32(M, D)
+        # transients shared by all layers
+        w["u16"] = e16(M, D)
+        w["t16"] = e16(M, Fd)
+        w["dh"] = e32(M, D)
+        w["dy16"] = e16(M, D)
+        w["dt16"] = e16(M, Fd)
+        w["da1"] = e16(M, Fd)
+        w["dmixed"] = e16(M, D)
+        w["delta"] = e32(nb, M, 16)
+        w["dqkv32"] = e32(M, 3 * D)
+        w["dqkv16"] = e16(M, 3 * D)
+        w["scratch32"] = e32(Mp, D)
+        self._ws[key] = w
+        return w
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, coords, genes: Sequence[torch.Tensor], task_onehots: torch.Tensor,
+                need_grad: bool = True) -> torch.Tensor:
+        """x [L, in_chans] (or [1,L,in]); coords [L,2] (host or device); genes: list of [1, n_i]; task_onehots [B, num_tasks].
+        Returns logits [B, output_dim] (fp32, device)."""
+        cfg, dev, t = self.cfg, self.device, self.store.tensors
+        if not self._caches_ready:
+            self._build_caches()
+        x = x.reshape(-1, x.shape[-1])
+        L = x.shape[0]
+        B = task_onehots.shape[0]
+        N, D, Fd, E, T = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim, self.T
+        M, Mp = B * N, B * L
+        ws = self._workspace(B, L)
+        tape = self.tape
+        tape.reset()
+        tape.grad_enabled = need_grad
+        self._ctx = dict(B=B, L=L, N=N, M=M, Mp=Mp, ws=ws)
+        plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
+        self._ctx["plan"] = plan
+        P = self.store.param
+        patch_map = rowmap(L, N, 1)     # patch rows of a [B, N, D] buffer
+        self._ctx["patch_map"] = patch_map
+
+        # ---- patch embedding + positional table + cls (LVA:232-242); shared by the B passes
+        coords_np = coords.detach().cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords)
+        prow, pcol = coords_to_rowcol(coords_np.reshape(-1, 2), float(cfg.tile_size))
+        if int(prow.max()) >= cfg.slide_ngrids or int(pcol.max()) >= cfg.slide_ngrids or int(min(prow.min(), pcol.min())) < 0:
+            raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid")
+        ws["prow"].copy_(torch.from_numpy(prow.astype(np.int32)))
+        ws["pcol"].copy_(torch.from_numpy(pcol.astype(np.int32)))
+        if x.dtype == H16:
+            ws["x16"].copy_(x)
+        else:
+            ops.cast_f32_to_f16(x.to(dev, F32).contiguous(), ws["x16"])
+        ops.gemm_nt(ws["x16"], self._frozen16["patch"].w, ws["x0"], L, D, cfg.in_chans, epilogue=ops.EPI_POSEMB,
+                    bias=t["patch_embed.proj.bias"], pos_table=self.pos_table, pos_row=ws["prow"], pos_col=ws["pcol"])
+
+        # ---- token side: gene encoder (shared) + task token per pass (LVA:257-266)
+        gene = self._gene_encoder(genes)                                   # Var [1, G64, D]
+        c = self._assemble_tokens(gene, task_onehots)                      # Var [B, T, D]
+        pe = P("gene_pe")
+
+        # ---- interaction blocks (LVA:294-307, AM:484-523)
+        nint = len(cfg.interaction_indexes)
+        src, src_map = ws["x0"], rowmap(L, 0, 0)      # injector 0 reads the shared patch embedding (broadcast)
+        for i, (la, lb) in enumerate(cfg.interaction_indexes):
+            if i > 0 and cfg.use_prompt_sa:
+                c = self._prompt_self_attention(c, pe, f"prompt_selfattention.{i}.")
+            hin = ws[f"hin{la}"]
+            # cls row of every pass: cls_token (+ pos_embed[0] = 0) for block 0, else carried from the previous block
+            if i == 0:
+                ops.copy_rows(t["cls_token"].view(1, D), hin, B, D, smap=rowmap(1, 0, 0), dmap=rowmap(1, N, 0))
+            else:
+                ops.copy_rows(ws[f"hout{i - 1}"], hin, B, D, smap=rowmap(1, N, 0), dmap=rowmap(1, N, 0))
+            self._injector(i, c, pe, src, src_map, hin, first=(i == 0))
+            for l in range(la, lb + 1):
+                out = ws[f"hin{l + 1}"] if l < lb else ws[f"hout{i}"]
+                self._layer(l, out)
+            c = self._extractor(f"interactions.{i}.extractor.", c, pe, ws[f"hout{i}"])
+            if i == nint - 1 and cfg.use_extra_extractor:
+                for j in range(2):
+                    c = self._extractor(f"interactions.{i}.extra_extractors.{j}.", c, pe, ws[f"hout{i}"])
+            src, src_map = ws[f"hout{i}"], patch_map
+            if self.collect_taps:
+                self.taps[f"cls{i}"] = ws[f"hout{i}"].view(B, N, D)[:, 0].clone()
+                self.taps[f"c{i}"] = c.data.clone()
+                self.taps[f"x{i}_head"] = ws[f"hout{i}"].view(B, N, D)[:, 1:9].clone()
+        # ---- fusion head (LVA:309-347)
+        logits = self._head(c, ws[f"hout{nint - 1}"])
+        self._logits = logits
+        return logits.data
+
+    # ------------------------------------------------------------------ token-side pieces
+    def _gene_encoder(self, genes: Sequence[torch.Tensor]) -> Var:
+        """GeneEncoder_Group.gene_encode (gene_encoder.py:194-215), batch 1."""
+        tape, P, g = self.tape, self.store.param, self.cfg.gene
+        G = len(self.group_sizes)
+        if len(genes) != G:
+            raise ValueError(f"expected {G} gene groups, got {len(genes)}")
+        z = Var(tape.new(1, G, g.latent_dim))
+        rows = []
+        for i, gi in enumerate(genes):
+            gi = gi.to(self.device, F32).reshape(1, -1).contiguous()
+            p = f"gene_encoder.gene_networks.{i}."
+            h1 = tape.linear(Var(gi, needs_grad=False), P(p + "0.0.weight"), P(p + "0.0.bias"), act=ops.ACT_ELU)
+            rows.append(tape.linear(h1, P(p + "1.0.weight"), P(p + "1.0.bias"), act=ops.ACT_ELU))
+        for i, r in enumerate(rows):      # torch.cat(x_in).unsqueeze(0)
+            ops.copy_rows(r.data, z.data[0, i:i + 1], 1, g.latent_dim)
+
+        def bwd_stack():
+            if z.grad is None:
+                return
+            for i, r in enumerate(rows):
+                ops.copy_rows(z.grad[0, i:i + 1], r.g(), 1, g.latent_dim, accumulate=True)
+        tape.record(bwd_stack)
+        for k in range(g.depth):
+            p = f"gene_encoder.mlp_mixer.{k}."
+            n1 = tape.layernorm(z, P(p + "0.norm.weight"), P(p + "0.norm.bias"))
+            m1 = tape.axis_linear(n1, P(p + "0.fn.0.weight"), P(p + "0.fn.0.bias"), act=ops.ACT_GELU)
+            m2 = tape.axis_linear(m1, P(p + "0.fn.3.weight"), P(p + "0.fn.3.bias"))
+            z = tape.add(z, m2)
+            n2 = tape.layernorm(z, P(p + "1.norm.weight"), P(p + "1.norm.bias"))
+            f1 = tape.linear(n2, P(p + "1.fn.0.weight"), P(p + "1.fn.0.bias"), act=ops.ACT_GELU)
+            f2 = tape.linear(f1, P(p + "1.fn.3.weight"), P(p + "1.fn.3.bias"))
+            z = tape.add(z, f2)
+        p = "gene_encoder.mlp_mixer."
+        z = tape.layernorm(z, P(p + f"{g.depth}.weight"), P(p + f"{g.depth}.bias"))
+        z = tape.linear(z, P(p + f"{g.depth + 1}.weight"), P(p + f"{g.depth + 1}.bias"))          # [1, G, D]
+        return tape.axis_linear(z, P("gene_encoder.pathway_compression.weight"), P("gene_encoder.pathway_compression.bias"))
+
+    def _assemble_tokens(self, gene: Var, onehots: torch.Tensor) -> Var:
+        """c[b] = cat(task_weight(onehot_b), gene_embedding) (LVA:263-266)."""
+        tape, P, D, T = self.tape, self.store.param, self.cfg.embed_dim, self.T
+        B = onehots.shape[0]
+        G64 = gene.data.shape[1]
+        c = Var(tape.new(B, T, D))
+        nt = int(self.cfg.is_multi)
+        task = None
+        if nt:
+            oh = Var(onehots.to(self.device, F32).contiguous(), needs_grad=False)
+            task = tape.layernorm(tape.linear(oh, P("task_weight.0.weight"), P("task_weight.0.bias")),
+                                  P("task_weight.1.weight"), P("task_weight.1.bias"))                  # [B, D]
+            ops.copy_rows(task.data, c.data, B, D, dmap=rowmap(1, T, 0))
+        ops.copy_rows(gene.data.view(G64, D), c.data, B * G64, D, smap=rowmap(G64, 0, 0), dmap=rowmap(G64, T, nt))
+
+        def bwd():
+            if c.grad is None:
+                return
+            if task is not None:
+                ops.copy_rows(c.grad, task.g(), B, D, smap=rowmap(1, T, 0), accumulate=True)
+            gg = gene.g().view(G64, D)
+            for b in range(B):      # d gene_embedding = sum over the passes
+                ops.copy_rows(c.grad, gg, G64, D, smap=rowmap(G64, T, b * T + nt), accumulate=True)
+        tape.record(bwd)
+        return c
+
+    def _mha_in(self, pref: str):
+        """Views of nn.MultiheadAttention's packed parameters (adapter_modules.py:157-164)."""
+        P, E = self.store.param, self.cfg.adapter_dim
+        b = self.store.tensors[pref + "in_proj_bias"]
+        gb = self.store.grads[pref + "in_proj_bias"]
+        bq, bk, bv = (Param(b[i * E:(i + 1) * E], gb[i * E:(i + 1) * E]) for i in range(3))
+        return P(pref + "q_proj_weight"), P(pref + "k_proj_weight"), P(pref + "v_proj_weight"), bq, bk, bv
+
+    def _prompt_self_attention(self, c: Var, pe: Param, pref: str) -> Var:
+        """SelfAttentionLayer.forward_pre (AM:81-94)."""
+        tape, P = self.tape, self.store.param
+        tn = tape.layernorm(c, P(pref + "norm.weight"), P(pref + "norm.bias"))
+        kin = tape.add_rows_param(tn, pe)
+        q1 = tape.linear(kin, P(pref + "q_proj.weight"), P(pref + "q_proj.bias"))
+        Wq, Wk, Wv, bq, bk, bv = self._mha_in(pref + "self_attn.")
+        q = tape.linear(q1, Wq, bq)
+        k = tape.linear(kin, Wk, bk)
+        v = tape.linear(tn, Wv, bv)
+        a = tape.token_mha(q, k, v, self.cfg.num_heads)
+        o = tape.linear(a, P(pref + "self_attn.out_proj.weight"), P(pref + "self_attn.out_proj.bias"))
+        o = tape.linear(o, P(pref + "output_proj.weight"), P(pref + "output_proj.bias"))
+        return tape.add(c, o)
+
+    # ------------------------------------------------------------------ injector (A.1)
+    def _injector(self, i: int, c: Var, pe: Param, src: torch.Tensor, src_map, hin: torch.Tensor, first: bool):
+        cfg, ctx, tape, P, t = self.cfg, self._ctx, self.tape, self.store.param, self.store.tensors
+        B, L, N, Mp, D, E, T = ctx["B"], ctx["L"], ctx["N"], ctx["Mp"], cfg.embed_dim, cfg.adapter_dim, self.T
+        pref = f"interactions.{i}.injector."
+        ap = pref + "attn."
+        pm = ctx["patch_map"]
+        w16 = self._train16
+        dev = self.device
+        # token side: k, v from LN_kq(c) + pe (AM:218,227)
+        chat = tape.layernorm(c, P(ap + "norm_kq.weight"), P(ap + "norm_kq.bias"), add_rows=pe)
+        _, Wk, Wv, _, bk, bv = self._mha_in(ap + "multihead_attn.")
+        k = tape.linear(chat, Wk, bk)
+        v = tape.linear(chat, Wv, bv)
+        # patch side
+        xhat = torch.empty(Mp, D, dtype=H16, device=dev)
+        st = torch.empty(Mp, 2, dtype=F32, device=dev)
+        ops.layernorm_fwd(src, t[ap + "norm.weight"], t[ap + "norm.bias"], xhat, st, Mp, D, xmap=src_map)
+        q1 = torch.empty(Mp, E, dtype=H16, device=dev)
+        ops.gemm_nt(xhat, w16[ap + "q_proj"].w, q1, Mp, E, D, bias=t[ap + "q_proj.bias"])
+        q2 = torch.empty(Mp, E, dtype=H16, device=dev)
+        bqi = t[ap + "multihead_attn.in_proj_bias"][:E]
+        ops.gemm_nt(q1, w16[ap + "q_in"].w, q2, Mp, E, E, bias=bqi)
+        a = torch.empty(Mp, E, dtype=H16, device=dev)
+        ops.inject_attn_fwd(q2, k.data, v.data, a, Mp, L, T)
+        o1 = torch.empty(Mp, E, dtype=H16, device=dev)
+        ops.gemm_nt(a, w16[ap + "out_in"].w, o1, Mp, E, E, bias=t[ap + "multihead_attn.out_proj.bias"])
+        ops.gemm_nt(o1, w16[ap + "output_proj"].w, hin, Mp, D, E, cmap=pm, epilogue=ops.EPI_INJECT, bias=t[ap + "output_proj.bias"],
+                    resid=src, ldr=D, rmap=src_map, colscale=t[pref + "gamma"])
+        g = self.store.grads
+        ws = ctx["ws"]
+
+        def bwd():
+            dh = ws["dh"]
+            proj = torch.empty(Mp, D, dtype=H16, device=dev)
+            ops.gemm_nt(o1, w16[ap + "output_proj"].w, proj, Mp, D, E, bias=t[ap + "output_proj.bias"])
+            dproj = torch.empty(Mp, D, dtype=H16, device=dev)
+            # residual path: dh_patch <- (1+gamma) dh_patch (in place; block 0's input x0 needs no gradient)
+            ops.inject_resid_bwd(dh, src, proj, t[pref + "gamma"], dh if not first else ws["scratch32"], dproj,
+                                 g[pref + "gamma"], Mp, D, dymap=pm, xmap=src_map, dxmap=pm if not first else None)
+            ops.gemm_tn(dproj, o1, g[ap + "output_proj.weight"], Mp, D, E)
+            ops.colsum(dproj, g[ap + "output_proj.bias"], Mp, D)
+            do1 = torch.empty(Mp, E, dtype=H16, device=dev)
+            ops.gemm_nt(dproj, w16[ap + "output_proj"].wt, do1, Mp, E, D)
+            ops.gemm_tn(do1, a, g[ap + "multihead_attn.out_proj.weight"], Mp, E, E)
+            ops.colsum(do1, g[ap + "multihead_attn.out_proj.bias"], Mp, E)
+            da = torch.empty(Mp, E, dtype=H16, device=dev)
+            ops.gemm_nt(do1, w16[ap + "out_in"].wt, da, Mp, E, E)
+            dq2 = torch.empty(Mp, E, dtype=H16, device=dev)
+            ops.inject_attn_bwd(q2, da, k.data, v.data, dq2, k.g(), v.g(), Mp, L, T)
+            ops.gemm_tn(dq2, q1, g[ap + "multihead_attn.q_proj_weight"], Mp, E, E)
+            ops.colsum(dq2, g[ap + "multihead_attn.in_proj_bias"][:E], Mp, E)
+            dq1 = torch.empty(Mp, E, dtype=H16, device=dev)
+            ops.gemm_nt(dq2, w16[ap + "q_in"].wt, dq1, Mp, E, E)
+            ops.gemm_tn(dq1, xhat, g[ap + "q_proj.weight"], Mp, E, D)
+            ops.colsum(dq1, g[ap + "q_proj.bias"], Mp, E)
+            dxhat = torch.empty(Mp, D, dtype=H16, device=dev)
+            ops.gemm_nt(dq1, w16[ap + "q_proj"].wt, dxhat, Mp, D, E)
+            if first:
+                ops.layernorm_bwd(dxhat, src, t[ap + "norm.weight"], st, ws["scratch32"], Mp, D, xmap=src_map,
+                                  dw=g[ap + "norm.weight"], db=g[ap + "norm.bias"])
+            else:
+                ops.layernorm_bwd(dxhat, src, t[ap + "norm.weight"], st, dh, Mp, D, xmap=src_map, dxmap=pm, accumulate=True,
+                                  dw=g[ap + "norm.weight"], db=g[ap + "norm.bias"])
+        tape.record(bwd)
+
+    # ------------------------------------------------------------------ one frozen LongNet layer (A.4)
+    def _layer(self, l: int, out: torch.Tensor):
+        cfg, ctx, t = self.cfg, self._ctx, self.store.tensors
+        M, D, Fd, ws, plan = ctx["M"], cfg.embed_dim, cfg.ffn_dim, ctx["ws"], ctx["plan"]
+        p = f"encoder.layers.{l}."
+        f16 = self._frozen16
+        hin, hmid, qkv, obr, lsebr, lsetot, a1 = (ws[f"hin{l}"], ws[f"hmid{l}"], ws[f"qkv{l}"], ws[f"obr{l}"], ws[f"lsebr{l}"],
+                                                  ws[f"lsetot{l}"], ws[f"a1_{l}"])
+        st1, stin, st2, stf = ws[f"st1_{l}"], ws[f"stin_{l}"], ws[f"st2_{l}"], ws[f"stf_{l}"]
+        u16, t16 = ws["u16"], ws["t16"]
+        ops.layernorm_fwd(hin, t[p + "self_attn_layer_norm.weight"], t[p + "self_attn_layer_norm.bias"], u16, st1, M, D)
+        ops.gemm_nt(u16, f16[p + "qkv"].w, qkv, M, 3 * D, D, bias=f16[p + "bqkv"])
+        ops.dilated_attn_fwd(qkv, plan, obr, lsebr)
+        ops.dilated_mix_ln_fwd(obr, lsebr, plan, t[p + "self_attn.inner_attn_ln.weight"], t[p + "self_attn.inner_attn_ln.bias"],
+                               u16, stin, lsetot)
+        ops.gemm_nt(u16, f16[p + "out"].w, hmid, M, D, D, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "self_attn.out_proj.bias"],
+                    resid=hin, ldr=D)
+        ops.layernorm_fwd(hmid, t[p + "final_layer_norm.weight"], t[p + "final_layer_norm.bias"], u16, st2, M, D)
+        ops.gemm_nt(u16, f16[p + "fc1"].w, a1, M, Fd, D, bias=t[p + "ffn.fc1.bias"])
+        ops.layernorm_fwd(a1, t[p + "ffn.ffn_layernorm.weight"], t[p + "ffn.ffn_layernorm.bias"], t16, stf, M, Fd, gelu_in=True)
+        ops.gemm_nt(t16, f16[p + "fc2"].w, out, M, D, Fd, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "ffn.fc2.bias"], resid=hmid, ldr=D)
+
+        def bwd():
+            dh, dy16, dt16, da1 = ws["dh"], ws["dy16"], ws["dt16"], ws["da1"]
+            # FFN: out = hmid + fc2(LN(gelu(fc1(LN(hmid)))))
+            ops.cast_f32_to_f16(dh, dy16)
+            ops.gemm_nt(dy16, f16[p + "fc2"].wt, dt16, M, Fd, D)
+            ops.layernorm_bwd(dt16, a1, t[p + "ffn.ffn_layernorm.weight"], stf, da1, M, Fd, gelu_in=True)
+            ops.gemm_nt(da1, f16[p + "fc1"].wt, dy16, M, D, Fd)
+            ops.layernorm_bwd(dy16, hmid, t[p + "final_layer_norm.weight"], st2, dh, M, D, accumulate=True)
+            # attention: hmid = hin + out_proj(LN(mix(dilated(qkv(LN(hin))))))
+            ops.cast_f32_to_f16(dh, dy16)
+            ops.gemm_nt(dy16, f16[p + "out"].wt, u16, M, D, D)
+            ops.dilated_mix_ln_bwd(u16, obr, lsebr, lsetot, plan, t[p + "self_attn.inner_attn_ln.weight"], stin, ws["dmixed"], ws["delta"])
+            ops.dilated_attn_bwd(qkv, ws["dmixed"], lsetot, ws["delta"], plan, ws["dqkv32"])
+            ops.cast_f32_to_f16(ws["dqkv32"], ws["dqkv16"])
+            ops.gemm_nt(ws["dqkv16"], f16[p + "qkv"].wt, dy16, M, D, 3 * D)
+            ops.layernorm_bwd(dy16, hin, t[p + "self_attn_layer_norm.weight"], st1, dh, M, D, accumulate=True)
+        self.tape.record(bwd)
+
+    # ------------------------------------------------------------------ extractor (A.2)
+    def _extractor(self, pref: str, c: Var, pe: Param, hout: torch.Tensor) -> Var:
+        cfg, ctx, tape, P, t, g = self.cfg, self._ctx, self.tape, self.store.param, self.store.tensors, self.store.grads
+        B, L, N, Mp, D, E, T = ctx["B"], ctx["L"], ctx["N"], ctx["Mp"], cfg.embed_dim, cfg.adapter_dim, self.T
+        ap = pref + "attn."
+        pm, dev, w16, ws = ctx["patch_map"], self.device, self._train16, ctx["ws"]
+        # patch side: k | v of LN_kq(x)
+        xk = torch.empty(Mp, D, dtype=H16, device=dev)
+        st = torch.empty(Mp, 2, dtype=F32, device=dev)
+        ops.layernorm_fwd(hout, t[ap + "norm_kq.weight"], t[ap + "norm_kq.bias"], xk, st, Mp, D, xmap=pm)
+        kv = torch.empty(Mp, 2 * E, dtype=H16, device=dev)
+        bkv = t[ap + "multihead_attn.in_proj_bias"][E:]
+        ops.gemm_nt(xk, w16[ap + "kv"].w, kv, Mp, 2 * E, D, bias=bkv)
+        # token side: q = in_proj_q(q_proj(LN(c) + pe))
+        t2 = tape.layernorm(c, P(ap + "norm.weight"), P(ap + "norm.bias"), add_rows=pe)
+        q1 = tape.linear(t2, P(ap + "q_proj.weight"), P(ap + "q_proj.bias"))
+        Wq, _, _, bq, _, _ = self._mha_in(ap + "multihead_attn.")
+        q2 = tape.linear(q1, Wq, bq)
+        out = Var(tape.new(B, T, E))
+        lse = tape.new(B, T, 12)
+        nsplit = max(1, min(64, L // 256))
+        pa = tape.new(B * 12 * nsplit * T * 16)
+        pml = tape.new(B * 12 * nsplit * T * 2)
+        ops.extract_attn_fwd(q2.data, kv, out.data, lse, pa, pml, B, T, L, nsplit)
+
+        def bwd_core():
+            if out.grad is None:
+                return
+            dkv = torch.empty(Mp, 2 * E, dtype=H16, device=dev)
+            ops.extract_attn_bwd(q2.data, kv, out.data, lse, out.grad, q2.g(), dkv, B, T, L)
+            ops.gemm_tn(dkv, xk, g[ap + "multihead_attn.k_proj_weight"], Mp, 2 * E, D)       # k | v weights are adjacent
+            ops.colsum(dkv, g[ap + "multihead_attn.in_proj_bias"][E:], Mp, 2 * E)
+            dxk = torch.empty(Mp, D, dtype=H16, device=dev)
+            ops.gemm_nt(dkv, w16[ap + "kv"].wt, dxk, Mp, D, 2 * E)
+            ops.layernorm_bwd(dxk, hout, t[ap + "norm_kq.weight"], st, ws["dh"], Mp, D, xmap=pm, dxmap=pm, accumulate=True,
+                              dw=g[ap + "norm_kq.weight"], db=g[ap + "norm_kq.bias"])
+        tape.record(bwd_core)
+        o = tape.linear(out, P(ap + "multihead_attn.out_proj.weight"), P(ap + "multihead_attn.out_proj.bias"))
+        attn_out = tape.linear(o, P(ap + "output_proj.weight"), P(ap + "output_proj.bias"))
+        c1 = tape.add(c, tape.add(c, attn_out))         # query + (tgt + output_proj(.)) (AM:231,324)
+        fp = pref + "ffn."
+        tn = tape.layernorm(c1, P(fp + "norm.weight"), P(fp + "norm.bias"))
+        f = tape.linear(tape.linear(tn, P(fp + "linear1.weight"), P(fp + "linear1.bias"), act=ops.ACT_RELU),
+                        P(fp + "linear2.weight"), P(fp + "linear2.bias"))
+        return tape.add(c1, f)
+
+    # ------------------------------------------------------------------ fusion head (LVA:309-347)
+    def _head(self, c: Var, hout: torch.Tensor) -> Var:
+        cfg, ctx, tape, P = self.cfg, self._ctx, self.tape, self.store.param
+        B, N, D, T, ws = ctx["B"], ctx["N"], cfg.embed_dim, self.T, ctx["ws"]
+        nt = int(cfg.is_multi)
+        G64 = T - nt
+        cls = Var(tape.new(B, D))
+        ops.copy_rows(hout, cls.data, B, D, smap=rowmap(1, N, 0))
+        gene = Var(tape.new(B, D))
+        # mean over the gene tokens: gene[b, d] = sum_t (1/G64) c[b, nt + t, d]
+        ops.sgemm(self._mean_w, (0, 1), c.data[:, nt:], (1, D), gene.data, (D, 1), 1, D, G64, batch=B, b_bs=T * D, c_bs=D)
+        task = None
+        if nt:
+            task = Var(tape.new(B, D))
+            ops.copy_rows(c.data, task.data, B, D, smap=rowmap(1, T, 0))
+
+        def bwd_gather():
+            dh = ws["dh"]
+            dh.zero_()                       # start of the patch-side backward: only the cls rows carry gradient
+            if cls.grad is not None:
+                ops.copy_rows(cls.grad, dh, B, D, dmap=rowmap(1, N, 0))
+            cg = c.g()
+            if gene.grad is not None:   # dc[b, nt + t, :] += dgene[b, :] / G64
+                ops.sgemm(self._mean_w, (1, 0), gene.grad, (1, 0), cg[:, nt:], (D, 1), G64, D, 1, accumulate=True, batch=B,
+                          b_bs=D, c_bs=T * D)
+            if task is not None and task.grad is not None:
+                ops.copy_rows(task.grad, cg, B, D, dmap=rowmap(1, T, 0), accumulate=True)
+        tape.record(bwd_gather)
+        if cfg.token_agg == "sum":
+            outc = tape.add(cls, gene)
+            if task is not None:
+                outc = tape.add(outc, task)
+        else:
+            parts = [cls, task, gene] if task is not None else [cls, gene]
+            outc = Var(tape.new(B, D * len(parts)))
+            for j, pv in enumerate(parts):
+                ops.copy_rows(pv.data, outc.data[:, j * D:], B, D, ldd=D * len(parts))
+
+            def bwd_cat():
+                if outc.grad is None:
+                    return
+                for j, pv in enumerate(parts):
+                    ops.copy_rows(outc.grad[:, j * D:], pv.g(), B, D, lds=D * len(parts), accumulate=True)
+            tape.record(bwd_cat)
+        n = tape.layernorm(outc, P("final_norm.weight"), P("final_norm.bias"))
+        return tape.linear(n, P("final_project.weight"), P("final_project.bias"))
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dlogits: torch.Tensor):
+        """Accumulates into ParamStore.flat_grad; dlogits [B, output_dim] fp32 (already loss-scaled if desired)."""
+        self._logits.grad = dlogits.to(self.device, F32).contiguous()
+        self.tape.run_backward()

@@ -156,6 +156,10 @@ def cast_f16_to_f32(x, y, n=None):
     check(_lib.load().mt_cast_f16_to_f32(_p(x), _p(y), n if n is not None else x.numel(), _s()), "cast")
 
 
+def pack_weight(src, dst, R, C, transpose=False):
+    check(_lib.load().mt_pack_weight_f16(_p(src), R, C, _p(dst), int(transpose), _s()), "pack_weight")
+
+
 def act_fwd(x, y, act, n=None):
     check(_lib.load().mt_act_fwd(_p(x), _p(y), n if n is not None else x.numel(), act, _s()), "act_fwd")
 
@@ -181,14 +185,24 @@ def inject_resid_bwd(dy, x, proj, gamma, dx, dproj, dgamma, M, D, *, lddy=None, 
                                           _p(dgamma), M, D, _s()), "inject_resid_bwd")
 
 
-def distill_loss(logits, target, loss, dlogits, R, O, loss_scale=1.0):
-    check(_lib.load().mt_distill_loss(_p(logits), _p(target), R, O, float(loss_scale), _p(loss), _p(dlogits), _s()),
-          "distill_loss")
+def l2norm_row(x, y, O):
+    check(_lib.load().mt_l2norm_rows(_p(x), _p(y), 1, O, _s()), "l2norm_rows")
 
 
-def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_count, scale=None, found_inf=None):
+def distill_loss(logits, target, loss, dlogits, R, O, loss_scale=1.0, scale_dev=None):
+    check(_lib.load().mt_distill_loss(_p(logits), _p(target), R, O, float(loss_scale), _p(scale_dev), _p(loss),
+                                      _p(dlogits), _s()), "distill_loss")
+
+
+def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_count, scale=None, found_inf=None, grad_mult=1.0,
+               step_dev=None):
     check(_lib.load().mt_adamw_step(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, step_count,
-                                    _p(scale), _p(found_inf), _s()), "adamw_step")
+                                    _p(step_dev), float(grad_mult), _p(scale), _p(found_inf), _s()), "adamw_step")
+
+
+def scaler_update(scale, tracker, found_inf, step_dev=None, growth=2.0, backoff=0.5, interval=2000):
+    check(_lib.load().mt_scaler_update(_p(scale), _p(tracker), _p(found_inf), _p(step_dev), growth, backoff, interval,
+                                       _s()), "scaler_update")
 
 
 def check_finite(g, n, found_inf):

@@ -1,0 +1,91 @@
+"""GPU parity of the full HIP train step (3 task passes, loss, backward) against golden vectors produced by the
+reference (tests/golden/model_*.npz) and against the CPU oracle.  Tolerance: 1e-3 relative on logits / loss
+(BASELINE.json north_star); gradients are checked at 2e-2 (fp16 operands, scaled fp16 gradient stream)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from modaltune_amd import synth  # noqa: E402
+from modaltune_amd.config import ModelConfig  # noqa: E402
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def _build(path):
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    g = np.load(path)
+    L, depth, seed, ngrids = int(g["L"]), int(g["depth"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    cfg = ModelConfig(depth=depth, interaction_indexes=tuple(tuple(int(i) for i in p) for p in g["inter"]), slide_ngrids=ngrids)
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed))
+    ts = TrainStep(eng)
+    ts.set_projector(synth.projector_state(seed))
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    return g, cfg, eng, ts, inp
+
+
+@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12"])
+def test_train_step_matches_reference_golden(golden_dir, name):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(golden_dir, f"model_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g, cfg, eng, ts, inp = _build(path)
+    eng.collect_taps = True
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    loss = ts.step(x, inp["coords"], genes, torch.from_numpy(inp["text"]), update=False)
+    torch.cuda.synchronize()
+    logits = ts.last_logits.cpu().numpy()
+    report = {}
+    for i in range(len(cfg.interaction_indexes)):
+        for t in range(3):
+            report[f"cls{i}/t{t}"] = _rel(eng.taps[f"cls{i}"][t].cpu().numpy(), g[f"f64_tap/task{t}/cls{i}"].reshape(-1))
+            report[f"c{i}/t{t}"] = _rel(eng.taps[f"c{i}"][t].cpu().numpy(), g[f"f64_tap/task{t}/c{i}"][0])
+    report["logits"] = _rel(logits, g["f64_logits"])
+    report["loss"] = abs(float(loss) - float(g["f64_loss"])) / abs(float(g["f64_loss"]))
+    print(name, {k: f"{v:.2e}" for k, v in report.items()})
+    assert report["logits"] < 1e-3, report
+    assert report["loss"] < 1e-3, report
+    assert int(ts.found_inf) == 0
+    grads = ts.unscaled_grads()
+    names = [str(n) for n in g["f64_grad_names"]]
+    ours = np.array([float(grads[n].double().norm()) for n in names])
+    ref = g["f64_grad_norms"]
+    bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > 2e-2 * r + 1e-6 * ref.max()]
+    assert not bad, bad[:10]
+    for k in g.files:
+        if k.startswith("f64_grad/"):
+            assert _rel(grads[k[len("f64_grad/"):]].cpu().numpy(), g[k]) < 2e-2, k
+
+
+def test_optimizer_step_matches_oracle_adamw(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import modaltune_oracle as O
+    g, cfg, eng, ts, inp = _build(os.path.join(golden_dir, "model_L37_d3.npz"))
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    before = {k: v.clone() for k, v in eng.store.tensors.items() if k in eng.store.grads}
+    ts.step(x, inp["coords"], genes, torch.from_numpy(inp["text"]), update=True)
+    torch.cuda.synchronize()
+    assert int(ts.step_dev) == 1
+    for k in ("interactions.0.injector.gamma", "final_project.bias", "gene_pe"):
+        gk = (eng.store.grads[k] / 2.0 ** 15).double().cpu()
+        want, _, _ = O.adamw_update(before[k].double().cpu(), gk, torch.zeros_like(gk), torch.zeros_like(gk), 1, ts.lr)
+        got = eng.store.tensors[k].double().cpu()
+        assert float((got - want).abs().max()) < 1e-6 * float(want.abs().max()) + 1e-9, k
+    # second step runs on the refreshed fp16 weight caches and stays finite
+    loss2 = ts.step(x, inp["coords"], genes, torch.from_numpy(inp["text"]), update=True)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss2)) and int(ts.step_dev) == 2
