@@ -302,11 +302,13 @@ class Engine:
         for i, r in enumerate(rows):      # torch.cat(x_in).unsqueeze(0)
             ops.copy_rows(r.data, z.data[0, i:i + 1], 1, g.latent_dim)
 
+        z0 = z          # (closures bind late: `z` is rebound by the mixer loop below)
+
         def bwd_stack():
-            if z.grad is None:
+            if z0.grad is None:
                 return
             for i, r in enumerate(rows):
-                ops.copy_rows(z.grad[0, i:i + 1], r.g(), 1, g.latent_dim, accumulate=True)
+                ops.copy_rows(z0.grad[0, i:i + 1], r.g(), 1, g.latent_dim, accumulate=True)
         tape.record(bwd_stack)
         for k in range(g.depth):
             p = f"gene_encoder.mlp_mixer.{k}."
