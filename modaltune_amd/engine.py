@@ -500,7 +500,8 @@ class Engine:
         q2 = tape.linear(q1, Wq, bq)
         out = Var(tape.new(B, T, E))
         lse = tape.new(B, T, 12)
-        nsplit = max(1, min(64, L // 256))
+        kps = -(-(-(-L // max(1, min(64, L // 256))) ) // 64) * 64      # keys per split: multiple of the 64-key tile
+        nsplit = -(-L // kps)                                           # every split owns >= 1 key
         pa = tape.new(B * 12 * nsplit * T * 16)
         pml = tape.new(B * 12 * nsplit * T * 2)
         ops.extract_attn_fwd(q2.data, kv, out.data, lse, pa, pml, B, T, L, nsplit)

@@ -207,3 +207,52 @@ def scaler_update(scale, tracker, found_inf, step_dev=None, growth=2.0, backoff=
 
 def check_finite(g, n, found_inf):
     check(_lib.load().mt_check_finite(_p(g), n, _p(found_inf), _s()), "check_finite")
+
+
+# ------------------------------------------------------------------------------------------------
+# Optional per-kernel timing with HIP events on the launch stream (bench.py --> roofline.achieved).
+# TIMER maps "<op>[shape]" -> list of (start_event, end_event); None = disabled (zero overhead path).
+# ------------------------------------------------------------------------------------------------
+TIMER = None
+
+
+def _timed(name_fn):
+    def deco(fn):
+        def wrapper(*a, **k):
+            if TIMER is None:
+                return fn(*a, **k)
+            key = name_fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            TIMER.setdefault(key, []).append((e0, e1))
+            return r
+        wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+        return wrapper
+    return deco
+
+
+gemm_nt = _timed(lambda A, W, out, M, N, K, **k: f"gemm_nt[{N}x{K}]")(gemm_nt)
+gemm_tn = _timed(lambda A, B, out, M, N1, N2, **k: f"gemm_tn[{N1}x{N2}]")(gemm_tn)
+dilated_attn_fwd = _timed(lambda *a, **k: "dilated_attn_fwd")(dilated_attn_fwd)
+dilated_attn_bwd = _timed(lambda *a, **k: "dilated_attn_bwd")(dilated_attn_bwd)
+dilated_mix_ln_fwd = _timed(lambda *a, **k: "dilated_mix_ln_fwd")(dilated_mix_ln_fwd)
+dilated_mix_ln_bwd = _timed(lambda *a, **k: "dilated_mix_ln_bwd")(dilated_mix_ln_bwd)
+layernorm_fwd = _timed(lambda x, w, b, y, stats, M, D, **k: f"layernorm_fwd[{D}]" if M > 1024 else "token_side")(layernorm_fwd)
+layernorm_bwd = _timed(lambda dy, x, w, stats, dx, M, D, **k: f"layernorm_bwd[{D}]" if M > 1024 else "token_side")(layernorm_bwd)
+cast_f32_to_f16 = _timed(lambda *a, **k: "cast")(cast_f32_to_f16)
+inject_attn_fwd = _timed(lambda *a, **k: "inject_attn_fwd")(inject_attn_fwd)
+inject_attn_bwd = _timed(lambda *a, **k: "inject_attn_bwd")(inject_attn_bwd)
+extract_attn_fwd = _timed(lambda *a, **k: "extract_attn_fwd")(extract_attn_fwd)
+extract_attn_bwd = _timed(lambda *a, **k: "extract_attn_bwd")(extract_attn_bwd)
+inject_resid_bwd = _timed(lambda *a, **k: "inject_resid_bwd")(inject_resid_bwd)
+colsum = _timed(lambda *a, **k: "colsum")(colsum)
+sgemm = _timed(lambda *a, **k: "token_side")(sgemm)
+adamw_step = _timed(lambda *a, **k: "adamw")(adamw_step)
+
+
+def timer_summary(timer):
+    """{key: (launches, total_ms)} after a device sync."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in timer.items()}
