@@ -1,0 +1,144 @@
+"""Drop-in nn.Module surface of the reference for the hot path.
+
+Same registry names, constructor kwargs, forward signature, `is_multi` attribute and state_dict keys as
+models/aggregators/aggregators.py:6-58 and models/aggregators/longvit_adapter.py:30-347 — backed by the HIP
+engine instead of PyTorch modules, so train_modaltune.py:123-126,172-177 can use it unchanged:
+
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, **json_cfg, multi_task=3)
+    logits = model(x=images, coords=coords, genes=gene_data, clinical=[], task_token=torch.eye(3)[t].cuda())
+
+The module-level forward is the compatibility path (one pass per call, any number of forwards before a backward);
+`forward_tasks` batches the task passes like the fused TrainStep does.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Any, Dict, Iterator, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import ModelConfig
+from .engine import Engine, F32
+
+
+class Aggregator(nn.Module):
+    """Registry base (models/aggregators/aggregators.py:6-41)."""
+    subclasses: Dict[str, Any] = {}
+
+    @classmethod
+    def register(cls, subclass_name: str):
+        def decorator(subclass):
+            cls.subclasses[subclass_name] = subclass
+            return subclass
+        return decorator
+
+    @classmethod
+    def create(cls, subclass_name: str, **params):
+        if subclass_name not in cls.subclasses:
+            raise ValueError("Unknown subclass name {}".format(subclass_name))
+        return cls.subclasses[subclass_name](**params)
+
+
+class _ModelFn(torch.autograd.Function):
+    """autograd bridge: forward runs the HIP engine (own tape + workspace per call); backward replays that call's
+    tape.  Parameter gradients are accumulated by the kernels into the flat gradient buffer and surfaced as
+    `param.grad` views, so torch optimisers / GradScaler / DDP-style hooks see ordinary gradients."""
+
+    @staticmethod
+    def forward(ctx, dummy, module, x, coords, genes, onehots, need):
+        eng = module.engine
+        logits = eng.forward(x, coords, genes, onehots, need_grad=need, fresh=need)
+        ctx.module, ctx.call = module, (eng.last_call if need else None)
+        return logits.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module, eng = ctx.module, ctx.module.engine
+        if ctx.call is None:
+            raise RuntimeError("backward through a forward that ran with gradients disabled")
+        params = module._trainable
+        fresh = any(p.grad is None for p in params.values())
+        store = eng.store
+        # fp16 activation-gradient stream: run the tape on rescaled dlogits (max |.| -> 2^10), then unscale
+        amax = float(dlogits.abs().max())
+        if not (amax > 0.0) or amax != amax or amax == float("inf"):
+            s = 1.0
+        else:
+            s = 1024.0 / amax
+        acc = None if fresh else store.flat_grad.clone()
+        store.flat_grad.zero_()
+        eng.backward(dlogits.to(F32) * s, call=ctx.call)
+        if acc is None:
+            ops.axpy(torch.zeros_like(store.flat_grad), store.flat_grad, 1.0 / s, store.flat_grad)
+        else:
+            ops.axpy(acc, store.flat_grad, 1.0 / s, store.flat_grad)
+        for k, p in params.items():
+            if p.grad is None:
+                p.grad = store.grads[k]
+        return torch.zeros(1, device=dlogits.device), None, None, None, None, None, None
+
+
+@Aggregator.register("longnetvit_gene_adapter")
+class LongNetGeneAdapter(Aggregator):
+    """LongNet-ViT + Modal Adapter (reference LongNetGeneAdapter, longvit_adapter.py:30-347) on the HIP engine."""
+
+    def __init__(self, gene_group_defination: Dict[Any, Sequence[str]] = None, multi_task: int = 1, device="cuda", **kwargs):
+        super().__init__()
+        gene_group_defination = gene_group_defination or {}
+        cfg = ModelConfig.from_json(kwargs, multi_task=multi_task)
+        self.cfg = cfg
+        self.is_multi = multi_task > 1                       # longvit_adapter.py:88 (read at TM:174)
+        self.engine = Engine(cfg, [len(v) for v in gene_group_defination.values()], device)
+        self._params: "OrderedDict[str, nn.Parameter]" = OrderedDict()
+        for k, shape, kind, train in self.engine.store.specs:
+            self._params[k] = nn.Parameter(self.engine.store.tensors[k], requires_grad=bool(train))
+        self._trainable = OrderedDict((k, p) for k, p in self._params.items() if p.requires_grad)
+        self._dummy = torch.zeros(1, device=self.engine.device, requires_grad=True)
+        self._versions = None
+        self.training_grad = True
+
+    # ---- parameter / state_dict surface under the reference's key names
+    def named_parameters(self, prefix: str = "", recurse: bool = True, remove_duplicate: bool = True) -> Iterator[Tuple[str, nn.Parameter]]:
+        for k, p in self._params.items():
+            yield (prefix + ("." if prefix else "") + k, p)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = destination if destination is not None else OrderedDict()
+        for k, p in self._params.items():
+            out[prefix + k] = p if keep_vars else p.detach()
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        self.engine.load_state_dict(state_dict, strict=strict)
+        self._versions = None
+        return torch.nn.modules.module._IncompatibleKeys([], [])
+
+    def _apply(self, fn, recurse=True):     # .to()/.cuda()/.float(): tensors already live on the GPU in their final dtypes
+        return self
+
+    def _sync_weight_caches(self):
+        v = tuple(p._version for p in self._trainable.values())
+        if v != self._versions:
+            self.engine.refresh_trainable_caches()
+            self._versions = v
+
+    # ---- forward (longvit_adapter.py:205-215 signature)
+    def forward(self, x, coords, genes, task_token=None, attn_mask=None, multiway_split_position=None,
+                incremental_state=None, **kwargs):
+        if self.is_multi:
+            if task_token is None:
+                raise ValueError("task_token is required when multi_task > 1")
+            onehots = task_token.reshape(1, -1)
+        else:
+            onehots = torch.zeros(1, 1, device=self.engine.device)
+        return self.forward_tasks(x, coords, genes, onehots)
+
+    def forward_tasks(self, x, coords, genes, task_onehots):
+        """All task passes of one slide in one batched engine call: logits [B, output_dim]."""
+        self._sync_weight_caches()
+        if isinstance(genes, dict):
+            genes = [genes[k] for k in sorted(genes.keys())] if all(isinstance(k, int) for k in genes) else list(genes.values())
+        need = torch.is_grad_enabled() and self.training_grad     # (grad mode is off inside Function.forward)
+        return _ModelFn.apply(self._dummy, self, x, coords, genes, task_onehots.to(self.engine.device, F32), need)

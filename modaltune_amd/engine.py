@@ -168,11 +168,12 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, B: int, L: int) -> Dict[str, torch.Tensor]:
+    def _workspace(self, B: int, L: int, fresh: bool = False) -> Dict[str, torch.Tensor]:
         key = (B, L)
-        if key in self._ws:
+        if not fresh and key in self._ws:
             return self._ws[key]
-        self._ws.clear()          # one resident geometry at a time
+        if not fresh:
+            self._ws.clear()      # one resident geometry at a time
         cfg, dev = self.cfg, self.device
         N, D, Fd, E = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim
         M, Mp = B * N, B * L
@@ -209,14 +210,17 @@ class Engine:
         w["dqkv32"] = e32(M, 3 * D)
         w["dqkv16"] = e16(M, 3 * D)
         w["scratch32"] = e32(Mp, D)
-        self._ws[key] = w
+        if not fresh:
+            self._ws[key] = w
         return w
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, coords, genes: Sequence[torch.Tensor], task_onehots: torch.Tensor,
-                need_grad: bool = True) -> torch.Tensor:
+                need_grad: bool = True, fresh: bool = False) -> torch.Tensor:
         """x [L, in_chans] (or [1,L,in]); coords [L,2] (host or device); genes: list of [1, n_i]; task_onehots [B, num_tasks].
-        Returns logits [B, output_dim] (fp32, device)."""
+        Returns logits [B, output_dim] (fp32, device).  fresh=True gives this call its own tape and workspace so that
+        several forwards can precede one backward (the reference calls the model 3x before loss.backward(), TM:175-177);
+        `self.last_call` is the handle `backward(..., call=)` takes."""
         cfg, dev, t = self.cfg, self.device, self.store.tensors
         if not self._caches_ready:
             self._build_caches()
@@ -225,7 +229,9 @@ class Engine:
         B = task_onehots.shape[0]
         N, D, Fd, E, T = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim, self.T
         M, Mp = B * N, B * L
-        ws = self._workspace(B, L)
+        ws = self._workspace(B, L, fresh=fresh)
+        if fresh:
+            self.tape = Tape(self.device)
         tape = self.tape
         tape.reset()
         tape.grad_enabled = need_grad
@@ -283,6 +289,7 @@ class Engine:
         # ---- fusion head (LVA:309-347)
         logits = self._head(c, ws[f"hout{nint - 1}"])
         self._logits = logits
+        self.last_call = (tape, logits)
         return logits.data
 
     # ------------------------------------------------------------------ token-side pieces
@@ -575,7 +582,8 @@ class Engine:
         return tape.linear(n, P("final_project.weight"), P("final_project.bias"))
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dlogits: torch.Tensor):
+    def backward(self, dlogits: torch.Tensor, call=None):
         """Accumulates into ParamStore.flat_grad; dlogits [B, output_dim] fp32 (already loss-scaled if desired)."""
-        self._logits.grad = dlogits.to(self.device, F32).contiguous()
-        self.tape.run_backward()
+        tape, logits = call if call is not None else (self.tape, self._logits)
+        logits.grad = dlogits.to(self.device, F32).contiguous()
+        tape.run_backward()

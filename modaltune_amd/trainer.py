@@ -13,7 +13,7 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 import torch
 
-from . import ops
+from . import dp, ops
 from .engine import Engine, F32
 from .tape import Param, Var
 
@@ -82,11 +82,7 @@ class TrainStep:
 
     def optimizer_step(self):
         eng = self.engine
-        world = 1
-        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            world = torch.distributed.get_world_size(self.pg)
-            if world > 1:
-                torch.distributed.all_reduce(eng.store.flat_grad, group=self.pg)      # sum; mean folded into AdamW
+        world = dp.allreduce_sum_(eng.store.flat_grad, self.pg)      # sum over ranks; mean folded into AdamW
         n = eng.store.n_flat
         ops.check_finite(eng.store.flat_grad, n, self.found_inf)
         ops.adamw_step(eng.store.flat, eng.store.flat_grad, self.m, self.v, n, self.lr, self.betas[0], self.betas[1], self.eps,

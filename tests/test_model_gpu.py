@@ -91,3 +91,56 @@ def test_optimizer_step_matches_oracle_adamw(golden_dir):
     loss2 = ts.step(x, inp["coords"], genes, torch.from_numpy(inp["text"]), update=True)
     torch.cuda.synchronize()
     assert np.isfinite(float(loss2)) and int(ts.step_dev) == 2
+
+
+def test_nn_module_dropin_api_matches_reference_golden(golden_dir):
+    """The reference's own call pattern (TM:123-126,172-177,225-235): Aggregator.create(...), 3x model(...), torch loss,
+    loss.backward() -> param.grad; state_dict keys round-trip."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    from oracle import modaltune_oracle as O
+    g = np.load(os.path.join(golden_dir, "model_L37_d3.npz"))
+    L, seed, ngrids = int(g["L"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    json_cfg = dict(in_chans=1536, embed_dim=768, depth=3, slide_ngrids=ngrids, interaction_indexes=[[0, 0], [1, 1], [2, 2]],
+                    num_heads=12, output_dim=256, init_values=0.0, geneclass_name="gene_mixer_group", with_cffn=True,
+                    cffn_ratio=0.25, add_prompt_feature=True, use_extra_extractor=True, freeze_vit=True, with_cp=False,
+                    use_prompt_sa=True, prompt_dropout=0.0, prompt_agg="avg", token_agg="sum", pretrained=False,
+                    dropout=0.25, drop_path_rate=0.1, mlp_ratio=4, global_pool=False, tile_size=256, max_wsi_size=262144,
+                    clinfeat_dim=5)
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, **json_cfg, multi_task=3).to("cuda")
+    assert model.is_multi
+    cfg = ModelConfig.from_json(json_cfg, multi_task=3)
+    sd = synth.synth_state_dict(cfg, sizes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    assert sum(p.numel() for p in trainable) == 9229831 and len(trainable) == 244
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    x = torch.from_numpy(inp["x"]).cuda()
+    coords = torch.from_numpy(inp["coords"]).cuda()
+    genes = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    model.train()
+    logits = torch.cat([model(x=x, coords=coords, genes=genes, clinical=[], task_token=torch.eye(3)[t].cuda()) for t in (0, 1, 2)], dim=0)
+    assert _rel(logits.detach().cpu().numpy(), g["f64_logits"]) < 1e-3
+    text = torch.from_numpy(g["f64_text"]).float().cuda()
+    loss = O.distill_loss(logits, text)            # torch ops on the GPU, exactly as the reference trainer computes it
+    assert abs(float(loss.detach()) - float(g["f64_loss"])) < 1e-3 * float(g["f64_loss"])
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [str(n) for n in g["f64_grad_names"]]
+    params = dict(model.named_parameters())
+    ours = np.array([float(params[n].grad.double().norm()) for n in names])
+    ref = g["f64_grad_norms"]
+    bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > 2e-2 * r + 1e-6 * ref.max()]
+    assert not bad, bad[:10]
+    # a torch optimiser over model.parameters() works on the flat-buffer views, and the next forward sees the update
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    opt.step()
+    opt.zero_grad()
+    with torch.no_grad():
+        model.eval()
+        l2 = model(x=x, coords=coords, genes=genes, task_token=torch.eye(3)[0].cuda())
+    assert torch.isfinite(l2).all() and float((l2 - logits[:1].detach()).abs().max()) > 0
