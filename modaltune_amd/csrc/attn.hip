@@ -12,6 +12,8 @@
 //   S^T[key, q] = K . Q^T           v_mfma_f32_32x32x16_f16, K rows from LDS (ds_read_b128), Q^T in registers
 //   O^T[d, q]  += V^T[d, key] . P^T  P^T taken straight from the S accumulators (no LDS round trip),
 //                                    V^T via ds_read_b64_tr_b16; V carries a ones column so O^T row 48 = sum(P)
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -21,6 +23,7 @@ constexpr int KSTR = 56;    // halves per K-layout LDS row (112 B: conflict-free
 constexpr int VSTR = 96;    // halves per V-layout LDS row (192 B: conflict-free ds_read_b64_tr_b16)
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_LOG2 = 8.0f;
 
 struct Plan {
   int nbranch, N, B;
@@ -96,7 +99,15 @@ struct Seq {
     return i < n && loc < s && seg_base + loc < N;
   }
   MT_DEVINL long row(int i) const { return row_base + seg_base + r + (long)i * dr; }
+  // always-in-bounds row for unconditional loads (the value is discarded with a select when !valid(i)):
+  // a branch around each load would make hipcc wait for every load separately (guide §5 trap (c))
+  MT_DEVINL long row_clamped(int i) const { return min(row(i), row_base + (long)N - 1); }
 };
+
+MT_DEVINL h16x8 sel8(bool ok, h16x8 v) {
+  const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return ok ? v : z;
+}
 
 MT_DEVINL Seq make_seq(const Plan& p, const WorkItem& w) {
   Seq q;
@@ -141,35 +152,30 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   // Q^T fragments (B operand): lane = query, element j of k-step ks = Q[q][16 ks + 8 hh + j]
   const int iq = w.qt * 128 + wave * 32 + l31;
   const bool qvalid = sq.valid(iq);
-  const long qrow = qvalid ? sq.row(iq) : 0;
+  const long qrow = sq.row_clamped(iq);
   h16x8 qf[3];
-  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
-    qf[ks] = qvalid ? ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8) : zero8;
+    qf[ks] = sel8(qvalid, ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8));
 
   const StageIdx st(tid);
   h16x8 rk0, rk1, rv0, rv1;
+  bool ok0 = false, ok1 = false;
+  // The loads are unconditional and their results are first touched in lstore() (after the tile's MFMAs), so the
+  // global-load latency hides under the compute; padded rows are zeroed by a select at store time.
   auto gload = [&](int kb) {
-    const int i0 = kb + st.row0;
-    if (sq.valid(i0)) {
-      const h16* base = qkv + sq.row(i0) * QKV_LD + w.h * HD + st.part0 * 8;
-      rk0 = ldg8(base + DM); rv0 = ldg8(base + 2 * DM);
-    } else { rk0 = zero8; rv0 = zero8; }
-    if (st.has1) {
-      const int i1 = kb + st.row1;
-      if (sq.valid(i1)) {
-        const h16* base = qkv + sq.row(i1) * QKV_LD + w.h * HD + st.part1 * 8;
-        rk1 = ldg8(base + DM); rv1 = ldg8(base + 2 * DM);
-      } else { rk1 = zero8; rv1 = zero8; }
-    }
+    const int i0 = kb + st.row0, i1 = kb + st.row1;
+    const h16* b0 = qkv + sq.row_clamped(i0) * QKV_LD + w.h * HD + st.part0 * 8;
+    const h16* b1 = qkv + sq.row_clamped(i1) * QKV_LD + w.h * HD + st.part1 * 8;
+    rk0 = ldg8(b0 + DM); rv0 = ldg8(b0 + 2 * DM); rk1 = ldg8(b1 + DM); rv1 = ldg8(b1 + 2 * DM);
+    ok0 = sq.valid(i0); ok1 = sq.valid(i1);
   };
   auto lstore = [&](int buf) {
-    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = rk0;
-    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = rv0;
+    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = sel8(ok0, rk0);
+    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = sel8(ok0, rv0);
     if (st.has1) {
-      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = rk1;
-      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = rv1;
+      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = sel8(ok1, rk1);
+      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = sel8(ok1, rv1);
     }
   };
 
@@ -184,7 +190,9 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   __syncthreads();
   // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  for (int t = 0; t < ntile; ++t) {
+  // m_run is the running row maximum of the RAW logits q.k (scale c folded into the exp2 argument)
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = t & 1, kb = t * 64;
     if (t + 1 < ntile) gload(kb + 64);
     f32x16 s[2];
@@ -198,36 +206,36 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
       }
     }
-    // scaled logits (log2 domain); keys >= n are tile padding (excluded); zero-padded keys keep logit 0
+    // keys >= n are tile padding (excluded, last tile only); zero-padded keys keep logit 0 (DA:98-101)
     float mx = NEG_BIG;
-    const bool tail = kb + 64 > sq.n;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float v = s[sub][i] * c;
-        if (tail) {
+        if (TAIL) {
           const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (kidx >= sq.n) v = NEG_BIG;
+          if (kidx >= sq.n) s[sub][i] = NEG_BIG;
         }
-        s[sub][i] = v;
-        mx = fmaxf(mx, v);
+        mx = fmaxf(mx, s[sub][i]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    if (__any(m_new > m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    // Deferred rescale (exact): the reference point m_run only moves when some row's maximum grew by more than
+    // 2^RESCALE_LOG2; until then P = exp2((s - m_run) c) <= 2^RESCALE_LOG2, which fp16 P / fp32 O hold without loss.
+    if (__any((m_new - m_run) * c > RESCALE_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
 #pragma unroll
       for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      m_run = m_new;
     }
-    m_run = m_new;
+    const float mc = m_run * c;
     h16x8 pf[2][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[sub][s2][e] = (h16)__builtin_amdgcn_exp2f(s[sub][8 * s2 + e] - m_new);
+        for (int e = 0; e < 8; ++e) pf[sub][s2][e] = (h16)__builtin_amdgcn_exp2f(fmaf(s[sub][8 * s2 + e], c, -mc));
     // O^T += V^T . P^T ; A fragment element e of lane half hh = V[key 16 s2 + 8 (e>>2) + 4 hh + (e&3)][d = lane & 31]
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -241,7 +249,10 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       }
     if (t + 1 < ntile) lstore(buf ^ 1);
     __syncthreads();
-  }
+  };
+  const int nfull = (sq.n & 63) ? ntile - 1 : ntile;
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  if (nfull < ntile) tile(ntile - 1, std::true_type{});
 
   if (qvalid) {
     const float l = o1[8];           // O^T row 48 (lane half 0) / row 52 (lane half 1): both carry sum(P)
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       h16x4 v = {(h16)(o1[4 * gq] * inv), (h16)(o1[4 * gq + 1] * inv), (h16)(o1[4 * gq + 2] * inv), (h16)(o1[4 * gq + 3] * inv)};
       *reinterpret_cast<h16x4*>(orow + 32 + 8 * gq + 4 * hh) = v;
     }
-    if (hh == 0) lse_br[((long)w.br * M + qrow) * H + w.h] = (m_run + __log2f(l)) * LN2;
+    if (hh == 0) lse_br[((long)w.br * M + qrow) * H + w.h] = (m_run * c + __log2f(l)) * LN2;
   }
 }
 
@@ -440,41 +451,38 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 
   const int iq = w.qt * 128 + wave * 32 + l31;
   const bool qvalid = sq.valid(iq);
-  const long qrow = qvalid ? sq.row(iq) : 0;
+  const long qrow = sq.row_clamped(iq);
   h16x8 qf[3], dof[3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
-    qf[ks] = qvalid ? ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8) : zero8;
-    dof[ks] = qvalid ? ldg8(dmixed + qrow * DM + w.h * HD + ks * 16 + hh * 8) : zero8;
+    qf[ks] = sel8(qvalid, ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8));
+    dof[ks] = sel8(qvalid, ldg8(dmixed + qrow * DM + w.h * HD + ks * 16 + hh * 8));
   }
   // invalid queries: L2 = +big -> P~ = 0
-  const float L2 = qvalid ? lse_tot[qrow * H + w.h] * LOG2E : 1.0e30f;
-  const float delta = qvalid ? delta_br[((long)w.br * M + qrow) * H + w.h] : 0.f;
+  const float L2raw = lse_tot[qrow * H + w.h], dlraw = delta_br[((long)w.br * M + qrow) * H + w.h];
+  const float L2 = qvalid ? L2raw * LOG2E : 1.0e30f;
+  const float delta = qvalid ? dlraw : 0.f;
 
   const StageIdx st(tid);
   h16x8 rk0, rk1, rv0, rv1;
-  auto gload = [&](int kb) {
-    const int i0 = kb + st.row0;
-    if (sq.valid(i0)) {
-      const h16* base = qkv + sq.row(i0) * QKV_LD + w.h * HD + st.part0 * 8;
-      rk0 = ldg8(base + DM); rv0 = ldg8(base + 2 * DM);
-    } else { rk0 = zero8; rv0 = zero8; }
-    if (st.has1) {
-      const int i1 = kb + st.row1;
-      if (sq.valid(i1)) {
-        const h16* base = qkv + sq.row(i1) * QKV_LD + w.h * HD + st.part1 * 8;
-        rk1 = ldg8(base + DM); rv1 = ldg8(base + 2 * DM);
-      } else { rk1 = zero8; rv1 = zero8; }
-    }
+  bool ok0 = false, ok1 = false;
+  auto gload = [&](int kb) {      // unconditional loads, first touched in lstore() (latency hides under the MFMAs)
+    const int i0 = kb + st.row0, i1 = kb + st.row1;
+    const h16* b0 = qkv + sq.row_clamped(i0) * QKV_LD + w.h * HD + st.part0 * 8;
+    const h16* b1 = qkv + sq.row_clamped(i1) * QKV_LD + w.h * HD + st.part1 * 8;
+    rk0 = ldg8(b0 + DM); rv0 = ldg8(b0 + 2 * DM); rk1 = ldg8(b1 + DM); rv1 = ldg8(b1 + 2 * DM);
+    ok0 = sq.valid(i0); ok1 = sq.valid(i1);
   };
   auto lstore = [&](int buf) {
-    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = rk0;
-    *reinterpret_cast<h16x8*>(&Kt[buf][st.row0 * VSTR + st.part0 * 8]) = rk0;
-    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * KSTR + st.part0 * 8]) = rv0;
+    const h16x8 k0 = sel8(ok0, rk0), v0 = sel8(ok0, rv0);
+    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = k0;
+    *reinterpret_cast<h16x8*>(&Kt[buf][st.row0 * VSTR + st.part0 * 8]) = k0;
+    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * KSTR + st.part0 * 8]) = v0;
     if (st.has1) {
-      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = rk1;
-      *reinterpret_cast<h16x8*>(&Kt[buf][st.row1 * VSTR + st.part1 * 8]) = rk1;
-      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * KSTR + st.part1 * 8]) = rv1;
+      const h16x8 k1 = sel8(ok1, rk1), v1 = sel8(ok1, rv1);
+      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = k1;
+      *reinterpret_cast<h16x8*>(&Kt[buf][st.row1 * VSTR + st.part1 * 8]) = k1;
+      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * KSTR + st.part1 * 8]) = v1;
     }
   };
 
@@ -486,10 +494,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   lstore(0);
   __syncthreads();
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  for (int t = 0; t < ntile; ++t) {
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = t & 1, kb = t * 64;
     if (t + 1 < ntile) gload(kb + 64);
-    const bool tail = kb + 64 > sq.n;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -505,8 +513,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
       h16x8 dsf[2];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float pt = __builtin_amdgcn_exp2f(s[i] * c - L2);
-        if (tail) {
+        float pt = __builtin_amdgcn_exp2f(fmaf(s[i], c, -L2));
+        if (TAIL) {
           const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
           if (kidx >= sq.n) pt = 0.f;
         }
@@ -523,7 +531,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
     }
     if (t + 1 < ntile) lstore(buf ^ 1);
     __syncthreads();
-  }
+  };
+  const int nfull = (sq.n & 63) ? ntile - 1 : ntile;
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  if (nfull < ntile) tile(ntile - 1, std::true_type{});
   if (qvalid) {
     float* out = dqkv + qrow * QKV_LD + w.h * HD;
 #pragma unroll
@@ -584,53 +595,43 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   // this lane's key: K^T / V^T fragments (B operands), element j of k-step ks = K[key][16 ks + 8 hh + j]
   const int ik = w.qt * 128 + wave * 32 + l31;
   const bool kvalid = sq.valid(ik);
-  const long krow = kvalid ? sq.row(ik) : 0;
+  const long krow = sq.row_clamped(ik);
   h16x8 kf[3], vf[3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
-    kf[ks] = kvalid ? ldg8(qkv + krow * QKV_LD + DM + w.h * HD + ks * 16 + hh * 8) : zero8;
-    vf[ks] = kvalid ? ldg8(qkv + krow * QKV_LD + 2 * DM + w.h * HD + ks * 16 + hh * 8) : zero8;
+    kf[ks] = sel8(kvalid, ldg8(qkv + krow * QKV_LD + DM + w.h * HD + ks * 16 + hh * 8));
+    vf[ks] = sel8(kvalid, ldg8(qkv + krow * QKV_LD + 2 * DM + w.h * HD + ks * 16 + hh * 8));
   }
 
   const StageIdx st(tid);
   h16x8 rq0, rq1, rd0, rd1;
   float rl2 = 0.f, rdl = 0.f;
-  auto gload = [&](int qb) {
-    const int i0 = qb + st.row0;
-    if (sq.valid(i0)) {
-      const long r = sq.row(i0);
-      rq0 = ldg8(qkv + r * QKV_LD + w.h * HD + st.part0 * 8);
-      rd0 = ldg8(dmixed + r * DM + w.h * HD + st.part0 * 8);
-    } else { rq0 = zero8; rd0 = zero8; }
-    if (st.has1) {
-      const int i1 = qb + st.row1;
-      if (sq.valid(i1)) {
-        const long r = sq.row(i1);
-        rq1 = ldg8(qkv + r * QKV_LD + w.h * HD + st.part1 * 8);
-        rd1 = ldg8(dmixed + r * DM + w.h * HD + st.part1 * 8);
-      } else { rq1 = zero8; rd1 = zero8; }
-    }
-    if (tid < 64) {
-      const int i = qb + tid;
-      if (sq.valid(i)) {
-        const long r = sq.row(i);
-        rl2 = lse_tot[r * H + w.h] * LOG2E;
-        rdl = delta_br[((long)w.br * M + r) * H + w.h];
-      } else { rl2 = 1.0e30f; rdl = 0.f; }     // padded / out-of-range queries contribute nothing
-    }
+  bool ok0 = false, ok1 = false, ok2 = false;
+  auto gload = [&](int qb) {      // unconditional loads, first touched in lstore()
+    const int i0 = qb + st.row0, i1 = qb + st.row1, i2 = qb + (tid & 63);
+    const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1), r2 = sq.row_clamped(i2);
+    rq0 = ldg8(qkv + r0 * QKV_LD + w.h * HD + st.part0 * 8); rd0 = ldg8(dmixed + r0 * DM + w.h * HD + st.part0 * 8);
+    rq1 = ldg8(qkv + r1 * QKV_LD + w.h * HD + st.part1 * 8); rd1 = ldg8(dmixed + r1 * DM + w.h * HD + st.part1 * 8);
+    rl2 = lse_tot[r2 * H + w.h]; rdl = delta_br[((long)w.br * M + r2) * H + w.h];
+    ok0 = sq.valid(i0); ok1 = sq.valid(i1); ok2 = sq.valid(i2);
   };
   auto lstore = [&]() {
-    *reinterpret_cast<h16x8*>(&Qs[st.row0 * KSTR + st.part0 * 8]) = rq0;
-    *reinterpret_cast<h16x8*>(&Qt[st.row0 * VSTR + st.part0 * 8]) = rq0;
-    *reinterpret_cast<h16x8*>(&Ds[st.row0 * KSTR + st.part0 * 8]) = rd0;
-    *reinterpret_cast<h16x8*>(&Dt[st.row0 * VSTR + st.part0 * 8]) = rd0;
+    const h16x8 q0 = sel8(ok0, rq0), d0 = sel8(ok0, rd0);
+    *reinterpret_cast<h16x8*>(&Qs[st.row0 * KSTR + st.part0 * 8]) = q0;
+    *reinterpret_cast<h16x8*>(&Qt[st.row0 * VSTR + st.part0 * 8]) = q0;
+    *reinterpret_cast<h16x8*>(&Ds[st.row0 * KSTR + st.part0 * 8]) = d0;
+    *reinterpret_cast<h16x8*>(&Dt[st.row0 * VSTR + st.part0 * 8]) = d0;
     if (st.has1) {
-      *reinterpret_cast<h16x8*>(&Qs[st.row1 * KSTR + st.part1 * 8]) = rq1;
-      *reinterpret_cast<h16x8*>(&Qt[st.row1 * VSTR + st.part1 * 8]) = rq1;
-      *reinterpret_cast<h16x8*>(&Ds[st.row1 * KSTR + st.part1 * 8]) = rd1;
-      *reinterpret_cast<h16x8*>(&Dt[st.row1 * VSTR + st.part1 * 8]) = rd1;
+      const h16x8 q1 = sel8(ok1, rq1), d1 = sel8(ok1, rd1);
+      *reinterpret_cast<h16x8*>(&Qs[st.row1 * KSTR + st.part1 * 8]) = q1;
+      *reinterpret_cast<h16x8*>(&Qt[st.row1 * VSTR + st.part1 * 8]) = q1;
+      *reinterpret_cast<h16x8*>(&Ds[st.row1 * KSTR + st.part1 * 8]) = d1;
+      *reinterpret_cast<h16x8*>(&Dt[st.row1 * VSTR + st.part1 * 8]) = d1;
     }
-    if (tid < 64) { L2s[tid] = rl2; Dls[tid] = rdl; }
+    if (tid < 64) {      // padded / out-of-range queries contribute nothing: L2 = +big -> P~ = 0
+      L2s[tid] = ok2 ? rl2 * LOG2E : 1.0e30f;
+      Dls[tid] = ok2 ? rdl : 0.f;
+    }
   };
 
   f32x16 dk0, dk1, dv0, dv1;
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g4 + e;
-          const float pt = __builtin_amdgcn_exp2f(s[i] * c - l2[e]);
+          const float pt = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l2[e]));
           pf[i >> 3][i & 7] = (h16)pt;
           dsf[i >> 3][i & 7] = (h16)(pt * (dp[i] - dl[e]) * scale);
         }

@@ -201,12 +201,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   const int srow = tid >> 3, skc = tid & 7;
   h16x8 ra, rb;
   const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto gload = [&](int mt) {
-    const int m = mt + srow;
-    if (m < mend) {
-      ra = ldg8(g.A + g.amap.map(m) * g.lda + n1_0 + skc * 8);
-      rb = ldg8(g.B + g.bmap.map(m) * g.ldb + n2_0 + skc * 8);
-    } else { ra = zero; rb = zero; }
+  auto gload = [&](int mt) {      // branch-free: clamp the row, select zero past the end of the split
+    const int m = mt + srow, mc = min(m, mend - 1);
+    const h16x8 a = ldg8(g.A + g.amap.map(mc) * g.lda + n1_0 + skc * 8);
+    const h16x8 b = ldg8(g.B + g.bmap.map(mc) * g.ldb + n2_0 + skc * 8);
+    ra = m < mend ? a : zero; rb = m < mend ? b : zero;
   };
   auto lstore = [&](int buf) {
     *reinterpret_cast<h16x8*>(&As[buf][srow * TN_STRIDE + skc * 8]) = ra;

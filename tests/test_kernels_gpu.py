@@ -261,6 +261,37 @@ def test_dilated_attention_fwd_mix_vs_reference_golden(ops, golden_dir, case):
     assert float((lse_tot.view(B, N, 16).double().cpu() - tot).abs().max()) < 2e-3
 
 
+def test_dilated_attention_deferred_rescale_branch(ops):
+    """Force the rarely-taken online-softmax rescale (guide rule 26): logits jump by >> 2^8 at late key tiles,
+    for some rows only, so the deferred-rescale branch fires mid-sequence; compare all rows with the fp64 oracle."""
+    from oracle import modaltune_oracle as O
+    g = rng(77)
+    B, N = 1, 1500
+    segs, ratios = [1024, 5792, 32768, 185363, 1048576], [1, 2, 4, 8, 16]
+    q = torch.randn(B, N, 16, 48, generator=g) * 0.5
+    k = torch.randn(B, N, 16, 48, generator=g) * 0.5
+    v = torch.randn(B, N, 16, 48, generator=g)
+    for pos, key, gain in ((5, 700, 40.0), (1100, 1400, 60.0), (300, 1023, 25.0), (1499, 1300, 80.0)):
+        k[0, key] = q[0, pos] * gain          # a huge logit for query `pos` at a late key
+    qkv = torch.cat([q.reshape(B, N, 768), k.reshape(B, N, 768), v.reshape(B, N, 768)], -1).half()
+    bt = branch_table(N, segs, ratios)
+    plan = ops.make_plan(bt, N, B)
+    M = B * N
+    o_br = torch.zeros(5, M, 768, dtype=torch.float16, device=DEV)
+    lse_br = torch.zeros(5, M, 16, device=DEV)
+    ops.dilated_attn_fwd(qkv.to(DEV).view(M, 2304), plan, o_br, lse_br)
+    torch.cuda.synchronize()
+    qd, kd, vd = (t.view(B, N, 16, 48) for t in qkv.double().split(768, dim=-1))
+    _, outs, lses = O.dilated_attention_core(qd, kd, vd, segs, ratios, return_branches=True)
+    for i in range(5):
+        cov = lses[i] > -1e7
+        got_o = o_br[i].view(B, N, 16, 48).double().cpu()
+        got_l = lse_br[i].view(B, N, 16).double().cpu()
+        assert torch.isfinite(got_o).all()
+        assert float(((got_o - outs[i]).abs() * cov.unsqueeze(-1)).max()) < 4e-3 * float(outs[i].abs().max())
+        assert float((((got_l - lses[i]) / lses[i].abs().clamp(min=1.0)).abs() * cov).max()) < 2e-3
+
+
 @pytest.mark.parametrize("case", ["a", "b", "c"])
 def test_dilated_attention_bwd_vs_oracle_autograd(ops, golden_dir, case):
     from oracle import modaltune_oracle as O
