@@ -50,7 +50,8 @@ SIGNATURES = {
     "mt_dilated_attn_fwd": [P, PL, P, P, P],
     "mt_dilated_mix_ln_fwd": [P, P, PL, P, P, P, P, P, P],
     "mt_dilated_mix_ln_bwd": [P, P, P, P, PL, P, P, P, P, P],
-    "mt_dilated_attn_bwd": [P, P, P, P, PL, P, P],
+    "mt_dilated_attn_bwd_workspace_bytes": [PL],
+    "mt_dilated_attn_bwd": [P, P, P, P, PL, P, P, P],
     "mt_inject_attn_fwd": [P, I, I, P, P, I, P, P],
     "mt_inject_attn_bwd": [P, P, I, I, P, P, I, P, P, P, P],
     "mt_extract_attn_fwd": [P, P, I, I, I, P, P, P, P, I, P],
@@ -71,7 +72,7 @@ SIGNATURES = {
     "mt_scaler_update": [P, P, P, P, F, F, I, P],
     "mt_check_finite": [P, L, P, P],
 }
-_RESTYPE = {"mt_status_string": C.c_char_p}
+_RESTYPE = {"mt_status_string": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long}
 
 _lib = None
 

@@ -29,6 +29,7 @@ struct Plan {
   int nbranch, N, B;
   int seg[MT_MAX_BRANCHES], ratio[MT_MAX_BRANCHES], nseg[MT_MAX_BRANCHES], n[MT_MAX_BRANCHES];
   int order[MT_MAX_BRANCHES], qtiles[MT_MAX_BRANCHES], blk_off[MT_MAX_BRANCHES + 1];
+  long ws_off[MT_MAX_BRANCHES + 1];   // backward workspace: per-branch compact [pass][seg][head][i][q|k|v][48] fp32
 };
 
 Plan make_plan(const MtDilatedPlan* p, int qtile) {
@@ -48,6 +49,8 @@ Plan make_plan(const MtDilatedPlan* p, int qtile) {
     const int b = d.order[i];
     d.blk_off[i + 1] = d.blk_off[i] + d.B * d.nseg[b] * H * d.qtiles[b];
   }
+  d.ws_off[0] = 0;
+  for (int b = 0; b < d.nbranch; ++b) d.ws_off[b + 1] = d.ws_off[b] + (long)d.B * d.nseg[b] * H * d.n[b] * 3 * HD;
   return d;
 }
 
@@ -63,23 +66,40 @@ bool plan_ok(const MtDilatedPlan* p) {
 
 struct WorkItem { int br, b, j, h, qt; };
 
-MT_DEVINL int xcd_remap(int bid, int nwg) {
-  const int q = nwg / 8, r = nwg % 8, x = bid % 8;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
-}
-
+// Workgroup -> work item.  Blocks b and b + 8 share an XCD (round-robin dispatch), so XCD x = bid % 8 walks its own
+// list j = bid / 8: per branch (longest sequences first) the (pass, segment, head) groups x, x + 8, x + 16, ... and,
+// inside a group, the query tiles back to back.  All query tiles of a group -- which re-read the same K/V rows --
+// therefore run on ONE XCD's L2, and every XCD gets the same mix of long and short sequences (each branch has a
+// multiple of 8 groups because there are 16 heads).  Placement only affects speed, never results.
 MT_DEVINL WorkItem decode(const Plan& p, int bid) {
+  const int x = bid & 7, j = bid >> 3;
   int oi = 0;
 #pragma unroll
   for (int i = 1; i < MT_MAX_BRANCHES; ++i)
-    if (i < p.nbranch && bid >= p.blk_off[i]) oi = i;
+    if (i < p.nbranch && j >= (p.blk_off[i] >> 3)) oi = i;
   WorkItem w;
   w.br = p.order[oi];
-  int local = bid - p.blk_off[oi];
-  w.qt = local % p.qtiles[w.br]; local /= p.qtiles[w.br];
-  w.h = local % H; local /= H;
-  w.j = local % p.nseg[w.br];
-  w.b = local / p.nseg[w.br];
+  int local = j - (p.blk_off[oi] >> 3);
+  w.qt = local % p.qtiles[w.br];
+  const int gid = (local / p.qtiles[w.br]) * 8 + x;     // group index inside the branch
+  w.h = gid % H;
+  const int r = gid / H;
+  w.j = r % p.nseg[w.br];
+  w.b = r / p.nseg[w.br];
+  return w;
+}
+
+// single-branch launches (backward): same XCD-balanced walk over one branch
+MT_DEVINL WorkItem decode_branch(const Plan& p, int br, int bid) {
+  const int x = bid & 7, j = bid >> 3;
+  WorkItem w;
+  w.br = br;
+  w.qt = j % p.qtiles[br];
+  const int gid = (j / p.qtiles[br]) * 8 + x;
+  w.h = gid % H;
+  const int r = gid / H;
+  w.j = r % p.nseg[br];
+  w.b = r / p.nseg[br];
   return w;
 }
 
@@ -109,6 +129,11 @@ MT_DEVINL h16x8 sel8(bool ok, h16x8 v) {
   return ok ? v : z;
 }
 
+// backward workspace slot of sparse entry i of work item w: 3 x 48 floats (dq | dk | dv)
+MT_DEVINL long ws_slot(const Plan& p, const WorkItem& w, int i) {
+  return p.ws_off[w.br] + ((((long)w.b * p.nseg[w.br] + w.j) * H + w.h) * p.n[w.br] + i) * (3 * HD);
+}
+
 MT_DEVINL Seq make_seq(const Plan& p, const WorkItem& w) {
   Seq q;
   q.n = p.n[w.br]; q.s = p.seg[w.br]; q.dr = p.ratio[w.br];
@@ -128,7 +153,10 @@ struct StageIdx {
 };
 
 // ------------------------------------------------------------------------------------------------
-// forward
+// forward.  Software-pipelined across key tiles inside each wave: while the softmax of tile t runs on the VALU
+// (exp2 dominates at head dim 48), the S^T = K.Q^T MFMAs of tile t+1 are already in flight, and the P.V MFMAs of
+// tile t follow.  K and V ring through two LDS buffers each (K one tile ahead of V), one barrier per tile;
+// global loads for K(t+2) / V(t+1) are issued at the top of the tile and first touched at its end.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __restrict__ qkv, Plan p, h16* __restrict__ o_br,
                                                                float* __restrict__ lse_br) {
@@ -136,7 +164,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * VSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
-  const WorkItem w = decode(p, xcd_remap(blockIdx.x, gridDim.x));
+  const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
   const float c = 0.14433756729740643f * LOG2E;   // 48^-1/2 * log2(e)
@@ -159,43 +187,31 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
     qf[ks] = sel8(qvalid, ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8));
 
   const StageIdx st(tid);
-  h16x8 rk0, rk1, rv0, rv1;
-  bool ok0 = false, ok1 = false;
-  // The loads are unconditional and their results are first touched in lstore() (after the tile's MFMAs), so the
-  // global-load latency hides under the compute; padded rows are zeroed by a select at store time.
-  auto gload = [&](int kb) {
-    const int i0 = kb + st.row0, i1 = kb + st.row1;
-    const h16* b0 = qkv + sq.row_clamped(i0) * QKV_LD + w.h * HD + st.part0 * 8;
-    const h16* b1 = qkv + sq.row_clamped(i1) * QKV_LD + w.h * HD + st.part1 * 8;
-    rk0 = ldg8(b0 + DM); rv0 = ldg8(b0 + 2 * DM); rk1 = ldg8(b1 + DM); rv1 = ldg8(b1 + 2 * DM);
-    ok0 = sq.valid(i0); ok1 = sq.valid(i1);
-  };
-  auto lstore = [&](int buf) {
-    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = sel8(ok0, rk0);
-    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = sel8(ok0, rv0);
-    if (st.has1) {
-      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = sel8(ok1, rk1);
-      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = sel8(ok1, rv1);
-    }
-  };
-
-  f32x16 o0, o1;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-  float m_run = NEG_BIG;
-
   const int ntile = (sq.n + 63) / 64;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
-  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  // m_run is the running row maximum of the RAW logits q.k (scale c folded into the exp2 argument)
-  auto tile = [&](int t, auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    const int buf = t & 1, kb = t * 64;
-    if (t + 1 < ntile) gload(kb + 64);
-    f32x16 s[2];
+  h16x8 rk0, rk1, rv0, rv1;
+  bool kok0 = false, kok1 = false, vok0 = false, vok1 = false;
+  // unconditional loads (clamped rows); padded rows are zeroed by a select when the tile is written to LDS
+  auto gload_k = [&](int kb) {
+    const int i0 = kb + st.row0, i1 = kb + st.row1;
+    rk0 = ldg8(qkv + sq.row_clamped(i0) * QKV_LD + DM + w.h * HD + st.part0 * 8);
+    rk1 = ldg8(qkv + sq.row_clamped(i1) * QKV_LD + DM + w.h * HD + st.part1 * 8);
+    kok0 = sq.valid(i0); kok1 = sq.valid(i1);
+  };
+  auto gload_v = [&](int kb) {
+    const int i0 = kb + st.row0, i1 = kb + st.row1;
+    rv0 = ldg8(qkv + sq.row_clamped(i0) * QKV_LD + 2 * DM + w.h * HD + st.part0 * 8);
+    rv1 = ldg8(qkv + sq.row_clamped(i1) * QKV_LD + 2 * DM + w.h * HD + st.part1 * 8);
+    vok0 = sq.valid(i0); vok1 = sq.valid(i1);
+  };
+  auto lstore_k = [&](int buf) {
+    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = sel8(kok0, rk0);
+    if (st.has1) *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = sel8(kok1, rk1);
+  };
+  auto lstore_v = [&](int buf) {
+    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = sel8(vok0, rv0);
+    if (st.has1) *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = sel8(vok1, rv1);
+  };
+  auto qk = [&](int buf, f32x16 (&s)[2]) {      // raw scores of one 64-key tile: s[sub][reg] (key = row, query = lane)
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -206,6 +222,32 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
       }
     }
+  };
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+  float m_run = NEG_BIG;      // running row maximum of the RAW logits q.k (scale c folded into the exp2 argument)
+
+  // prologue: K(0), V(0) -> LDS; K(1) in flight; S(0)
+  gload_k(0); gload_v(0);
+  lstore_k(0); lstore_v(0);
+  if (ntile > 1) gload_k(64);
+  __syncthreads();
+  f32x16 s_cur[2], s_nxt[2];
+  qk(0, s_cur);
+  if (ntile > 1) lstore_k(1);
+  __syncthreads();
+
+  // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  auto tile = [&](int t, auto last_tag, auto tail_tag) {
+    constexpr bool LAST = decltype(last_tag)::value, TAIL = decltype(tail_tag)::value;
+    const int kb = t * 64;
+    if (!LAST) {
+      gload_v(kb + 64);                       // V(t+1)
+      if (t + 2 < ntile) gload_k(kb + 128);   // K(t+2)
+    }
     // keys >= n are tile padding (excluded, last tile only); zero-padded keys keep logit 0 (DA:98-101)
     float mx = NEG_BIG;
 #pragma unroll
@@ -214,9 +256,9 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       for (int i = 0; i < 16; ++i) {
         if (TAIL) {
           const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (kidx >= sq.n) s[sub][i] = NEG_BIG;
+          if (kidx >= sq.n) s_cur[sub][i] = NEG_BIG;
         }
-        mx = fmaxf(mx, s[sub][i]);
+        mx = fmaxf(mx, s_cur[sub][i]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
@@ -229,30 +271,37 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       m_run = m_new;
     }
     const float mc = m_run * c;
+    if (!LAST) qk((t + 1) & 1, s_nxt);        // S(t+1): MFMAs overlap the exp2 work below
     h16x8 pf[2][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[sub][s2][e] = (h16)__builtin_amdgcn_exp2f(fmaf(s[sub][8 * s2 + e], c, -mc));
+        for (int e = 0; e < 8; ++e) pf[sub][s2][e] = (h16)__builtin_amdgcn_exp2f(fmaf(s_cur[sub][8 * s2 + e], c, -mc));
     // O^T += V^T . P^T ; A fragment element e of lane half hh = V[key 16 s2 + 8 (e>>2) + 4 hh + (e&3)][d = lane & 31]
+    const int vbuf = t & 1;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const h16* vrow = &Vs[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
+        const h16* vrow = &Vs[vbuf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
         const h16x8 v0 = cat8(lds_tr4(vrow), lds_tr4(vrow + 8 * VSTR));
         const h16x8 v1 = cat8(lds_tr4(vrow + 32), lds_tr4(vrow + 8 * VSTR + 32));
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[sub][s2], o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[sub][s2], o1, 0, 0, 0);
       }
-    if (t + 1 < ntile) lstore(buf ^ 1);
-    __syncthreads();
+    if (!LAST) {
+      lstore_v((t + 1) & 1);                  // V(t+1) -> the buffer V(t-1) lived in
+      if (t + 2 < ntile) lstore_k(t & 1);     // K(t+2) -> the buffer K(t) lived in (S(t) is already in registers)
+      __syncthreads();
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) s_cur[sub] = s_nxt[sub];
+    }
   };
-  const int nfull = (sq.n & 63) ? ntile - 1 : ntile;
-  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
-  if (nfull < ntile) tile(ntile - 1, std::true_type{});
+  for (int t = 0; t < ntile - 1; ++t) tile(t, std::false_type{}, std::false_type{});
+  if (sq.n & 63) tile(ntile - 1, std::true_type{}, std::true_type{});
+  else tile(ntile - 1, std::true_type{}, std::false_type{});
 
   if (qvalid) {
     const float l = o1[8];           // O^T row 48 (lane half 0) / row 52 (lane half 1): both carry sum(P)
@@ -423,21 +472,13 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                  const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
-                                                                 Plan p, int br_only, int accumulate, float* __restrict__ dqkv) {
+                                                                 Plan p, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];   // row-read layout
   __shared__ __attribute__((aligned(16))) h16 Kt[2][64 * VSTR];   // transposed-read layout
   __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * KSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
-  WorkItem w;
-  {
-    int local = blockIdx.x;
-    w.br = br_only;
-    w.qt = local % p.qtiles[w.br]; local /= p.qtiles[w.br];
-    w.h = local % H; local /= H;
-    w.j = local % p.nseg[w.br];
-    w.b = local / p.nseg[w.br];
-  }
+  const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
   const float scale = 0.14433756729740643f, c = scale * LOG2E;
@@ -536,20 +577,16 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < ntile) tile(ntile - 1, std::true_type{});
   if (qvalid) {
-    float* out = dqkv + qrow * QKV_LD + w.h * HD;
+    float* out = ws + ws_slot(p, w, iq);
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      f32x4 v = {dq0[4 * gq], dq0[4 * gq + 1], dq0[4 * gq + 2], dq0[4 * gq + 3]};
-      f32x4* dst = reinterpret_cast<f32x4*>(out + 8 * gq + 4 * hh);
-      if (accumulate) v += *dst;
-      *dst = v;
+      const f32x4 v = {dq0[4 * gq], dq0[4 * gq + 1], dq0[4 * gq + 2], dq0[4 * gq + 3]};
+      *reinterpret_cast<f32x4*>(out + 8 * gq + 4 * hh) = v;
     }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
-      f32x4 v = {dq1[4 * gq], dq1[4 * gq + 1], dq1[4 * gq + 2], dq1[4 * gq + 3]};
-      f32x4* dst = reinterpret_cast<f32x4*>(out + 32 + 8 * gq + 4 * hh);
-      if (accumulate) v += *dst;
-      *dst = v;
+      const f32x4 v = {dq1[4 * gq], dq1[4 * gq + 1], dq1[4 * gq + 2], dq1[4 * gq + 3]};
+      *reinterpret_cast<f32x4*>(out + 32 + 8 * gq + 4 * hh) = v;
     }
   }
 }
@@ -564,7 +601,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
-                                                                  Plan p, int br_only, int accumulate, float* __restrict__ dqkv) {
+                                                                  Plan p, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) h16 Qs[64 * KSTR];
   __shared__ __attribute__((aligned(16))) h16 Qt[64 * VSTR];
   __shared__ __attribute__((aligned(16))) h16 Ds[64 * KSTR];
@@ -573,15 +610,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   __shared__ __attribute__((aligned(16))) float Dls[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
-  WorkItem w;
-  {
-    int local = blockIdx.x;
-    w.br = br_only;
-    w.qt = local % p.qtiles[w.br]; local /= p.qtiles[w.br];
-    w.h = local % H; local /= H;
-    w.j = local % p.nseg[w.br];
-    w.b = local / p.nseg[w.br];
-  }
+  const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
   const float scale = 0.14433756729740643f, c = scale * LOG2E;
@@ -686,25 +715,57 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     }
   }
   if (kvalid) {
-    float* outk = dqkv + krow * QKV_LD + DM + w.h * HD;
-    float* outv = outk + DM;
+    float* outk = ws + ws_slot(p, w, ik) + HD;
+    float* outv = outk + HD;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      f32x4 a = {dk0[4 * gq], dk0[4 * gq + 1], dk0[4 * gq + 2], dk0[4 * gq + 3]};
-      f32x4 b = {dv0[4 * gq], dv0[4 * gq + 1], dv0[4 * gq + 2], dv0[4 * gq + 3]};
-      f32x4* pk = reinterpret_cast<f32x4*>(outk + 8 * gq + 4 * hh);
-      f32x4* pv = reinterpret_cast<f32x4*>(outv + 8 * gq + 4 * hh);
-      if (accumulate) { a += *pk; b += *pv; }
-      *pk = a; *pv = b;
+      const f32x4 a = {dk0[4 * gq], dk0[4 * gq + 1], dk0[4 * gq + 2], dk0[4 * gq + 3]};
+      const f32x4 b = {dv0[4 * gq], dv0[4 * gq + 1], dv0[4 * gq + 2], dv0[4 * gq + 3]};
+      *reinterpret_cast<f32x4*>(outk + 8 * gq + 4 * hh) = a;
+      *reinterpret_cast<f32x4*>(outv + 8 * gq + 4 * hh) = b;
     }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
-      f32x4 a = {dk1[4 * gq], dk1[4 * gq + 1], dk1[4 * gq + 2], dk1[4 * gq + 3]};
-      f32x4 b = {dv1[4 * gq], dv1[4 * gq + 1], dv1[4 * gq + 2], dv1[4 * gq + 3]};
-      f32x4* pk = reinterpret_cast<f32x4*>(outk + 32 + 8 * gq + 4 * hh);
-      f32x4* pv = reinterpret_cast<f32x4*>(outv + 32 + 8 * gq + 4 * hh);
-      if (accumulate) { a += *pk; b += *pv; }
-      *pk = a; *pv = b;
+      const f32x4 a = {dk1[4 * gq], dk1[4 * gq + 1], dk1[4 * gq + 2], dk1[4 * gq + 3]};
+      const f32x4 b = {dv1[4 * gq], dv1[4 * gq + 1], dv1[4 * gq + 2], dv1[4 * gq + 3]};
+      *reinterpret_cast<f32x4*>(outk + 32 + 8 * gq + 4 * hh) = a;
+      *reinterpret_cast<f32x4*>(outv + 32 + 8 * gq + 4 * hh) = b;
+    }
+  }
+}
+
+// Sum the per-branch compact gradients into the dense fp16 dqkv [B*N, 2304] that feeds the dX GEMM.
+// 192 threads per token row: thread -> 12 consecutive columns of one (q|k|v, head).
+__global__ __launch_bounds__(192) void dilated_attn_bwd_combine_kernel(const float* __restrict__ ws, Plan p, h16* __restrict__ dqkv) {
+  const long M = (long)p.B * p.N;
+  const int t = threadIdx.x;
+  const int col = t * 12, which = col / DM, h = (col % DM) / HD, d0 = col % HD;
+  for (long m = blockIdx.x; m < M; m += gridDim.x) {
+    const int b = (int)(m / p.N), pos = (int)(m % p.N);
+    float acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int br = 0; br < MT_MAX_BRANCHES; ++br) {
+      if (br < p.nbranch) {
+        const int dr = p.ratio[br], sg = p.seg[br];
+        const int j = pos / sg, loc = pos - j * sg;
+        const int r = h / (H / dr);
+        if (loc % dr == r) {
+          const int i = loc / dr;
+          const float* src = ws + p.ws_off[br] + ((((long)b * p.nseg[br] + j) * H + h) * p.n[br] + i) * (3 * HD) + which * HD + d0;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4),
+                      a2 = *reinterpret_cast<const f32x4*>(src + 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[e] += a0[e]; acc[4 + e] += a1[e]; acc[8 + e] += a2[e]; }
+        }
+      }
+    }
+    h16* dst = dqkv + m * QKV_LD + col;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const h16x4 o = {(h16)acc[4 * k], (h16)acc[4 * k + 1], (h16)acc[4 * k + 2], (h16)acc[4 * k + 3]};
+      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
     }
   }
 }
@@ -746,23 +807,26 @@ extern "C" int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, con
   return MT_OK;
 }
 
-extern "C" int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot,
-                                   const float* delta_br, const MtDilatedPlan* plan, float* dqkv, mt_stream_t stream) {
-  if (!qkv || !dmixed || !lse_tot || !delta_br || !dqkv || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+extern "C" long mt_dilated_attn_bwd_workspace_bytes(const MtDilatedPlan* plan) {
+  if (!plan_ok(plan)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
-  // branch with ratio 1 visits every (position, head): run it first in store mode, the others accumulate.
-  int first = -1;
-  for (int b = 0; b < p.nbranch; ++b) if (p.ratio[b] == 1) { first = b; break; }
-  if (first < 0) return MT_ERR_UNSUPPORTED;
-  for (int k = 0; k < p.nbranch; ++k) {
-    const int b = k == 0 ? first : (k <= first ? k - 1 : k);
-    const int nblk = p.B * p.nseg[b] * H * p.qtiles[b];
-    const int acc = k == 0 ? 0 : 1;
-    hipLaunchKernelGGL(dilated_attn_bwd_q_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv,
-                       (const h16*)dmixed, lse_tot, delta_br, p, b, acc, dqkv);
-    hipLaunchKernelGGL(dilated_attn_bwd_kv_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv,
-                       (const h16*)dmixed, lse_tot, delta_br, p, b, acc, dqkv);
-    MT_CHECK_LAUNCH();
-  }
+  return p.ws_off[p.nbranch] * (long)sizeof(float);
+}
+
+extern "C" int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot,
+                                   const float* delta_br, const MtDilatedPlan* plan, float* workspace, mt_half* dqkv,
+                                   mt_stream_t stream) {
+  if (!qkv || !dmixed || !lse_tot || !delta_br || !workspace || !dqkv || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  const int nblk = p.blk_off[p.nbranch];
+  hipStream_t s = (hipStream_t)stream;
+  // every (branch, position, head) slot of the workspace is written exactly once by each of the two kernels
+  hipLaunchKernelGGL(dilated_attn_bwd_kv_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
+                     delta_br, p, workspace);
+  hipLaunchKernelGGL(dilated_attn_bwd_q_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
+                     delta_br, p, workspace);
+  const long M = (long)p.B * p.N;
+  hipLaunchKernelGGL(dilated_attn_bwd_combine_kernel, dim3((int)min(M, 16384L)), dim3(192), 0, s, workspace, p, (h16*)dqkv);
+  MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -207,7 +207,8 @@ class Engine:
         w["da1"] = e16(M, Fd)
         w["dmixed"] = e16(M, D)
         w["delta"] = e32(nb, M, 16)
-        w["dqkv32"] = e32(M, 3 * D)
+        plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
+        w["attn_ws"] = torch.empty(ops.dilated_attn_bwd_workspace_bytes(plan) // 4, dtype=F32, device=dev)
         w["dqkv16"] = e16(M, 3 * D)
         w["scratch32"] = e32(Mp, D)
         if not fresh:
@@ -481,8 +482,7 @@ class Engine:
             ops.cast_f32_to_f16(dh, dy16)
             ops.gemm_nt(dy16, f16[p + "out"].wt, u16, M, D, D)
             ops.dilated_mix_ln_bwd(u16, obr, lsebr, lsetot, plan, t[p + "self_attn.inner_attn_ln.weight"], stin, ws["dmixed"], ws["delta"])
-            ops.dilated_attn_bwd(qkv, ws["dmixed"], lsetot, ws["delta"], plan, ws["dqkv32"])
-            ops.cast_f32_to_f16(ws["dqkv32"], ws["dqkv16"])
+            ops.dilated_attn_bwd(qkv, ws["dmixed"], lsetot, ws["delta"], plan, ws["attn_ws"], ws["dqkv16"])
             ops.gemm_nt(ws["dqkv16"], f16[p + "qkv"].wt, dy16, M, D, 3 * D)
             ops.layernorm_bwd(dy16, hin, t[p + "self_attn_layer_norm.weight"], st1, dh, M, D, accumulate=True)
         self.tape.record(bwd)

@@ -115,9 +115,16 @@ def dilated_mix_ln_bwd(dy, o_br, lse_br, lse_tot, plan, ln_w, stats, dmixed, del
                                             _p(dmixed), _p(delta_br), _s()), "dilated_mix_ln_bwd")
 
 
-def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, dqkv):
-    check(_lib.load().mt_dilated_attn_bwd(_p(qkv), _p(dmixed), _p(lse_tot), _p(delta_br), C.byref(plan), _p(dqkv), _s()),
-          "dilated_attn_bwd")
+def dilated_attn_bwd_workspace_bytes(plan) -> int:
+    n = _lib.load().mt_dilated_attn_bwd_workspace_bytes(C.byref(plan))
+    if n < 0:
+        check(int(n), "dilated_attn_bwd_workspace_bytes")
+    return int(n)
+
+
+def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
+    check(_lib.load().mt_dilated_attn_bwd(_p(qkv), _p(dmixed), _p(lse_tot), _p(delta_br), C.byref(plan), _p(workspace),
+                                          _p(dqkv16), _s()), "dilated_attn_bwd")
 
 
 def inject_attn_fwd(q, k, v, a, M, rows_per_pass, T):
