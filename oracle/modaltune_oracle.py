@@ -93,8 +93,24 @@ def prompt_self_attention(c, pe, sd, prefix, heads):
 # ------------------------------------------------------------------------------------------------
 # Dilated attention (torchscale/component/dilated_attention.py:22-59,82-144,212-255)
 # ------------------------------------------------------------------------------------------------
+def _softmax_attention(qs, ks, vs, scale, impl):
+    """qs, ks, vs: [B, nseg, n, g, d, r] sparse sequences -> (o [B,nseg,n,g,d,r], lse [B,nseg,r,g,n]).
+    impl "explicit": materialised softmax (any dtype, differentiable; small n).  impl "flash": ATen's CPU flash kernel
+    (fp32, returns the logsumexp; used for the long sequences of the cpu_baseline timing).  Same arithmetic."""
+    if impl == "flash":
+        B, nseg, n, g, d, r = qs.shape
+        f = lambda t: t.permute(0, 1, 5, 3, 2, 4).reshape(B * nseg, r * g, n, d)       # [batch, heads, n, d]
+        o, lse = torch.ops.aten._scaled_dot_product_flash_attention_for_cpu(f(qs), f(ks), f(vs), 0.0, False, scale=scale)
+        o = o.reshape(B, nseg, r, g, n, d).permute(0, 1, 4, 3, 5, 2)
+        return o, lse.reshape(B, nseg, r, g, n)
+    sc = torch.einsum("bjqgdr,bjkgdr->bjrgqk", qs, ks) * scale
+    lse = torch.logsumexp(sc.float() if sc.dtype != torch.float64 else sc, dim=-1)        # [B,nseg,r,g,n]
+    o = torch.einsum("bjrgqk,bjkgdr->bjqgdr", torch.softmax(sc, dim=-1), vs)                # [B,nseg,n,g,d,r]
+    return o, lse
+
+
 def dilated_attention_core(q, k, v, seg_lengths: Sequence[int], ratios: Sequence[int],
-                           return_branches: bool = False):
+                           return_branches: bool = False, impl: str = "auto"):
     """q,k,v: [B, N, H, d] -> [B, N, H*d].
 
     Independent restatement: per branch, every head group r walks positions r, r+dr, ... inside each
@@ -121,9 +137,8 @@ def dilated_attention_core(q, k, v, seg_lengths: Sequence[int], ratios: Sequence
             return torch.diagonal(t, dim1=3, dim2=4)                 # [B, nseg, n, g, d, r]: pos offset == head group
 
         qs, ks, vs = sparse(q), sparse(k), sparse(v)
-        sc = torch.einsum("bjqgdr,bjkgdr->bjrgqk", qs, ks) * scale
-        lse = torch.logsumexp(sc.float() if sc.dtype != torch.float64 else sc, dim=-1)   # [B,nseg,r,g,n]
-        o = torch.einsum("bjrgqk,bjkgdr->bjqgdr", torch.softmax(sc, dim=-1), vs)           # [B,nseg,n,g,d,r]
+        use = impl if impl != "auto" else ("flash" if (n > 512 and q.dtype == torch.float32) else "explicit")
+        o, lse = _softmax_attention(qs, ks, vs, scale, use)
         # scatter back to dense [B, N, H, d]; unvisited (pos, head) -> O = 0, lse = -1e8
         od = q.new_zeros(B, nseg, n, dr, dr, g, d)
         ld = torch.full((B, nseg, n, dr, dr, g), -1e8, dtype=lse.dtype)
@@ -144,7 +159,7 @@ def dilated_attention_core(q, k, v, seg_lengths: Sequence[int], ratios: Sequence
     return out
 
 
-def encoder_layer(x, sd, prefix, seg_lengths, ratios, heads=16):
+def encoder_layer(x, sd, prefix, seg_lengths, ratios, heads=16, attn_impl="auto"):
     """EncoderLayer.forward (torchscale/architecture/encoder.py:121-175) with DilatedAttention.forward
     (dilated_attention.py:146-262) and FeedForwardNetwork.forward (feedforward_network.py:132-143);
     pre-LN (subln), alpha = 1, dropout/droppath off.  SURVEY A.4."""
@@ -153,7 +168,7 @@ def encoder_layer(x, sd, prefix, seg_lengths, ratios, heads=16):
     q = _linear(h, sd, prefix + ".self_attn.q_proj").view(B, N, heads, D // heads)
     k = _linear(h, sd, prefix + ".self_attn.k_proj").view(B, N, heads, D // heads)
     v = _linear(h, sd, prefix + ".self_attn.v_proj").view(B, N, heads, D // heads)
-    a = dilated_attention_core(q, k, v, seg_lengths, ratios)
+    a = dilated_attention_core(q, k, v, seg_lengths, ratios, impl=attn_impl)
     a = _ln(a, sd, prefix + ".self_attn.inner_attn_ln")
     x = x + _linear(a, sd, prefix + ".self_attn.out_proj")
     h = _ln(x, sd, prefix + ".final_layer_norm")

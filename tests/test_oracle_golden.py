@@ -58,6 +58,20 @@ def test_encoder_layer_and_dilated_attention(golden_dir, case):
     assert _maxrel(a, g[f"{case}_attn"]) < tol
 
 
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_flash_path_of_the_oracle_matches_reference_too(golden_dir, case):
+    """The ATen CPU-flash path (long sequences, cpu_baseline timing) is the same arithmetic: hold it to the golden."""
+    g = np.load(os.path.join(golden_dir, "unit_layer.npz"))
+    seed = int(g["seed"])
+    N, segs, ratios = unit_inputs.LAYER_CASES[case]
+    sd = _sd(_small_cfg(), synth.toy_group_sizes(), seed, torch.float32)
+    x = torch.from_numpy(unit_inputs.layer_inputs(seed, N)).float().requires_grad_(True)
+    y = O.encoder_layer(x, sd, "encoder.layers.0", segs, ratios, attn_impl="flash")
+    assert _maxrel(y.detach(), g[f"{case}_y"]) < 2e-5
+    y.sum().backward()                              # differentiable (used with backward in bench.py's cpu_baseline)
+    assert torch.isfinite(x.grad).all()
+
+
 @pytest.mark.parametrize("name", ["toy6", "g21"])
 def test_gene_encoder(golden_dir, name):
     g = np.load(os.path.join(golden_dir, "unit_gene.npz"))
