@@ -47,10 +47,27 @@ MT_DEVINL float wave_max(float v) {
   return v;
 }
 
-MT_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-level for the fp16-stored activations):
+// erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z >= 0.  About 14 VALU ops against ~40 for erff();
+// the FFN's GELU (feedforward_network.py:136) and its derivative were the VALU bound of the LN-3072 kernels.
+// Returns erf(x / sqrt 2) and e = exp(-x^2 / 2) (shared with the derivative).
+MT_DEVINL float erf_rsqrt2(float x, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float r = fmaf(-poly, e, 1.0f);
+  return copysignf(r, x);
+}
+MT_DEVINL float gelu_erf(float x) { float e; return 0.5f * x * (1.0f + erf_rsqrt2(x, e)); }
 MT_DEVINL float gelu_erf_grad(float x) {
-  const float k = 0.39894228040143267794f;  // 1/sqrt(2 pi)
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * k * __expf(-0.5f * x * x);
+  float e;
+  const float er = erf_rsqrt2(x, e);
+  return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + er));   // Phi(x) + x phi(x)
 }
 
 // 16-byte global load/store helpers

@@ -31,8 +31,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
   constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
   constexpr int MI = TM / 16, NI = TN / 16;     // 16x16 MFMA tiles per wave
   constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;  // 16-B chunks per thread per K-tile
-  __shared__ __attribute__((aligned(16))) h16 As[2][BM * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) h16 Bs[2][BN * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) h16 smem_ab[2 * BM * LDS_STRIDE + 2 * BN * LDS_STRIDE];
+  h16 (*As)[BM * LDS_STRIDE] = reinterpret_cast<h16 (*)[BM * LDS_STRIDE]>(smem_ab);
+  h16 (*Bs)[BN * LDS_STRIDE] = reinterpret_cast<h16 (*)[BN * LDS_STRIDE]>(smem_ab + 2 * BM * LDS_STRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -115,36 +116,54 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  // ---- epilogue.  The accumulators (16x16 MFMA C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg) are
+  // staged through LDS (the operand buffers are free now) so that every global access of the epilogue -- the
+  // residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B contiguous per row)
+  // instead of 32-byte fragments per store instruction.
+  constexpr int CS = BN + 4;                                   // fp32 staging row stride (floats), 16-B aligned rows
+  static_assert(BM * CS * 4 <= 2 * BM * LDS_STRIDE * 2 + 2 * BN * LDS_STRIDE * 2, "C tile must fit the operand LDS");
+  float* Cs = reinterpret_cast<float*>(smem_ab);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cs[(wm * TM + i * 16 + fq * 4 + r) * CS + wn * TN + j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
   OutT* C = reinterpret_cast<OutT*>(g.C);
+  constexpr int CPR = BN / 4;                                  // float4 chunks per tile row
+  constexpr int RPP = 256 / CPR;                               // rows per pass
+  const int cc = (tid % CPR) * 4, r0 = tid / CPR;
+  const int n = n0 + cc;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gm4 = {0.f, 0.f, 0.f, 0.f};
+  if (n < g.N) {
+    if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+    if (EPI == MT_EPI_INJECT) gm4 = *reinterpret_cast<const f32x4*>(g.colscale + n);
+  }
+#pragma unroll 4
+  for (int rr = r0; rr < BM; rr += RPP) {
+    const int m = m0 + rr;
+    if (m >= g.M || n >= g.N) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * CS + cc]);
+    v += bias4;
+    if (EPI == MT_EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+    if (EPI == MT_EPI_INJECT) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wm * TM + i * 16 + fq * 4 + r;
-      if (m >= g.M) continue;
-      const long crow = g.cmap.map(m) * g.ldc;
-      long rrow = 0;
-      if (EPI == MT_EPI_BIAS_RESID || EPI == MT_EPI_INJECT) rrow = g.rmap.map(m) * g.ldr;
-      int prow = 0, pcol = 0;
-      if (EPI == MT_EPI_POSEMB) { prow = g.pos_row[m]; pcol = g.pos_col[m]; }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * TN + j * 16 + fr;
-        if (n >= g.N) continue;
-        float v = acc[i][j][r];
-        if (g.bias) v += g.bias[n];
-        if (EPI == MT_EPI_BIAS_RESID) v += g.resid[rrow + n];
-        if (EPI == MT_EPI_INJECT) {
-          const float gm = g.colscale[n];
-          v = (1.0f + gm) * g.resid[rrow + n] + gm * v;
-        }
-        if (EPI == MT_EPI_POSEMB) {
-          const int half = g.N >> 1;   // first half encodes the grid column, second half the row (A.8)
-          v += (n < half) ? g.pos_table[(long)pcol * half + n] : g.pos_table[(long)prow * half + (n - half)];
-        }
-        C[crow + n] = (OutT)v;
-      }
+      for (int e = 0; e < 4; ++e) v[e] = (1.0f + gm4[e]) * x[e] + gm4[e] * v[e];
+    }
+    if (EPI == MT_EPI_POSEMB) {
+      const int half = g.N >> 1;   // first half encodes the grid column, second half the row (A.8)
+      const float* tab = (n < half) ? g.pos_table + (long)g.pos_col[m] * half + n : g.pos_table + (long)g.pos_row[m] * half + (n - half);
+      v += *reinterpret_cast<const f32x4*>(tab);
+    }
+    OutT* dst = C + g.cmap.map(m) * g.ldc + n;
+    if constexpr (sizeof(OutT) == 4) {
+      *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+      *reinterpret_cast<h16x4*>(dst) = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
     }
   }
 }
@@ -295,21 +314,27 @@ MT_DEVINL float apply_act(float v, int act) {
 }
 
 __global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
-  __shared__ float As[16][17], Bs[16][17];
+  constexpr int KC = 64;                       // K chunk per barrier pair (tiny GEMMs are barrier/latency bound)
+  __shared__ float As[16][KC + 1], Bs[16][KC + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, bz = blockIdx.z;
   const float* A = g.A + (long)bz * g.a_bs;
   const float* B = g.B + (long)bz * g.b_bs;
   float* C = g.C + (long)bz * g.c_bs;
+  // staging: thread -> (row = tid / 16, k = tid % 16 + 16 j), j = 0..3
+  const int sr = threadIdx.x >> 4, sk = threadIdx.x & 15;
+  const int am = m0 + sr, bn = n0 + sr;
   float acc = 0.f;
-  for (int k0 = 0; k0 < g.K; k0 += 16) {
-    const int am = m0 + ty, ak = k0 + tx;
-    As[ty][tx] = (am < g.M && ak < g.K) ? A[am * g.as0 + ak * g.as1] : 0.f;
-    const int bn = n0 + ty;
-    Bs[ty][tx] = (bn < g.N && ak < g.K) ? B[bn * g.bs0 + ak * g.bs1] : 0.f;
+  for (int k0 = 0; k0 < g.K; k0 += KC) {
+#pragma unroll
+    for (int j = 0; j < KC / 16; ++j) {
+      const int kk = k0 + sk + 16 * j;
+      As[sr][sk + 16 * j] = (am < g.M && kk < g.K) ? A[am * g.as0 + kk * g.as1] : 0.f;
+      Bs[sr][sk + 16 * j] = (bn < g.N && kk < g.K) ? B[bn * g.bs0 + kk * g.bs1] : 0.f;
+    }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
+    for (int k = 0; k < KC; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
     __syncthreads();
   }
   const int m = m0 + ty, n = n0 + tx;
@@ -327,8 +352,9 @@ extern "C" int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, 
                               int epilogue, const MtGemmEpilogue* epi, void* C, long ldc, const MtRowMap* cmap,
                               int out_dtype, mt_stream_t stream) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return MT_ERR_BAD_ARG;
-  if (K % BK != 0 || lda % 8 != 0 || (N % 64) != 0) return MT_ERR_BAD_ARG;
-  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return MT_ERR_BAD_ARG;
+  if (K % BK != 0 || lda % 8 != 0 || (N % 64) != 0 || (ldc % 4) != 0) return MT_ERR_BAD_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7)) return MT_ERR_BAD_ARG;
+  if (epi && epi->resid && (((uintptr_t)epi->resid & 15) || (epi->ldr % 4))) return MT_ERR_BAD_ARG;
   GemmNtArgs a;
   a.A = (const h16*)A; a.lda = lda; a.amap = make_rowmap(amap);
   a.W = (const h16*)W; a.M = M; a.N = N; a.K = K;
