@@ -44,7 +44,9 @@ const char* mt_status_string(int status);
 enum { MT_EPI_BIAS = 0,        /* C = acc + bias                                   (nn.Linear)            */
        MT_EPI_BIAS_RESID = 1,  /* C = resid + acc + bias                           (ENC:149-154,169-172)  */
        MT_EPI_INJECT = 2,      /* C = (1+g[n]) * resid + g[n] * (acc + bias)       (AM:231,362; A.1)      */
-       MT_EPI_POSEMB = 3 };    /* C = acc + bias + sincos(col|row)                 (LVA:232-237)          */
+       MT_EPI_POSEMB = 3,      /* C = acc + bias + sincos(col|row)                 (LVA:232-237)          */
+       MT_EPI_QKV_HM = 4 };    /* C = acc + bias, written head-major [N/48][M][48] (fp16): the q|k|v layout the
+                                  dilated-attention kernels read (DA:169-175 "b l (h d) -> (b h) l d")          */
 enum { MT_OUT_F16 = 0, MT_OUT_F32 = 1 };
 
 typedef struct {
@@ -112,7 +114,7 @@ typedef struct {
   int n[MT_MAX_BRANCHES];             /* sparse length ceil(s / r) incl. zero padding DA:22-37  */
 } MtDilatedPlan;
 
-/* qkv: fp16 [B*N, 3*768] (q | k | v, 16 heads x 48 each).  For every branch, every (segment, head):
+/* qkv: fp16 HEAD-MAJOR [3][16][B*N][48] (q | k | v; MT_EPI_QKV_HM writes it).  For every branch, every (segment, head):
  * O_b = softmax(Q K^T / sqrt(48)) V over the head's dilated positions, zero-padded rows acting as keys with
  * logit 0 / value 0 (DA:98-101,24-28).  o_br: fp16 [nbranch][B*N, 768]; lse_br: fp32 [nbranch][B*N, 16]
  * (natural log).  (position, head) pairs a branch does not visit are left untouched.  DA:212-253, MHA:109-119. */
@@ -126,7 +128,7 @@ int mt_dilated_mix_ln_fwd(const mt_half* o_br, const float* lse_br, const MtDila
                           const float* ln_b, mt_half* y, float* stats, float* lse_tot, mt_stream_t stream);
 
 /* Backward of mix + inner_attn_ln: given dy (fp16, gradient wrt the LN output) recomputes mixed, writes
- * dmixed fp16 [B*N,768] and delta_br[b][row][head] = sum_d dmixed * O_b (fp32). */
+ * dmixed fp16 HEAD-MAJOR [16][B*N][48] and delta_br[b][row][head] = sum_d dmixed * O_b (fp32). */
 int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, const float* lse_br, const float* lse_tot,
                           const MtDilatedPlan* plan, const float* ln_w, const float* stats, mt_half* dmixed,
                           float* delta_br, mt_stream_t stream);

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_C", "libmodaltune_hip.so")
+LIB_PATH = os.environ.get("MODALTUNE_HIP_LIB", os.path.join(_HERE, "_C", "libmodaltune_hip.so"))   # override: diagnostic builds
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 

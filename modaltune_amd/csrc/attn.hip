@@ -12,6 +12,7 @@
 //   S^T[key, q] = K . Q^T           v_mfma_f32_32x32x16_f16, K rows from LDS (ds_read_b128), Q^T in registers
 //   O^T[d, q]  += V^T[d, key] . P^T  P^T taken straight from the S accumulators (no LDS round trip),
 //                                    V^T via ds_read_b64_tr_b16; V carries a ones column so O^T row 48 = sum(P)
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -124,6 +125,11 @@ struct Seq {
   MT_DEVINL long row_clamped(int i) const { return min(row(i), row_base + (long)N - 1); }
 };
 
+// q / k / v are HEAD-MAJOR: [which = q|k|v][head][B*N rows][48] (written that way by the QKV GEMM epilogue), so a
+// head's dilated key walk touches rows 96 * r bytes apart (contiguous for r = 1) instead of 4608 * r in the
+// token-major [B*N, 2304] layout; dmixed is head-major too ([head][B*N][48]).
+MT_DEVINL const h16* hm_ptr(const h16* base, long M, int slab, long row) { return base + ((long)slab * M + row) * HD; }
+
 MT_DEVINL h16x8 sel8(bool ok, h16x8 v) {
   const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
   return ok ? v : z;
@@ -158,6 +164,12 @@ struct StageIdx {
 // tile t follow.  K and V ring through two LDS buffers each (K one tile ahead of V), one barrier per tile;
 // global loads for K(t+2) / V(t+1) are issued at the top of the tile and first touched at its end.
 // ------------------------------------------------------------------------------------------------
+#ifdef MT_DIAG
+#define DIAG_V(v) (VARIANT == (v))
+template <int VARIANT>
+#else
+#define DIAG_V(v) false
+#endif
 __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __restrict__ qkv, Plan p, h16* __restrict__ o_br,
                                                                float* __restrict__ lse_br) {
   __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   h16x8 qf[3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
-    qf[ks] = sel8(qvalid, ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8));
+    qf[ks] = sel8(qvalid, ldg8(hm_ptr(qkv, M, w.h, qrow) + ks * 16 + hh * 8));
 
   const StageIdx st(tid);
   const int ntile = (sq.n + 63) / 64;
@@ -193,14 +205,14 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   // unconditional loads (clamped rows); padded rows are zeroed by a select when the tile is written to LDS
   auto gload_k = [&](int kb) {
     const int i0 = kb + st.row0, i1 = kb + st.row1;
-    rk0 = ldg8(qkv + sq.row_clamped(i0) * QKV_LD + DM + w.h * HD + st.part0 * 8);
-    rk1 = ldg8(qkv + sq.row_clamped(i1) * QKV_LD + DM + w.h * HD + st.part1 * 8);
+    rk0 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
+    rk1 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
     kok0 = sq.valid(i0); kok1 = sq.valid(i1);
   };
   auto gload_v = [&](int kb) {
     const int i0 = kb + st.row0, i1 = kb + st.row1;
-    rv0 = ldg8(qkv + sq.row_clamped(i0) * QKV_LD + 2 * DM + w.h * HD + st.part0 * 8);
-    rv1 = ldg8(qkv + sq.row_clamped(i1) * QKV_LD + 2 * DM + w.h * HD + st.part1 * 8);
+    rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
+    rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
     vok0 = sq.valid(i0); vok1 = sq.valid(i1);
   };
   auto lstore_k = [&](int buf) {
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   auto tile = [&](int t, auto last_tag, auto tail_tag) {
     constexpr bool LAST = decltype(last_tag)::value, TAIL = decltype(tail_tag)::value;
     const int kb = t * 64;
-    if (!LAST) {
+    if (!LAST && !DIAG_V(1)) {
       gload_v(kb + 64);                       // V(t+1)
       if (t + 2 < ntile) gload_k(kb + 128);   // K(t+2)
     }
@@ -271,14 +283,22 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       m_run = m_new;
     }
     const float mc = m_run * c;
-    if (!LAST) qk((t + 1) & 1, s_nxt);        // S(t+1): MFMAs overlap the exp2 work below
+    if (!LAST) {
+      if (DIAG_V(4)) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s_nxt[sub][i] = s_cur[sub][i] * 0.999f;
+      } else qk((t + 1) & 1, s_nxt);        // S(t+1): MFMAs overlap the exp2 work below
+    }
     h16x8 pf[2][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[sub][s2][e] = (h16)__builtin_amdgcn_exp2f(fmaf(s_cur[sub][8 * s2 + e], c, -mc));
+        for (int e = 0; e < 8; ++e)
+          pf[sub][s2][e] = DIAG_V(2) ? (h16)fmaf(s_cur[sub][8 * s2 + e], c, -mc) : (h16)__builtin_amdgcn_exp2f(fmaf(s_cur[sub][8 * s2 + e], c, -mc));
     // O^T += V^T . P^T ; A fragment element e of lane half hh = V[key 16 s2 + 8 (e>>2) + 4 hh + (e&3)][d = lane & 31]
     const int vbuf = t & 1;
 #pragma unroll
@@ -288,13 +308,17 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
         const h16* vrow = &Vs[vbuf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
         const h16x8 v0 = cat8(lds_tr4(vrow), lds_tr4(vrow + 8 * VSTR));
         const h16x8 v1 = cat8(lds_tr4(vrow + 32), lds_tr4(vrow + 8 * VSTR + 32));
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[sub][s2], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[sub][s2], o1, 0, 0, 0);
+        if (DIAG_V(3)) {
+          asm volatile("" :: "v"(pf[sub][s2]), "v"(v0), "v"(v1));
+        } else {
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[sub][s2], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[sub][s2], o1, 0, 0, 0);
+        }
       }
     if (!LAST) {
       lstore_v((t + 1) & 1);                  // V(t+1) -> the buffer V(t-1) lived in
       if (t + 2 < ntile) lstore_k(t & 1);     // K(t+2) -> the buffer K(t) lived in (S(t) is already in registers)
-      __syncthreads();
+      if (!DIAG_V(5)) __syncthreads();
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) s_cur[sub] = s_nxt[sub];
     }
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
     }
     const float c1 = wave_sum(s1) * (1.0f / DM), c2 = wave_sum(s2) * (1.0f / DM);
     float dm[12];
-    h16* dst = dmixed + m * DM + c0;
+    h16* dst = dmixed + ((long)h * M + m) * HD + (c0 - h * HD);      // head-major [head][B*N][48]
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       h16x4 o;
@@ -496,8 +520,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   h16x8 qf[3], dof[3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
-    qf[ks] = sel8(qvalid, ldg8(qkv + qrow * QKV_LD + w.h * HD + ks * 16 + hh * 8));
-    dof[ks] = sel8(qvalid, ldg8(dmixed + qrow * DM + w.h * HD + ks * 16 + hh * 8));
+    qf[ks] = sel8(qvalid, ldg8(hm_ptr(qkv, M, w.h, qrow) + ks * 16 + hh * 8));
+    dof[ks] = sel8(qvalid, ldg8(hm_ptr(dmixed, M, w.h, qrow) + ks * 16 + hh * 8));
   }
   // invalid queries: L2 = +big -> P~ = 0
   const float L2raw = lse_tot[qrow * H + w.h], dlraw = delta_br[((long)w.br * M + qrow) * H + w.h];
@@ -509,9 +533,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   bool ok0 = false, ok1 = false;
   auto gload = [&](int kb) {      // unconditional loads, first touched in lstore() (latency hides under the MFMAs)
     const int i0 = kb + st.row0, i1 = kb + st.row1;
-    const h16* b0 = qkv + sq.row_clamped(i0) * QKV_LD + w.h * HD + st.part0 * 8;
-    const h16* b1 = qkv + sq.row_clamped(i1) * QKV_LD + w.h * HD + st.part1 * 8;
-    rk0 = ldg8(b0 + DM); rv0 = ldg8(b0 + 2 * DM); rk1 = ldg8(b1 + DM); rv1 = ldg8(b1 + 2 * DM);
+    const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1);
+    rk0 = ldg8(hm_ptr(qkv, M, H + w.h, r0) + st.part0 * 8); rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r0) + st.part0 * 8);
+    rk1 = ldg8(hm_ptr(qkv, M, H + w.h, r1) + st.part1 * 8); rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r1) + st.part1 * 8);
     ok0 = sq.valid(i0); ok1 = sq.valid(i1);
   };
   auto lstore = [&](int buf) {
@@ -628,8 +652,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   h16x8 kf[3], vf[3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
-    kf[ks] = sel8(kvalid, ldg8(qkv + krow * QKV_LD + DM + w.h * HD + ks * 16 + hh * 8));
-    vf[ks] = sel8(kvalid, ldg8(qkv + krow * QKV_LD + 2 * DM + w.h * HD + ks * 16 + hh * 8));
+    kf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, H + w.h, krow) + ks * 16 + hh * 8));
+    vf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, 2 * H + w.h, krow) + ks * 16 + hh * 8));
   }
 
   const StageIdx st(tid);
@@ -639,8 +663,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   auto gload = [&](int qb) {      // unconditional loads, first touched in lstore()
     const int i0 = qb + st.row0, i1 = qb + st.row1, i2 = qb + (tid & 63);
     const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1), r2 = sq.row_clamped(i2);
-    rq0 = ldg8(qkv + r0 * QKV_LD + w.h * HD + st.part0 * 8); rd0 = ldg8(dmixed + r0 * DM + w.h * HD + st.part0 * 8);
-    rq1 = ldg8(qkv + r1 * QKV_LD + w.h * HD + st.part1 * 8); rd1 = ldg8(dmixed + r1 * DM + w.h * HD + st.part1 * 8);
+    rq0 = ldg8(hm_ptr(qkv, M, w.h, r0) + st.part0 * 8); rd0 = ldg8(hm_ptr(dmixed, M, w.h, r0) + st.part0 * 8);
+    rq1 = ldg8(hm_ptr(qkv, M, w.h, r1) + st.part1 * 8); rd1 = ldg8(hm_ptr(dmixed, M, w.h, r1) + st.part1 * 8);
     rl2 = lse_tot[r2 * H + w.h]; rdl = delta_br[((long)w.br * M + r2) * H + w.h];
     ok0 = sq.valid(i0); ok1 = sq.valid(i1); ok2 = sq.valid(i2);
   };
@@ -777,8 +801,15 @@ extern "C" int mt_dilated_attn_fwd(const mt_half* qkv, const MtDilatedPlan* plan
   if (!qkv || !o_br || !lse_br || !plan_ok(plan)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
   const int nblk = p.blk_off[p.nbranch];
+#ifdef MT_DIAG
+  const char* ev = getenv("MT_DIAG_VARIANT");
+  const int variant = ev ? atoi(ev) : 0;
+#define MT_LAUNCH_V(v) case v: hipLaunchKernelGGL(dilated_attn_fwd_kernel<v>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv, p, (h16*)o_br, lse_br); break;
+  switch (variant) { MT_LAUNCH_V(0) MT_LAUNCH_V(1) MT_LAUNCH_V(2) MT_LAUNCH_V(3) MT_LAUNCH_V(4) MT_LAUNCH_V(5) default: return MT_ERR_BAD_ARG; }
+#else
   hipLaunchKernelGGL(dilated_attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv, p,
                      (h16*)o_br, lse_br);
+#endif
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
       v += *reinterpret_cast<const f32x4*>(tab);
     }
     OutT* dst = C + g.cmap.map(m) * g.ldc + n;
+    if (EPI == MT_EPI_QKV_HM)     // [q|k|v][head][M][48]: column n -> slab n / 48, offset n % 48 (4 | 48: chunks never straddle)
+      dst = C + ((long)(n / 48) * g.M + m) * 48 + (n % 48);
     if constexpr (sizeof(OutT) == 4) {
       *reinterpret_cast<f32x4*>(dst) = v;
     } else {
@@ -379,6 +381,9 @@ extern "C" int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, 
     case MT_EPI_POSEMB:
       if (!a.pos_table || !a.pos_row || !a.pos_col || !f32) return MT_ERR_BAD_ARG;
       return launch_nt_bn<MT_EPI_POSEMB, float>(a, s);
+    case MT_EPI_QKV_HM:
+      if (f32 || (N % 48) != 0 || cmap) return MT_ERR_BAD_ARG;
+      return launch_nt_bn<MT_EPI_QKV_HM, h16>(a, s);
     default:
       return MT_ERR_BAD_ARG;
   }

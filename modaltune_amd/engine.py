@@ -459,7 +459,7 @@ class Engine:
         st1, stin, st2, stf = ws[f"st1_{l}"], ws[f"stin_{l}"], ws[f"st2_{l}"], ws[f"stf_{l}"]
         u16, t16 = ws["u16"], ws["t16"]
         ops.layernorm_fwd(hin, t[p + "self_attn_layer_norm.weight"], t[p + "self_attn_layer_norm.bias"], u16, st1, M, D)
-        ops.gemm_nt(u16, f16[p + "qkv"].w, qkv, M, 3 * D, D, bias=f16[p + "bqkv"])
+        ops.gemm_nt(u16, f16[p + "qkv"].w, qkv, M, 3 * D, D, bias=f16[p + "bqkv"], epilogue=ops.EPI_QKV_HM)   # head-major q|k|v
         ops.dilated_attn_fwd(qkv, plan, obr, lsebr)
         ops.dilated_mix_ln_fwd(obr, lsebr, plan, t[p + "self_attn.inner_attn_ln.weight"], t[p + "self_attn.inner_attn_ln.bias"],
                                u16, stin, lsetot)

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import MtDilatedPlan, MtGemmEpilogue, MtRowMap, check, rowmap
 
 F16, F32 = 0, 1
-EPI_BIAS, EPI_BIAS_RESID, EPI_INJECT, EPI_POSEMB = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_RESID, EPI_INJECT, EPI_POSEMB, EPI_QKV_HM = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU = 0, 1, 2, 3
 
 

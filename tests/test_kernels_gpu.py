@@ -94,6 +94,19 @@ def test_gemm_nt_rowmaps_resid_inject_posemb(ops):
     assert rel(out2, ref2) < 2e-5
 
 
+def test_gemm_nt_head_major_qkv_epilogue(ops):
+    g = rng(19)
+    M, N, K = 333, 2304, 768
+    A = torch.randn(M, K, generator=g).half()
+    W = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g)
+    out = torch.zeros(3 * 16 * M * 48, dtype=torch.float16, device=DEV)
+    ops.gemm_nt(A.to(DEV), W.to(DEV), out, M, N, K, bias=bias.to(DEV), epilogue=ops.EPI_QKV_HM)
+    torch.cuda.synchronize()
+    ref = (A.double() @ W.double().t() + bias.double()).view(M, 3, 16, 48).permute(1, 2, 0, 3)
+    assert rel(out.view(3, 16, M, 48), ref) < 2e-3
+
+
 @pytest.mark.parametrize("M,N1,N2", [(1000, 192, 768), (4097, 64, 64), (333, 384, 768), (9000, 768, 192)])
 def test_gemm_tn_and_colsum(ops, M, N1, N2):
     g = rng(M)
@@ -204,6 +217,17 @@ def test_layernorm_gelu_f16_and_accumulate(ops):
 
 
 # ------------------------------------------------------------------------------------------ dilated attention
+def _hm(qkv_tok):
+    """token-major [M, 2304] (q|k|v, head h at 48h) -> head-major [3][16][M][48] as the kernels read it."""
+    M = qkv_tok.shape[0]
+    return qkv_tok.view(M, 3, 16, 48).permute(1, 2, 0, 3).contiguous()
+
+
+def _hm_inv(dm_hm, M):
+    """head-major [16][M][48] -> token-major [M, 768]."""
+    return dm_hm.view(16, M, 48).permute(1, 0, 2).reshape(M, 768)
+
+
 def _attn_case(case, B=2):
     N, segs, ratios = unit_inputs.LAYER_CASES[case]
     return N, segs, ratios
@@ -234,7 +258,7 @@ def test_dilated_attention_fwd_mix_vs_reference_golden(ops, golden_dir, case):
     nb = len(bt)
     o_br = torch.zeros(nb, M, 768, dtype=torch.float16, device=DEV)
     lse_br = torch.zeros(nb, M, 16, device=DEV)
-    ops.dilated_attn_fwd(qkv16.to(DEV).view(M, 2304), plan, o_br, lse_br)
+    ops.dilated_attn_fwd(_hm(qkv16.to(DEV).view(M, 2304)), plan, o_br, lse_br)
     ln_w = torch.ones(768, device=DEV)
     ln_b = torch.zeros(768, device=DEV)
     y = torch.zeros(M, 768, dtype=torch.float16, device=DEV)
@@ -279,7 +303,7 @@ def test_dilated_attention_deferred_rescale_branch(ops):
     M = B * N
     o_br = torch.zeros(5, M, 768, dtype=torch.float16, device=DEV)
     lse_br = torch.zeros(5, M, 16, device=DEV)
-    ops.dilated_attn_fwd(qkv.to(DEV).view(M, 2304), plan, o_br, lse_br)
+    ops.dilated_attn_fwd(_hm(qkv.to(DEV).view(M, 2304)), plan, o_br, lse_br)
     torch.cuda.synchronize()
     qd, kd, vd = (t.view(B, N, 16, 48) for t in qkv.double().split(768, dim=-1))
     _, outs, lses = O.dilated_attention_core(qd, kd, vd, segs, ratios, return_branches=True)
@@ -313,7 +337,7 @@ def test_dilated_attention_bwd_vs_oracle_autograd(ops, golden_dir, case):
     yref = torch.nn.functional.layer_norm(mixed, (768,), ln_w.double(), ln_b.double(), 1e-5)
     yref.backward(dy.double())
     # HIP
-    qkv_d = qkv16.to(DEV).view(M, 2304)
+    qkv_d = _hm(qkv16.to(DEV).view(M, 2304))
     o_br = torch.zeros(nb, M, 768, dtype=torch.float16, device=DEV)
     lse_br = torch.zeros(nb, M, 16, device=DEV)
     ops.dilated_attn_fwd(qkv_d, plan, o_br, lse_br)

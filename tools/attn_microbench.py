@@ -13,7 +13,7 @@ M = B * N
 bt = branch_table(N, segment_lengths())
 plan = ops.make_plan(bt, N, B)
 g = torch.Generator(device="cuda").manual_seed(0)
-qkv = (torch.randn(M, 2304, device="cuda", generator=g) * 0.8).half()
+qkv = (torch.randn(M, 2304, device="cuda", generator=g) * 0.8).half()   # (any layout: random data)
 o_br = torch.zeros(5, M, 768, dtype=torch.float16, device="cuda")
 lse_br = torch.zeros(5, M, 16, device="cuda")
 ops.dilated_attn_fwd(qkv, plan, o_br, lse_br)
