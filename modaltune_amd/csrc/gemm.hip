@@ -5,15 +5,14 @@
 //   colsum  : out[N]  += sum_m A[m,N]              bias gradients
 //   sgemm_small : strided fp32 GEMM for the token-side (T <= 66 rows) ops
 //
-// gemm_nt structure: 128 x BN x 64 tiles, 4 waves, v_mfma_f32_16x16x32_f16, register-staged double-buffered
-// LDS (issue the next tile's global loads before the MFMAs, write them to the other buffer after: one barrier
-// per K-tile), LDS rows padded to 144 B so the ds_read_b128 fragment reads are bank-conflict free.
+// gemm_nt structure: 128 x BN x 64 tiles, 4 waves, v_mfma_f32_16x16x32_f16, double-buffered LDS filled by LDS-DMA
+// (global_load_lds_dwordx4, issued for tile t+1 before the MFMAs of tile t; one barrier per K-tile), XOR-swizzled
+// 128-B rows so the ds_read_b128 fragment reads are bank-conflict free.
 #include "common.h"
 
 namespace {
 
 constexpr int BK = 64;
-constexpr int LDS_STRIDE = 72;  // halves per LDS row (64 + 8 pad = 144 B: conflict-free ds_read_b128)
 
 struct GemmNtArgs {
   const h16* A; long lda; RowMap amap;
@@ -26,14 +25,22 @@ struct GemmNtArgs {
   void* C; long ldc; RowMap cmap;
 };
 
+// LDS-DMA staging (global_load_lds_dwordx4): each wave-instruction drops 64 x 16 B = 1 KiB = 8 tile rows of 128 B
+// straight into LDS, no staging VGPRs and no ds_write pass.  The DMA destination is lane-linear, so the
+// bank-conflict fix is an XOR swizzle applied on the per-lane SOURCE address and again on the fragment reads
+// (guide rule 21): the 16-B chunk c of tile row r lives at chunk position c ^ (r & 7); with it the 16-lane groups
+// of ds_read_b128 hit 16 distinct 16-B slots.
 template <int BM, int BN, int WM, int WN, int EPI, typename OutT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
   constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
   constexpr int MI = TM / 16, NI = TN / 16;     // 16x16 MFMA tiles per wave
   constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;  // 16-B chunks per thread per K-tile
-  __shared__ __attribute__((aligned(16))) h16 smem_ab[2 * BM * LDS_STRIDE + 2 * BN * LDS_STRIDE];
-  h16 (*As)[BM * LDS_STRIDE] = reinterpret_cast<h16 (*)[BM * LDS_STRIDE]>(smem_ab);
-  h16 (*Bs)[BN * LDS_STRIDE] = reinterpret_cast<h16 (*)[BN * LDS_STRIDE]>(smem_ab + 2 * BM * LDS_STRIDE);
+  constexpr int CS = BN + 4;                    // fp32 epilogue staging stride (floats)
+  constexpr int EROWS = (BM * CS * 4 <= 2 * (BM + BN) * BK * 2) ? BM : BM / 2;   // epilogue rows per pass
+  static_assert(EROWS * CS * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the operand LDS");
+  __shared__ __attribute__((aligned(16))) h16 smem[2 * (BM + BN) * BK];
+  h16* const As0 = smem;
+  h16* const Bs0 = smem + 2 * BM * BK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -48,20 +55,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
   }
   const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
 
+  // per-thread DMA sources: chunk id c = i * 256 + tid -> tile row c >> 3, physical chunk c & 7, logical chunk
+  // (c & 7) ^ (row & 7); rows past the edge are clamped (their products are never stored)
+  const int srow = tid >> 3, lchunk = (tid & 7) ^ (srow & 7);
   const h16* aptr[ACH];
   const h16* bptr[BCH];
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
-    int c = tid + i * 256, row = c >> 3, kc = c & 7;
-    int m = min(m0 + row, g.M - 1);
-    aptr[i] = g.A + g.amap.map(m) * g.lda + kc * 8;
+    const int m = min(m0 + i * 32 + srow, g.M - 1);
+    aptr[i] = g.A + g.amap.map(m) * g.lda + lchunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < BCH; ++i) {
-    int c = tid + i * 256, row = c >> 3, kc = c & 7;
-    int n = min(n0 + row, g.N - 1);
-    bptr[i] = g.W + (long)n * g.K + kc * 8;
+    const int n = min(n0 + i * 32 + srow, g.N - 1);
+    bptr[i] = g.W + (long)n * g.K + lchunk * 8;
   }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < ACH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(As0 + buf * BM * BK + (i * 256 + wave * 64) * 8), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BCH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bptr[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(Bs0 + buf * BN * BK + (i * 256 + wave * 64) * 8), 16, 0, 0);
+  };
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -69,69 +87,37 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  h16x8 ra[ACH], rb[BCH];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < ACH; ++i) ra[i] = ldg8(aptr[i] + k0);
-#pragma unroll
-    for (int i = 0; i < BCH; ++i) rb[i] = ldg8(bptr[i] + k0);
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-      int c = tid + i * 256, row = c >> 3, kc = c & 7;
-      *reinterpret_cast<h16x8*>(&As[buf][row * LDS_STRIDE + kc * 8]) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BCH; ++i) {
-      int c = tid + i * 256, row = c >> 3, kc = c & 7;
-      *reinterpret_cast<h16x8*>(&Bs[buf][row * LDS_STRIDE + kc * 8]) = rb[i];
-    }
-  };
-
   const int nk = g.K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
+  const int sw = fr & 7;                         // row & 7 of every fragment row this lane reads
+  stage(0, 0);
+  __syncthreads();                               // (hipcc drains the LDS-DMA with vmcnt(0) before the barrier)
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nk) gload((t + 1) * BK);
+    if (t + 1 < nk) stage(buf ^ 1, (t + 1) * BK);
+    const h16* As = As0 + buf * BM * BK;
+    const h16* Bs = Bs0 + buf * BN * BK;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
+      const int pc = ((kk * 4 + fq) ^ sw) * 8;
       h16x8 af[MI], bf[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[i] = *reinterpret_cast<const h16x8*>(&As[buf][(wm * TM + i * 16 + fr) * LDS_STRIDE + kk * 32 + fq * 8]);
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const h16x8*>(&As[(wm * TM + i * 16 + fr) * BK + pc]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        bf[j] = *reinterpret_cast<const h16x8*>(&Bs[buf][(wn * TN + j * 16 + fr) * LDS_STRIDE + kk * 32 + fq * 8]);
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const h16x8*>(&Bs[(wn * TN + j * 16 + fr) * BK + pc]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue.  The accumulators (16x16 MFMA C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg) are
   // staged through LDS (the operand buffers are free now) so that every global access of the epilogue -- the
-  // residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B contiguous per row)
-  // instead of 32-byte fragments per store instruction.
-  constexpr int CS = BN + 4;                                   // fp32 staging row stride (floats), 16-B aligned rows
-  static_assert(BM * CS * 4 <= 2 * BM * LDS_STRIDE * 2 + 2 * BN * LDS_STRIDE * 2, "C tile must fit the operand LDS");
-  float* Cs = reinterpret_cast<float*>(smem_ab);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cs[(wm * TM + i * 16 + fq * 4 + r) * CS + wn * TN + j * 16 + fr] = acc[i][j][r];
-  __syncthreads();
+  // residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B contiguous per row).
+  float* Cs = reinterpret_cast<float*>(smem);
   OutT* C = reinterpret_cast<OutT*>(g.C);
   constexpr int CPR = BN / 4;                                  // float4 chunks per tile row
   constexpr int RPP = 256 / CPR;                               // rows per pass
@@ -142,30 +128,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
     if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
     if (EPI == MT_EPI_INJECT) gm4 = *reinterpret_cast<const f32x4*>(g.colscale + n);
   }
-#pragma unroll 4
-  for (int rr = r0; rr < BM; rr += RPP) {
-    const int m = m0 + rr;
-    if (m >= g.M || n >= g.N) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * CS + cc]);
-    v += bias4;
-    if (EPI == MT_EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
-    if (EPI == MT_EPI_INJECT) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (1.0f + gm4[e]) * x[e] + gm4[e] * v[e];
-    }
-    if (EPI == MT_EPI_POSEMB) {
-      const int half = g.N >> 1;   // first half encodes the grid column, second half the row (A.8)
-      const float* tab = (n < half) ? g.pos_table + (long)g.pos_col[m] * half + n : g.pos_table + (long)g.pos_row[m] * half + (n - half);
-      v += *reinterpret_cast<const f32x4*>(tab);
-    }
-    OutT* dst = C + g.cmap.map(m) * g.ldc + n;
-    if (EPI == MT_EPI_QKV_HM)     // [q|k|v][head][M][48]: column n -> slab n / 48, offset n % 48 (4 | 48: chunks never straddle)
-      dst = C + ((long)(n / 48) * g.M + m) * 48 + (n % 48);
-    if constexpr (sizeof(OutT) == 4) {
-      *reinterpret_cast<f32x4*>(dst) = v;
-    } else {
-      *reinterpret_cast<h16x4*>(dst) = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+  for (int pass = 0; pass < BM / EROWS; ++pass) {
+    const int rbase = pass * EROWS;
+    if (pass > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * TM + i * 16 + fq * 4 + r - rbase;
+        if (row >= 0 && row < EROWS) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j) Cs[row * CS + wn * TN + j * 16 + fr] = acc[i][j][r];
+        }
+      }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = r0; rr < EROWS; rr += RPP) {
+      const int m = m0 + rbase + rr;
+      if (m >= g.M || n >= g.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * CS + cc]);
+      v += bias4;
+      if (EPI == MT_EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+      if (EPI == MT_EPI_INJECT) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (1.0f + gm4[e]) * x[e] + gm4[e] * v[e];
+      }
+      if (EPI == MT_EPI_POSEMB) {
+        const int half = g.N >> 1;   // first half encodes the grid column, second half the row (A.8)
+        const float* tab = (n < half) ? g.pos_table + (long)g.pos_col[m] * half + n : g.pos_table + (long)g.pos_row[m] * half + (n - half);
+        v += *reinterpret_cast<const f32x4*>(tab);
+      }
+      OutT* dst = C + g.cmap.map(m) * g.ldc + n;
+      if (EPI == MT_EPI_QKV_HM)     // [q|k|v][head][M][48]: column n -> slab n / 48, offset n % 48 (4 | 48: chunks never straddle)
+        dst = C + ((long)(n / 48) * g.M + m) * 48 + (n % 48);
+      if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        *reinterpret_cast<h16x4*>(dst) = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+      }
     }
   }
 }
