@@ -61,19 +61,20 @@ __global__ __launch_bounds__(256) void inject_attn_fwd_kernel(const h16* __restr
 }
 
 // backward: workgroup = 128 rows x one head.  Phase 1 (thread = row): recompute p, dp = da . v, delta, ds and
-// dq; stage p / ds in LDS.  Phase 2 (thread = (token, dim)): dk[t,d] = sum_rows ds q, dv[t,d] = sum_rows p da,
-// one atomic per (token, dim) per workgroup.
+// dq; stage p / ds (fp16) in LDS.  Phase 2 (thread = (token, dim)): dk[t,d] = sum_rows ds q, dv[t,d] = sum_rows p da,
+// one atomic per (token, dim) per workgroup.  LDS is sized by the actual T (about 52 KB at T = 65: 3 workgroups/CU).
 constexpr int IBR = 128;
 __global__ __launch_bounds__(IBR) void inject_attn_bwd_kernel(const h16* __restrict__ q, const h16* __restrict__ da, int rows_per_pass,
                                                               const float* __restrict__ k, const float* __restrict__ v, int T,
                                                               h16* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int TP = T + 2;                   // h16 row stride of the p / ds images (odd dword stride: no bank conflicts)
   float* ks = smem;                       // [T][16]
-  float* vs = ks + TMAX * AD;             // [T][16]
-  float* qs = vs + TMAX * AD;             // [IBR][17]
+  float* vs = ks + T * AD;                // [T][16]
+  float* qs = vs + T * AD;                // [IBR][17]
   float* das = qs + IBR * 17;             // [IBR][17]
-  float* ps = das + IBR * 17;             // [IBR][T+1]
-  float* dss = ps + IBR * (T + 1);        // [IBR][T+1]
+  h16* ps = reinterpret_cast<h16*>(das + IBR * 17);   // [IBR][TP]
+  h16* dss = ps + IBR * TP;               // [IBR][TP]
   const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   for (int i = tid; i < T * AD; i += IBR) {
     const int t = i / AD, d = i % AD;
@@ -85,42 +86,43 @@ __global__ __launch_bounds__(IBR) void inject_attn_bwd_kernel(const h16* __restr
   const bool valid = r < rows_per_pass;
   const long m = (long)b * rows_per_pass + (valid ? r : 0);
   float qv[AD], dav[AD];
-  if (valid) { load16(q + m * AE + h * AD, qv); load16(da + m * AE + h * AD, dav); }
-  else {
+  load16(q + m * AE + h * AD, qv);
+  load16(da + m * AE + h * AD, dav);
+  if (!valid) {
 #pragma unroll
     for (int d = 0; d < AD; ++d) { qv[d] = 0.f; dav[d] = 0.f; }
   }
 #pragma unroll
   for (int d = 0; d < AD; ++d) { qs[tid * 17 + d] = qv[d]; das[tid * 17 + d] = dav[d]; }
-  // pass 1: max and sum
+  // pass 1: row maximum; pass 2: normaliser and delta = sum_t p_t dp_t
   float mx = -1.0e30f;
   for (int t = 0; t < T; ++t) {
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[t * AD + d], s);
-    s *= ASCALE;
-    ps[tid * (T + 1) + t] = s;
-    mx = fmaxf(mx, s);
+    mx = fmaxf(mx, s * ASCALE);
   }
-  float l = 0.f;
-  for (int t = 0; t < T; ++t) { const float p = __expf(ps[tid * (T + 1) + t] - mx); ps[tid * (T + 1) + t] = p; l += p; }
-  const float inv = 1.0f / l;
-  float delta = 0.f;
+  float l = 0.f, dsum = 0.f;
   for (int t = 0; t < T; ++t) {
-    const float p = ps[tid * (T + 1) + t] * inv;
-    float dp = 0.f;
+    float s = 0.f, dp = 0.f;
 #pragma unroll
-    for (int d = 0; d < AD; ++d) dp = fmaf(dav[d], vs[t * AD + d], dp);
-    ps[tid * (T + 1) + t] = valid ? p : 0.f;
-    dss[tid * (T + 1) + t] = dp;
-    delta = fmaf(p, dp, delta);
+    for (int d = 0; d < AD; ++d) { s = fmaf(qv[d], ks[t * AD + d], s); dp = fmaf(dav[d], vs[t * AD + d], dp); }
+    const float p = __expf(s * ASCALE - mx);
+    l += p;
+    dsum = fmaf(p, dp, dsum);
   }
+  const float inv = 1.0f / l, delta = dsum * inv;
   float dqv[AD];
 #pragma unroll
   for (int d = 0; d < AD; ++d) dqv[d] = 0.f;
   for (int t = 0; t < T; ++t) {
-    const float ds = valid ? ps[tid * (T + 1) + t] * (dss[tid * (T + 1) + t] - delta) * ASCALE : 0.f;
-    dss[tid * (T + 1) + t] = ds;
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < AD; ++d) { s = fmaf(qv[d], ks[t * AD + d], s); dp = fmaf(dav[d], vs[t * AD + d], dp); }
+    const float p = valid ? __expf(s * ASCALE - mx) * inv : 0.f;
+    const float ds = p * (dp - delta) * ASCALE;
+    ps[tid * TP + t] = (h16)p;
+    dss[tid * TP + t] = (h16)ds;
 #pragma unroll
     for (int d = 0; d < AD; ++d) dqv[d] = fmaf(ds, ks[t * AD + d], dqv[d]);
   }
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(IBR) void inject_attn_bwd_kernel(const h16* __restr
     const int t = i / AD, d = i % AD;
     float sk = 0.f, sv = 0.f;
     for (int rr = 0; rr < IBR; ++rr) {
-      sk = fmaf(dss[rr * (T + 1) + t], qs[rr * 17 + d], sk);
-      sv = fmaf(ps[rr * (T + 1) + t], das[rr * 17 + d], sv);
+      sk = fmaf((float)dss[rr * TP + t], qs[rr * 17 + d], sk);
+      sv = fmaf((float)ps[rr * TP + t], das[rr * 17 + d], sv);
     }
     atomicAdd(&dk[((long)b * T + t) * AE + h * AD + d], sk);
     atomicAdd(&dv[((long)b * T + t) * AE + h * AD + d], sv);
@@ -386,7 +388,7 @@ extern "C" int mt_inject_attn_bwd(const mt_half* q, const mt_half* da, int M, in
   if (!q || !da || !k || !v || !dq || !dk || !dv || M <= 0 || rows_per_pass <= 0 || M % rows_per_pass || T < 1 || T > TMAX)
     return MT_ERR_BAD_ARG;
   const int B = M / rows_per_pass;
-  const size_t shm = sizeof(float) * (2 * TMAX * AD + 2 * IBR * 17 + 2 * IBR * (T + 1));
+  const size_t shm = sizeof(float) * (2 * T * AD + 2 * IBR * 17) + sizeof(h16) * 2 * IBR * (T + 2);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)inject_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

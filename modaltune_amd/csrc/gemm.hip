@@ -318,25 +318,33 @@ MT_DEVINL float apply_act(float v, int act) {
 }
 
 __global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
-  constexpr int KC = 64;                       // K chunk per barrier pair (tiny GEMMs are barrier/latency bound)
+  constexpr int KC = 64;                       // K chunk per barrier pair
   __shared__ float As[16][KC + 1], Bs[16][KC + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, bz = blockIdx.z;
   const float* A = g.A + (long)bz * g.a_bs;
   const float* B = g.B + (long)bz * g.b_bs;
   float* C = g.C + (long)bz * g.c_bs;
-  // staging: thread -> (row = tid / 16, k = tid % 16 + 16 j), j = 0..3
+  // staging: thread -> (row = tid / 16, k = tid % 16 + 16 j), j = 0..3; the next chunk is prefetched into registers
+  // while the current one is consumed (these GEMMs are latency-bound: one global round trip per chunk otherwise)
   const int sr = threadIdx.x >> 4, sk = threadIdx.x & 15;
   const int am = m0 + sr, bn = n0 + sr;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < g.K; k0 += KC) {
+  float ra[KC / 16], rb[KC / 16];
+  auto gload = [&](int k0) {
 #pragma unroll
     for (int j = 0; j < KC / 16; ++j) {
       const int kk = k0 + sk + 16 * j;
-      As[sr][sk + 16 * j] = (am < g.M && kk < g.K) ? A[am * g.as0 + kk * g.as1] : 0.f;
-      Bs[sr][sk + 16 * j] = (bn < g.N && kk < g.K) ? B[bn * g.bs0 + kk * g.bs1] : 0.f;
+      ra[j] = (am < g.M && kk < g.K) ? A[am * g.as0 + kk * g.as1] : 0.f;
+      rb[j] = (bn < g.N && kk < g.K) ? B[bn * g.bs0 + kk * g.bs1] : 0.f;
     }
+  };
+  float acc = 0.f;
+  gload(0);
+  for (int k0 = 0; k0 < g.K; k0 += KC) {
+#pragma unroll
+    for (int j = 0; j < KC / 16; ++j) { As[sr][sk + 16 * j] = ra[j]; Bs[sr][sk + 16 * j] = rb[j]; }
     __syncthreads();
+    if (k0 + KC < g.K) gload(k0 + KC);
 #pragma unroll
     for (int k = 0; k < KC; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
     __syncthreads();

@@ -391,7 +391,7 @@ def test_inject_attention(ops, T):
     torch.cuda.synchronize()
     assert rel(a.view(B, L, 192), ref) < 2e-3
     assert rel(dq.view(B, L, 192), qd.grad) < 3e-3
-    assert rel(dk, kd.grad) < 1e-4 and rel(dv, vd.grad) < 1e-4
+    assert rel(dk, kd.grad) < 1e-3 and rel(dv, vd.grad) < 1e-3      # p / ds are staged as fp16 for the token-side reduction
 
 
 @pytest.mark.parametrize("T,L,nsplit", [(65, 700, 4), (7, 129, 1), (66, 1000, 16)])
