@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--pathways", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-times", action="store_true", help="print the per-kernel time table (stderr)")
+    ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,10 +92,13 @@ def main():
         slides.append((torch.from_numpy(inp["x"]).to(dev).half().reshape(L, -1).contiguous(), inp["coords"],
                        [torch.from_numpy(a).to(dev) for a in inp["genes"]], torch.from_numpy(inp["text"]).to(dev)))
 
-    def run(n):
+    def run(n, graphed=True):
         for i in range(n):
             x, coords, genes, text = slides[i % 2]
-            ts.step(x, coords, genes, text, update=True)
+            if graphed and not args.eager:
+                ts.step_graphed(x, coords, genes, text)      # hipGraph replay (2 eager warm-ups + capture happen in warm-up)
+            else:
+                ts.step(x, coords, genes, text, update=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -102,20 +106,25 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
+    run(max(args.warmup, 3))          # >= 3: two eager steps + the capture step of the graph path
     barrier()
-    ops.TIMER = {}
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    loss = float(ts.loss)
+    # per-kernel durations: HIP events on the launch stream around every launch of an eager, instrumented pass of the
+    # same step (events cannot be recorded inside a replayed graph); not part of the timed region above
+    prof_steps = min(args.steps, 3)
+    ops.TIMER = {}
+    run(prof_steps, graphed=False)
+    barrier()
     timer, ops.TIMER = ops.TIMER, None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
-    loss = float(ts.loss)
-    skipped = args.warmup + args.steps - int(ts.step_dev)
+    skipped = max(args.warmup, 3) + args.steps + prof_steps - int(ts.step_dev)
 
     if rank == 0:
         T = cfg.num_tokens
@@ -125,7 +134,7 @@ def main():
         tot_ms = sum(v[1] for v in summ.values())
         if args.kernel_times:
             for k, (n, ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
-                print(f"  {k:28s} launches/step {n / args.steps:7.1f}  ms/step {ms / args.steps:9.3f}  ({100 * ms / tot_ms:5.1f} %)",
+                print(f"  {k:28s} launches/step {n / prof_steps:7.1f}  ms/step {ms / prof_steps:9.3f}  ({100 * ms / tot_ms:5.1f} %)",
                       file=sys.stderr)
         # roofline of the dominant kernel: dilated attention forward (one launch per layer per step)
         n_l, ms = summ["dilated_attn_fwd"]
@@ -142,8 +151,10 @@ def main():
             "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / world / 1e12 / PEAK_F16_MFMA_TFLOPS,
             "roofline": {"kernel": "dilated_attn_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-                         "avg_launch_ms": ms / n_l, "flops_per_launch": launch_flops},
-            "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]},
+                         "avg_launch_ms": ms / n_l, "flops_per_launch": launch_flops,
+                         "measured": f"HIP events around each launch, eager instrumented pass of {prof_steps} steps after the timed region"},
+            "launch": "eager" if args.eager else "hipGraph replay",
+            "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(cfg, sizes, L, seed=0)

@@ -217,17 +217,21 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, coords, genes: Sequence[torch.Tensor], task_onehots: torch.Tensor,
-                need_grad: bool = True, fresh: bool = False) -> torch.Tensor:
+                need_grad: bool = True, fresh: bool = False, staged: bool = False, geometry=None) -> torch.Tensor:
         """x [L, in_chans] (or [1,L,in]); coords [L,2] (host or device); genes: list of [1, n_i]; task_onehots [B, num_tasks].
         Returns logits [B, output_dim] (fp32, device).  fresh=True gives this call its own tape and workspace so that
         several forwards can precede one backward (the reference calls the model 3x before loss.backward(), TM:175-177);
-        `self.last_call` is the handle `backward(..., call=)` takes."""
+        `self.last_call` is the handle `backward(..., call=)` takes.  staged=True: x / coords were already uploaded with
+        stage_inputs() into this geometry's workspace (hipGraph replay path: no host work inside the step)."""
         cfg, dev, t = self.cfg, self.device, self.store.tensors
         if not self._caches_ready:
             self._build_caches()
-        x = x.reshape(-1, x.shape[-1])
-        L = x.shape[0]
-        B = task_onehots.shape[0]
+        if staged:
+            B, L = geometry
+        else:
+            x = x.reshape(-1, x.shape[-1])
+            L = x.shape[0]
+            B = task_onehots.shape[0]
         N, D, Fd, E, T = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim, self.T
         M, Mp = B * N, B * L
         ws = self._workspace(B, L, fresh=fresh)
@@ -244,16 +248,8 @@ class Engine:
         self._ctx["patch_map"] = patch_map
 
         # ---- patch embedding + positional table + cls (LVA:232-242); shared by the B passes
-        coords_np = coords.detach().cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords)
-        prow, pcol = coords_to_rowcol(coords_np.reshape(-1, 2), float(cfg.tile_size))
-        if int(prow.max()) >= cfg.slide_ngrids or int(pcol.max()) >= cfg.slide_ngrids or int(min(prow.min(), pcol.min())) < 0:
-            raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid")
-        ws["prow"].copy_(torch.from_numpy(prow.astype(np.int32)))
-        ws["pcol"].copy_(torch.from_numpy(pcol.astype(np.int32)))
-        if x.dtype == H16:
-            ws["x16"].copy_(x)
-        else:
-            ops.cast_f32_to_f16(x.to(dev, F32).contiguous(), ws["x16"])
+        if not staged:
+            self.stage_inputs(x, coords, ws)
         ops.gemm_nt(ws["x16"], self._frozen16["patch"].w, ws["x0"], L, D, cfg.in_chans, epilogue=ops.EPI_POSEMB,
                     bias=t["patch_embed.proj.bias"], pos_table=self.pos_table, pos_row=ws["prow"], pos_col=ws["pcol"])
 
@@ -292,6 +288,25 @@ class Engine:
         self._logits = logits
         self.last_call = (tape, logits)
         return logits.data
+
+    def stage_inputs(self, x: torch.Tensor, coords, ws: Optional[Dict[str, torch.Tensor]] = None, B: Optional[int] = None):
+        """Host side of the input boundary: grid indices from coords (slide_encoder.py:198-211) and the fp16 copy of the
+        patch embeddings, written into the workspace's static buffers."""
+        cfg = self.cfg
+        x = x.reshape(-1, x.shape[-1])
+        L = x.shape[0]
+        if ws is None:
+            ws = self._workspace(B, L)
+        coords_np = coords.detach().cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords)
+        prow, pcol = coords_to_rowcol(coords_np.reshape(-1, 2), float(cfg.tile_size))
+        if int(prow.max()) >= cfg.slide_ngrids or int(pcol.max()) >= cfg.slide_ngrids or int(min(prow.min(), pcol.min())) < 0:
+            raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid")
+        ws["prow"].copy_(torch.from_numpy(prow.astype(np.int32)))
+        ws["pcol"].copy_(torch.from_numpy(pcol.astype(np.int32)))
+        if x.dtype == H16:
+            ws["x16"].copy_(x)
+        else:
+            ops.cast_f32_to_f16(x.to(self.device, F32).contiguous(), ws["x16"])
 
     # ------------------------------------------------------------------ token-side pieces
     def _gene_encoder(self, genes: Sequence[torch.Tensor]) -> Var:

@@ -80,15 +80,75 @@ class TrainStep:
             self.optimizer_step()
         return self.loss
 
-    def optimizer_step(self):
+    # ------------------------------------------------------------------ hipGraph replay of the whole step
+    def step_graphed(self, x, coords, genes, text) -> torch.Tensor:
+        """Same arithmetic as step(), replayed from a captured hipGraph: the ~900 kernel launches of a step are
+        recorded once (after two eager warm-up steps) and replayed with one host call; inputs are uploaded into static
+        buffers first.  With world_size > 1 the forward+backward graph and the optimiser graph are separate and the
+        gradient all-reduce runs between them."""
         eng = self.engine
-        world = dp.allreduce_sum_(eng.store.flat_grad, self.pg)      # sum over ranks; mean folded into AdamW
+        x = x.reshape(-1, x.shape[-1])
+        L = x.shape[0]
+        B = self.onehots.shape[0]
+        key = (L, tuple(int(g.numel()) for g in genes))
+        if getattr(self, "_gkey", None) != key:
+            self._gkey, self._graphs, self._gwarm = key, None, 0
+            self._sgenes = [torch.empty(1, int(g.numel()), dtype=F32, device=self.dev) for g in genes]
+            self._stext = torch.empty(tuple(text.shape), dtype=F32, device=self.dev)
+        eng.stage_inputs(x, coords, B=B)
+        for dst, g in zip(self._sgenes, genes):
+            dst.copy_(g.reshape(1, -1))
+        self._stext.copy_(text)
+        world = torch.distributed.get_world_size(self.pg) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+
+        def fwd_bwd():
+            target = self.project_text(self._stext)
+            eng.store.flat_grad.zero_()
+            logits = eng.forward(None, None, self._sgenes, self.onehots, need_grad=True, staged=True, geometry=(B, L))
+            self.last_logits = logits
+            R, O = logits.shape
+            dlogits = torch.empty_like(logits)
+            ops.distill_loss(logits, target, self.loss, dlogits, R, O, 1.0, self.scale)
+            eng.backward(dlogits)
+
+        if self._graphs is None and self._gwarm < 2:          # eager warm-up (allocator, lazy kernel attributes)
+            fwd_bwd()
+            self.optimizer_step()
+            self._gwarm += 1
+            return self.loss
+        if self._graphs is None:
+            torch.cuda.synchronize()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            if world == 1:
+                with torch.cuda.graph(g1):
+                    fwd_bwd()
+                    self.optimizer_step()
+                self._graphs = (g1, None)
+            else:
+                with torch.cuda.graph(g1):
+                    fwd_bwd()
+                with torch.cuda.graph(g2):
+                    self._adam_and_refresh(world)
+                self._graphs = (g1, g2)
+        g1, g2 = self._graphs
+        g1.replay()
+        if g2 is not None:
+            dp.allreduce_sum_(eng.store.flat_grad, self.pg)
+            g2.replay()
+        return self.loss
+
+    def _adam_and_refresh(self, world: int):
+        eng = self.engine
         n = eng.store.n_flat
         ops.check_finite(eng.store.flat_grad, n, self.found_inf)
         ops.adamw_step(eng.store.flat, eng.store.flat_grad, self.m, self.v, n, self.lr, self.betas[0], self.betas[1], self.eps,
                        self.wd, 0, scale=self.scale, found_inf=self.found_inf, grad_mult=1.0 / world, step_dev=self.step_dev)
         ops.scaler_update(self.scale, self.tracker, self.found_inf, self.step_dev, 2.0, 0.5, self.growth_interval)
         eng.refresh_trainable_caches()
+
+    def optimizer_step(self):
+        world = dp.allreduce_sum_(self.engine.store.flat_grad, self.pg)      # sum over ranks; mean folded into AdamW
+        self._adam_and_refresh(world)
 
     def unscaled_grads(self) -> Dict[str, torch.Tensor]:
         s = float(self.scale)
