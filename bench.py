@@ -70,7 +70,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     from modaltune_amd import ops, synth
@@ -106,7 +106,16 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run(max(args.warmup, 3))          # >= 3: two eager steps + the capture step of the graph path
+    try:
+        run(max(args.warmup, 3))      # >= 3: two eager steps + the capture step of the graph path
+    except Exception as e:            # graph capture unavailable -> same arithmetic with eager launches
+        if args.eager or world > 1:   # (with several ranks a one-sided fallback would desynchronise the collectives)
+            raise
+        print(f"[bench] hipGraph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+        args.eager = True
+        ts._graphs, ts._gwarm, ts._gkey = None, 0, None
+        torch.cuda.synchronize()
+        run(max(args.warmup, 3))
     barrier()
     t0 = time.perf_counter()
     run(args.steps)

@@ -120,14 +120,14 @@ class TrainStep:
             torch.cuda.synchronize()
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             if world == 1:
-                with torch.cuda.graph(g1):
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                     fwd_bwd()
                     self.optimizer_step()
                 self._graphs = (g1, None)
-            else:
-                with torch.cuda.graph(g1):
+            else:       # (thread_local: RCCL's watchdog thread must not invalidate the capture)
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                     fwd_bwd()
-                with torch.cuda.graph(g2):
+                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._adam_and_refresh(world)
                 self._graphs = (g1, g2)
         g1, g2 = self._graphs
