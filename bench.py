@@ -145,9 +145,12 @@ def main():
             for k, (n, ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
                 print(f"  {k:28s} launches/step {n / prof_steps:7.1f}  ms/step {ms / prof_steps:9.3f}  ({100 * ms / tot_ms:5.1f} %)",
                       file=sys.stderr)
-        # roofline of the dominant kernel: dilated attention forward (one launch per layer per step)
-        n_l, ms = summ["dilated_attn_fwd"]
-        launch_flops = 3 * fl["attn_layer"]                    # B = 3 task passes in one launch
+        # roofline of the dominant kernel (largest share of the step): the dK/dV kernel of the dilated-attention backward,
+        # one launch per layer per step over all 5 branches and all 3 task passes.  Algorithmic FLOPs per launch: the four
+        # products it owns (S = Q K^T, dP = dO V^T, dV = P^T dO, dK = dS^T Q) = 2 x the forward's two products
+        # (SURVEY §8d counts the whole flash backward as 2.5 x forward; the dQ kernel carries the remaining 0.5 x).
+        n_l, ms = summ["dilated_attn_bwd_kv"]
+        launch_flops = 2.0 * 3 * fl["attn_layer"]
         achieved = launch_flops / (ms / n_l * 1e-3) / 1e12
         out = {
             "metric": "slides/sec (train step) at 10k patches x 1536-d", "value": value, "unit": "slides/s",
@@ -158,7 +161,7 @@ def main():
                                    f"1 slide per GPU per step", "patches": L, "tokens": T, "parallelism": f"dp{world}"},
             "loss": loss, "skipped_steps": skipped,
             "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / world / 1e12 / PEAK_F16_MFMA_TFLOPS,
-            "roofline": {"kernel": "dilated_attn_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS,
+            "roofline": {"kernel": "dilated_attn_bwd_kv_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
                          "avg_launch_ms": ms / n_l, "flops_per_launch": launch_flops,
                          "measured": f"HIP events around each launch, eager instrumented pass of {prof_steps} steps after the timed region"},

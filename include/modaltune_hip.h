@@ -139,8 +139,9 @@ int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, const float* l
  * per-branch result once into `workspace` (fp32, mt_dilated_attn_bwd_workspace_bytes) and a combine kernel sums the
  * branches that visit a (position, head) into the dense fp16 gradient: no atomics, bitwise reproducible. */
 long mt_dilated_attn_bwd_workspace_bytes(const MtDilatedPlan* plan);
+enum { MT_ATTN_BWD_KV = 1, MT_ATTN_BWD_Q = 2, MT_ATTN_BWD_COMBINE = 4, MT_ATTN_BWD_ALL = 7 };   /* `phases` mask */
 int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot, const float* delta_br,
-                        const MtDilatedPlan* plan, float* workspace, mt_half* dqkv, mt_stream_t stream);
+                        const MtDilatedPlan* plan, float* workspace, mt_half* dqkv, int phases, mt_stream_t stream);
 
 /* ------------------------------------------------------------ adapter ops -------------------------- */
 /* Injector attention core (AM:225-229 inside AM:359-369): for each of M patch rows and 12 heads (dim 16):

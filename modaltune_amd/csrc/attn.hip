@@ -846,18 +846,21 @@ extern "C" long mt_dilated_attn_bwd_workspace_bytes(const MtDilatedPlan* plan) {
 
 extern "C" int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot,
                                    const float* delta_br, const MtDilatedPlan* plan, float* workspace, mt_half* dqkv,
-                                   mt_stream_t stream) {
-  if (!qkv || !dmixed || !lse_tot || !delta_br || !workspace || !dqkv || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+                                   int phases, mt_stream_t stream) {
+  if (!qkv || !dmixed || !lse_tot || !delta_br || !workspace || !dqkv || !plan_ok(plan) || !(phases & 7)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
   const int nblk = p.blk_off[p.nbranch];
   hipStream_t s = (hipStream_t)stream;
   // every (branch, position, head) slot of the workspace is written exactly once by each of the two kernels
-  hipLaunchKernelGGL(dilated_attn_bwd_kv_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
-                     delta_br, p, workspace);
-  hipLaunchKernelGGL(dilated_attn_bwd_q_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
-                     delta_br, p, workspace);
+  if (phases & MT_ATTN_BWD_KV)
+    hipLaunchKernelGGL(dilated_attn_bwd_kv_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
+                       delta_br, p, workspace);
+  if (phases & MT_ATTN_BWD_Q)
+    hipLaunchKernelGGL(dilated_attn_bwd_q_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
+                       delta_br, p, workspace);
   const long M = (long)p.B * p.N;
-  hipLaunchKernelGGL(dilated_attn_bwd_combine_kernel, dim3((int)min(M, 16384L)), dim3(192), 0, s, workspace, p, (h16*)dqkv);
+  if (phases & MT_ATTN_BWD_COMBINE)
+    hipLaunchKernelGGL(dilated_attn_bwd_combine_kernel, dim3((int)min(M, 16384L)), dim3(192), 0, s, workspace, p, (h16*)dqkv);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -122,9 +122,23 @@ def dilated_attn_bwd_workspace_bytes(plan) -> int:
     return int(n)
 
 
-def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
+ATTN_BWD_KV, ATTN_BWD_Q, ATTN_BWD_COMBINE, ATTN_BWD_ALL = 1, 2, 4, 7
+
+
+def _dilated_attn_bwd_phase(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16, phases):
     check(_lib.load().mt_dilated_attn_bwd(_p(qkv), _p(dmixed), _p(lse_tot), _p(delta_br), C.byref(plan), _p(workspace),
-                                          _p(dqkv16), _s()), "dilated_attn_bwd")
+                                          _p(dqkv16), phases, _s()), "dilated_attn_bwd")
+
+
+def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
+    if TIMER is None:
+        return _dilated_attn_bwd_phase(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16, ATTN_BWD_ALL)
+    for name, ph in (("dilated_attn_bwd_kv", ATTN_BWD_KV), ("dilated_attn_bwd_q", ATTN_BWD_Q), ("dilated_attn_bwd_combine", ATTN_BWD_COMBINE)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _dilated_attn_bwd_phase(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16, ph)
+        e1.record()
+        TIMER.setdefault(name, []).append((e0, e1))
 
 
 def inject_attn_fwd(q, k, v, a, M, rows_per_pass, T):
@@ -243,7 +257,6 @@ def _timed(name_fn):
 gemm_nt = _timed(lambda A, W, out, M, N, K, **k: f"gemm_nt[{N}x{K}]")(gemm_nt)
 gemm_tn = _timed(lambda A, B, out, M, N1, N2, **k: f"gemm_tn[{N1}x{N2}]")(gemm_tn)
 dilated_attn_fwd = _timed(lambda *a, **k: "dilated_attn_fwd")(dilated_attn_fwd)
-dilated_attn_bwd = _timed(lambda *a, **k: "dilated_attn_bwd")(dilated_attn_bwd)
 dilated_mix_ln_fwd = _timed(lambda *a, **k: "dilated_mix_ln_fwd")(dilated_mix_ln_fwd)
 dilated_mix_ln_bwd = _timed(lambda *a, **k: "dilated_mix_ln_bwd")(dilated_mix_ln_bwd)
 layernorm_fwd = _timed(lambda x, w, b, y, stats, M, D, **k: f"layernorm_fwd[{D}]" if M > 1024 else "token_side")(layernorm_fwd)
