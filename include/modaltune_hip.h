@@ -136,12 +136,12 @@ int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, const float* l
 /* Flash-style backward of all branches: dqkv fp16 [B*N, 2304] (overwritten) from qkv, dmixed, lse_tot, delta_br.
  * P~ = exp(s - lse_tot) (= w_b P_b), dS = P~ (dmixed V^T - delta_b), dQ = dS K, dK = dS^T Q, dV = P~^T dmixed.
  * Two launches cover all branches (a dK/dV kernel with key = lane, a dQ kernel with query = lane); each writes its
- * per-branch result once into `workspace` (fp32, mt_dilated_attn_bwd_workspace_bytes) and a combine kernel sums the
+ * per-branch result once into `workspace` (fp16, mt_dilated_attn_bwd_workspace_bytes) and a combine kernel sums the
  * branches that visit a (position, head) into the dense fp16 gradient: no atomics, bitwise reproducible. */
 long mt_dilated_attn_bwd_workspace_bytes(const MtDilatedPlan* plan);
 enum { MT_ATTN_BWD_KV = 1, MT_ATTN_BWD_Q = 2, MT_ATTN_BWD_COMBINE = 4, MT_ATTN_BWD_ALL = 7 };   /* `phases` mask */
 int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot, const float* delta_br,
-                        const MtDilatedPlan* plan, float* workspace, mt_half* dqkv, int phases, mt_stream_t stream);
+                        const MtDilatedPlan* plan, void* workspace, mt_half* dqkv, int phases, mt_stream_t stream);
 
 /* ------------------------------------------------------------ adapter ops -------------------------- */
 /* Injector attention core (AM:225-229 inside AM:359-369): for each of M patch rows and 12 heads (dim 16):

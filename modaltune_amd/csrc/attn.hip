@@ -30,7 +30,7 @@ struct Plan {
   int nbranch, N, B;
   int seg[MT_MAX_BRANCHES], ratio[MT_MAX_BRANCHES], nseg[MT_MAX_BRANCHES], n[MT_MAX_BRANCHES];
   int order[MT_MAX_BRANCHES], qtiles[MT_MAX_BRANCHES], blk_off[MT_MAX_BRANCHES + 1];
-  long ws_off[MT_MAX_BRANCHES + 1];   // backward workspace: per-branch compact [pass][seg][head][i][q|k|v][48] fp32
+  long ws_off[MT_MAX_BRANCHES + 1];   // backward workspace: per-branch compact [pass][seg][head][i][q|k|v][48] fp16
 };
 
 Plan make_plan(const MtDilatedPlan* p, int qtile) {
@@ -135,7 +135,7 @@ MT_DEVINL h16x8 sel8(bool ok, h16x8 v) {
   return ok ? v : z;
 }
 
-// backward workspace slot of sparse entry i of work item w: 3 x 48 floats (dq | dk | dv)
+// backward workspace slot of sparse entry i of work item w: 3 x 48 halves (dq | dk | dv)
 MT_DEVINL long ws_slot(const Plan& p, const WorkItem& w, int i) {
   return p.ws_off[w.br] + ((((long)w.b * p.nseg[w.br] + w.j) * H + w.h) * p.n[w.br] + i) * (3 * HD);
 }
@@ -159,10 +159,10 @@ struct StageIdx {
 };
 
 // ------------------------------------------------------------------------------------------------
-// forward.  Software-pipelined across key tiles inside each wave: while the softmax of tile t runs on the VALU
-// (exp2 dominates at head dim 48), the S^T = K.Q^T MFMAs of tile t+1 are already in flight, and the P.V MFMAs of
-// tile t follow.  K and V ring through two LDS buffers each (K one tile ahead of V), one barrier per tile;
-// global loads for K(t+2) / V(t+1) are issued at the top of the tile and first touched at its end.
+// forward.  K and V tiles are double-buffered in LDS, one barrier per tile; the global loads of tile t+1 are issued
+// at the top of tile t and first touched at its end.  (A variant software-pipelined across tiles inside each wave --
+// S^T of tile t+1 in flight during the softmax of tile t -- measured 5 % slower: it needs 185 VGPRs = 2 waves/SIMD
+// against 142 = 3 waves/SIMD here, and these kernels are latency-bound, not pipe-bound.)
 // ------------------------------------------------------------------------------------------------
 #ifdef MT_DIAG
 #define DIAG_V(v) (VARIANT == (v))
@@ -241,25 +241,19 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
   float m_run = NEG_BIG;      // running row maximum of the RAW logits q.k (scale c folded into the exp2 argument)
 
-  // prologue: K(0), V(0) -> LDS; K(1) in flight; S(0)
+  // prologue: tile 0 -> LDS
   gload_k(0); gload_v(0);
   lstore_k(0); lstore_v(0);
-  if (ntile > 1) gload_k(64);
-  __syncthreads();
-  f32x16 s_cur[2], s_nxt[2];
-  qk(0, s_cur);
-  if (ntile > 1) lstore_k(1);
   __syncthreads();
 
   // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   auto tile = [&](int t, auto last_tag, auto tail_tag) {
     constexpr bool LAST = decltype(last_tag)::value, TAIL = decltype(tail_tag)::value;
-    const int kb = t * 64;
-    if (!LAST && !DIAG_V(1)) {
-      gload_v(kb + 64);                       // V(t+1)
-      if (t + 2 < ntile) gload_k(kb + 128);   // K(t+2)
-    }
+    const int kb = t * 64, buf = t & 1;
+    if (!LAST) { gload_k(kb + 64); gload_v(kb + 64); }
+    f32x16 s_cur[2];
+    qk(buf, s_cur);
     // keys >= n are tile padding (excluded, last tile only); zero-padded keys keep logit 0 (DA:98-101)
     float mx = NEG_BIG;
 #pragma unroll
@@ -283,44 +277,23 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       m_run = m_new;
     }
     const float mc = m_run * c;
-    if (!LAST) {
-      if (DIAG_V(4)) {
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) s_nxt[sub][i] = s_cur[sub][i] * 0.999f;
-      } else qk((t + 1) & 1, s_nxt);        // S(t+1): MFMAs overlap the exp2 work below
-    }
-    h16x8 pf[2][2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          pf[sub][s2][e] = DIAG_V(2) ? (h16)fmaf(s_cur[sub][8 * s2 + e], c, -mc) : (h16)__builtin_amdgcn_exp2f(fmaf(s_cur[sub][8 * s2 + e], c, -mc));
     // O^T += V^T . P^T ; A fragment element e of lane half hh = V[key 16 s2 + 8 (e>>2) + 4 hh + (e&3)][d = lane & 31]
-    const int vbuf = t & 1;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const h16* vrow = &Vs[vbuf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
+        h16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (h16)__builtin_amdgcn_exp2f(fmaf(s_cur[sub][8 * s2 + e], c, -mc));
+        const h16* vrow = &Vs[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
         const h16x8 v0 = cat8(lds_tr4(vrow), lds_tr4(vrow + 8 * VSTR));
         const h16x8 v1 = cat8(lds_tr4(vrow + 32), lds_tr4(vrow + 8 * VSTR + 32));
-        if (DIAG_V(3)) {
-          asm volatile("" :: "v"(pf[sub][s2]), "v"(v0), "v"(v1));
-        } else {
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[sub][s2], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[sub][s2], o1, 0, 0, 0);
-        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf, o1, 0, 0, 0);
       }
     if (!LAST) {
-      lstore_v((t + 1) & 1);                  // V(t+1) -> the buffer V(t-1) lived in
-      if (t + 2 < ntile) lstore_k(t & 1);     // K(t+2) -> the buffer K(t) lived in (S(t) is already in registers)
-      if (!DIAG_V(5)) __syncthreads();
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) s_cur[sub] = s_nxt[sub];
+      lstore_k(buf ^ 1); lstore_v(buf ^ 1);
+      __syncthreads();
     }
   };
   for (int t = 0; t < ntile - 1; ++t) tile(t, std::false_type{}, std::false_type{});
@@ -496,7 +469,7 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                  const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
-                                                                 Plan p, float* __restrict__ ws) {
+                                                                 Plan p, h16* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];   // row-read layout
   __shared__ __attribute__((aligned(16))) h16 Kt[2][64 * VSTR];   // transposed-read layout
   __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * KSTR];
@@ -601,16 +574,16 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < ntile) tile(ntile - 1, std::true_type{});
   if (qvalid) {
-    float* out = ws + ws_slot(p, w, iq);
+    h16* out = ws + ws_slot(p, w, iq);
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      const f32x4 v = {dq0[4 * gq], dq0[4 * gq + 1], dq0[4 * gq + 2], dq0[4 * gq + 3]};
-      *reinterpret_cast<f32x4*>(out + 8 * gq + 4 * hh) = v;
+      const h16x4 v = {(h16)dq0[4 * gq], (h16)dq0[4 * gq + 1], (h16)dq0[4 * gq + 2], (h16)dq0[4 * gq + 3]};
+      *reinterpret_cast<h16x4*>(out + 8 * gq + 4 * hh) = v;
     }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
-      const f32x4 v = {dq1[4 * gq], dq1[4 * gq + 1], dq1[4 * gq + 2], dq1[4 * gq + 3]};
-      *reinterpret_cast<f32x4*>(out + 32 + 8 * gq + 4 * hh) = v;
+      const h16x4 v = {(h16)dq1[4 * gq], (h16)dq1[4 * gq + 1], (h16)dq1[4 * gq + 2], (h16)dq1[4 * gq + 3]};
+      *reinterpret_cast<h16x4*>(out + 32 + 8 * gq + 4 * hh) = v;
     }
   }
 }
@@ -625,7 +598,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
-                                                                  Plan p, float* __restrict__ ws) {
+                                                                  Plan p, h16* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) h16 Qs[64 * KSTR];
   __shared__ __attribute__((aligned(16))) h16 Qt[64 * VSTR];
   __shared__ __attribute__((aligned(16))) h16 Ds[64 * KSTR];
@@ -739,28 +712,28 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     }
   }
   if (kvalid) {
-    float* outk = ws + ws_slot(p, w, ik) + HD;
-    float* outv = outk + HD;
+    h16* outk = ws + ws_slot(p, w, ik) + HD;
+    h16* outv = outk + HD;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      const f32x4 a = {dk0[4 * gq], dk0[4 * gq + 1], dk0[4 * gq + 2], dk0[4 * gq + 3]};
-      const f32x4 b = {dv0[4 * gq], dv0[4 * gq + 1], dv0[4 * gq + 2], dv0[4 * gq + 3]};
-      *reinterpret_cast<f32x4*>(outk + 8 * gq + 4 * hh) = a;
-      *reinterpret_cast<f32x4*>(outv + 8 * gq + 4 * hh) = b;
+      const h16x4 a = {(h16)dk0[4 * gq], (h16)dk0[4 * gq + 1], (h16)dk0[4 * gq + 2], (h16)dk0[4 * gq + 3]};
+      const h16x4 b = {(h16)dv0[4 * gq], (h16)dv0[4 * gq + 1], (h16)dv0[4 * gq + 2], (h16)dv0[4 * gq + 3]};
+      *reinterpret_cast<h16x4*>(outk + 8 * gq + 4 * hh) = a;
+      *reinterpret_cast<h16x4*>(outv + 8 * gq + 4 * hh) = b;
     }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
-      const f32x4 a = {dk1[4 * gq], dk1[4 * gq + 1], dk1[4 * gq + 2], dk1[4 * gq + 3]};
-      const f32x4 b = {dv1[4 * gq], dv1[4 * gq + 1], dv1[4 * gq + 2], dv1[4 * gq + 3]};
-      *reinterpret_cast<f32x4*>(outk + 32 + 8 * gq + 4 * hh) = a;
-      *reinterpret_cast<f32x4*>(outv + 32 + 8 * gq + 4 * hh) = b;
+      const h16x4 a = {(h16)dk1[4 * gq], (h16)dk1[4 * gq + 1], (h16)dk1[4 * gq + 2], (h16)dk1[4 * gq + 3]};
+      const h16x4 b = {(h16)dv1[4 * gq], (h16)dv1[4 * gq + 1], (h16)dv1[4 * gq + 2], (h16)dv1[4 * gq + 3]};
+      *reinterpret_cast<h16x4*>(outk + 32 + 8 * gq + 4 * hh) = a;
+      *reinterpret_cast<h16x4*>(outv + 32 + 8 * gq + 4 * hh) = b;
     }
   }
 }
 
 // Sum the per-branch compact gradients into the dense fp16 dqkv [B*N, 2304] that feeds the dX GEMM.
 // 192 threads per token row: thread -> 12 consecutive columns of one (q|k|v, head).
-__global__ __launch_bounds__(192) void dilated_attn_bwd_combine_kernel(const float* __restrict__ ws, Plan p, h16* __restrict__ dqkv) {
+__global__ __launch_bounds__(192) void dilated_attn_bwd_combine_kernel(const h16* __restrict__ ws, Plan p, h16* __restrict__ dqkv) {
   const long M = (long)p.B * p.N;
   const int t = threadIdx.x;
   const int col = t * 12, which = col / DM, h = (col % DM) / HD, d0 = col % HD;
@@ -777,11 +750,11 @@ __global__ __launch_bounds__(192) void dilated_attn_bwd_combine_kernel(const flo
         const int r = h / (H / dr);
         if (loc % dr == r) {
           const int i = loc / dr;
-          const float* src = ws + p.ws_off[br] + ((((long)b * p.nseg[br] + j) * H + h) * p.n[br] + i) * (3 * HD) + which * HD + d0;
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4),
-                      a2 = *reinterpret_cast<const f32x4*>(src + 8);
+          const h16* src = ws + p.ws_off[br] + ((((long)b * p.nseg[br] + j) * H + h) * p.n[br] + i) * (3 * HD) + which * HD + d0;
+          const h16x4 a0 = *reinterpret_cast<const h16x4*>(src), a1 = *reinterpret_cast<const h16x4*>(src + 4),
+                      a2 = *reinterpret_cast<const h16x4*>(src + 8);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { acc[e] += a0[e]; acc[4 + e] += a1[e]; acc[8 + e] += a2[e]; }
+          for (int e = 0; e < 4; ++e) { acc[e] += (float)a0[e]; acc[4 + e] += (float)a1[e]; acc[8 + e] += (float)a2[e]; }
         }
       }
     }
@@ -841,11 +814,11 @@ extern "C" int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, con
 extern "C" long mt_dilated_attn_bwd_workspace_bytes(const MtDilatedPlan* plan) {
   if (!plan_ok(plan)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
-  return p.ws_off[p.nbranch] * (long)sizeof(float);
+  return p.ws_off[p.nbranch] * (long)sizeof(h16);
 }
 
 extern "C" int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot,
-                                   const float* delta_br, const MtDilatedPlan* plan, float* workspace, mt_half* dqkv,
+                                   const float* delta_br, const MtDilatedPlan* plan, void* workspace, mt_half* dqkv,
                                    int phases, mt_stream_t stream) {
   if (!qkv || !dmixed || !lse_tot || !delta_br || !workspace || !dqkv || !plan_ok(plan) || !(phases & 7)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
@@ -854,13 +827,13 @@ extern "C" int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, co
   // every (branch, position, head) slot of the workspace is written exactly once by each of the two kernels
   if (phases & MT_ATTN_BWD_KV)
     hipLaunchKernelGGL(dilated_attn_bwd_kv_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
-                       delta_br, p, workspace);
+                       delta_br, p, (h16*)workspace);
   if (phases & MT_ATTN_BWD_Q)
     hipLaunchKernelGGL(dilated_attn_bwd_q_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
-                       delta_br, p, workspace);
+                       delta_br, p, (h16*)workspace);
   const long M = (long)p.B * p.N;
   if (phases & MT_ATTN_BWD_COMBINE)
-    hipLaunchKernelGGL(dilated_attn_bwd_combine_kernel, dim3((int)min(M, 16384L)), dim3(192), 0, s, workspace, p, (h16*)dqkv);
+    hipLaunchKernelGGL(dilated_attn_bwd_combine_kernel, dim3((int)min(M, 16384L)), dim3(192), 0, s, (const h16*)workspace, p, (h16*)dqkv);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -208,7 +208,7 @@ class Engine:
         w["dmixed"] = e16(M, D)
         w["delta"] = e32(nb, M, 16)
         plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
-        w["attn_ws"] = torch.empty(ops.dilated_attn_bwd_workspace_bytes(plan) // 4, dtype=F32, device=dev)
+        w["attn_ws"] = torch.empty(ops.dilated_attn_bwd_workspace_bytes(plan) // 2, dtype=H16, device=dev)
         w["dqkv16"] = e16(M, 3 * D)
         w["scratch32"] = e32(Mp, D)
         if not fresh:

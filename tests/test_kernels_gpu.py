@@ -349,7 +349,7 @@ def test_dilated_attention_bwd_vs_oracle_autograd(ops, golden_dir, case):
     delta = torch.zeros(nb, M, 16, device=DEV)
     ops.dilated_mix_ln_bwd(dy.to(DEV).view(M, 768), o_br, lse_br, lse_tot, plan, ln_w.to(DEV), stats, dmixed, delta)
     dqkv = torch.full((M, 2304), float("nan"), device=DEV, dtype=torch.float16)
-    wsb = torch.full((ops.dilated_attn_bwd_workspace_bytes(plan) // 4,), float("nan"), device=DEV)
+    wsb = torch.full((ops.dilated_attn_bwd_workspace_bytes(plan) // 2,), float("nan"), device=DEV, dtype=torch.float16)
     ops.dilated_attn_bwd(qkv_d, dmixed, lse_tot, delta, plan, wsb, dqkv)
     torch.cuda.synchronize()
     assert rel(y.view(B, N, 768), yref) < 4e-3

@@ -24,7 +24,7 @@ dy = (torch.randn(M, 768, device="cuda", generator=g) * 0.1).half()
 dmixed = torch.zeros(M, 768, dtype=torch.float16, device="cuda"); delta = torch.zeros(5, M, 16, device="cuda")
 ops.dilated_mix_ln_bwd(dy, o_br, lse_br, lse_tot, plan, w, stats, dmixed, delta)
 dqkv = torch.zeros(M, 2304, device="cuda", dtype=torch.float16)
-wsb = torch.zeros(ops.dilated_attn_bwd_workspace_bytes(plan) // 4, device="cuda")
+wsb = torch.zeros(ops.dilated_attn_bwd_workspace_bytes(plan) // 2, device="cuda", dtype=torch.float16)
 torch.cuda.synchronize()
 fl = 3 * flops_per_slide_step(L, 65)["attn_layer"]
 for name, fn, mult in (("fwd", lambda: ops.dilated_attn_fwd(qkv, plan, o_br, lse_br), 1.0),
