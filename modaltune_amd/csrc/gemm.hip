@@ -109,14 +109,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: see epilogue
     }
     __syncthreads();
   }
 
-  // ---- epilogue.  The accumulators (16x16 MFMA C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg) are
-  // staged through LDS (the operand buffers are free now) so that every global access of the epilogue -- the
-  // residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B contiguous per row).
+  // ---- epilogue.  The MFMAs were issued with the operands swapped (W fragment as A, activation fragment as B), so
+  // each accumulator is a TRANSPOSED 16x16 tile: lane = (m = lane & 15, n = 4 * (lane >> 4) .. + 3), i.e. four
+  // consecutive output columns of one row per lane -> one 16-byte LDS write per tile instead of four scalar ones.
+  // The tile is staged through LDS (the operand buffers are free now) so that every global access of the epilogue --
+  // the residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B contiguous per row).
   float* Cs = reinterpret_cast<float*>(smem);
   OutT* C = reinterpret_cast<OutT*>(g.C);
   constexpr int CPR = BN / 4;                                  // float4 chunks per tile row
@@ -133,15 +135,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
     const int rbase = pass * EROWS;
     if (pass > 0) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * TM + i * 16 + fr - rbase;
+      if (row >= 0 && row < EROWS) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * TM + i * 16 + fq * 4 + r - rbase;
-        if (row >= 0 && row < EROWS) {
-#pragma unroll
-          for (int j = 0; j < NI; ++j) Cs[row * CS + wn * TN + j * 16 + fr] = acc[i][j][r];
-        }
+        for (int j = 0; j < NI; ++j) *reinterpret_cast<f32x4*>(&Cs[row * CS + wn * TN + j * 16 + fq * 4]) = acc[i][j];
       }
+    }
     __syncthreads();
 #pragma unroll 4
     for (int rr = r0; rr < EROWS; rr += RPP) {

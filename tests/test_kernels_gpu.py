@@ -37,7 +37,8 @@ def rng(seed):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (1000, 192, 768), (257, 3072, 768), (130, 768, 3072), (515, 384, 768)])
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (1000, 192, 768), (257, 3072, 768), (130, 768, 3072), (515, 384, 768),
+                                   (4100, 768, 768), (2303, 3072, 768), (2049, 768, 3072), (5000, 2304, 768)])   # >= 2048 rows: 8-wave kernel
 def test_gemm_nt_bias(ops, M, N, K):
     g = rng(M + N)
     A = torch.randn(M, K, generator=g).half()
@@ -74,6 +75,14 @@ def test_gemm_nt_rowmaps_resid_inject_posemb(ops):
     got = out.view(B, N_, Nc)[:, 1:]
     assert rel(got, ref) < 2e-5
     assert float(out.view(B, N_, Nc)[:, 0].abs().max()) == 0.0      # cls rows untouched
+    # BIAS_RESID on the 8-wave kernel (M >= 2048), fp32 residual stream
+    Mb = 2300
+    Ab = torch.randn(Mb, K, generator=g).half()
+    rb = torch.randn(Mb, Nc, generator=g)
+    ob = torch.zeros(Mb, Nc, device=DEV)
+    ops.gemm_nt(Ab.to(DEV), W.to(DEV), ob, Mb, Nc, K, epilogue=ops.EPI_BIAS_RESID, bias=bias.to(DEV), resid=rb.to(DEV), ldr=Nc)
+    torch.cuda.synchronize()
+    assert rel(ob, rb.double() + Ab.double() @ W.double().t() + bias.double()) < 2e-5
     # BIAS_RESID accumulate in place (dx += dy @ W)
     acc = torch.randn(M, Nc, generator=g)
     acc_d = acc.to(DEV).clone()
@@ -94,9 +103,10 @@ def test_gemm_nt_rowmaps_resid_inject_posemb(ops):
     assert rel(out2, ref2) < 2e-5
 
 
-def test_gemm_nt_head_major_qkv_epilogue(ops):
+@pytest.mark.parametrize("M", [333, 2600])
+def test_gemm_nt_head_major_qkv_epilogue(ops, M):
     g = rng(19)
-    M, N, K = 333, 2304, 768
+    N, K = 2304, 768
     A = torch.randn(M, K, generator=g).half()
     W = (torch.randn(N, K, generator=g) * 0.05).half()
     bias = torch.randn(N, generator=g)
