@@ -88,7 +88,7 @@ def main():
     # synthetic slides, distinct per rank, resident in HBM (2 alternating slides per rank)
     slides = []
     for j in range(2):
-        inp = synth.synth_inputs(L, sizes, seed=1000 + 17 * rank + j, grid=128)
+        inp = synth.synth_inputs(L, sizes, seed=1000 + 17 * rank + j, grid=128 if L <= 128 * 128 else 512)
         slides.append((torch.from_numpy(inp["x"]).to(dev).half().reshape(L, -1).contiguous(), inp["coords"],
                        [torch.from_numpy(a).to(dev) for a in inp["genes"]], torch.from_numpy(inp["text"]).to(dev)))
 
