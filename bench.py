@@ -60,17 +60,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-times", action="store_true", help="print the per-kernel time table (stderr)")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("MT_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # MT_BENCH_DEVICE: rehearsals only
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the hot path)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            torch.distributed.init_process_group(args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
 
     from modaltune_amd import ops, synth
@@ -109,7 +113,7 @@ def main():
     try:
         run(max(args.warmup, 3))      # >= 3: two eager steps + the capture step of the graph path
     except Exception as e:            # graph capture unavailable -> same arithmetic with eager launches
-        if args.eager or world > 1:   # (with several ranks a one-sided fallback would desynchronise the collectives)
+        if args.eager:                # (every rank runs the same code on the same hardware: the fallback is symmetric)
             raise
         print(f"[bench] hipGraph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
         args.eager = True
