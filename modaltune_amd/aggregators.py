@@ -47,9 +47,9 @@ class _ModelFn(torch.autograd.Function):
     `param.grad` views, so torch optimisers / GradScaler / DDP-style hooks see ordinary gradients."""
 
     @staticmethod
-    def forward(ctx, dummy, module, x, coords, genes, onehots, need):
+    def forward(ctx, dummy, module, x, coords, genes, onehots, need, clinical=None):
         eng = module.engine
-        logits = eng.forward(x, coords, genes, onehots, need_grad=need, fresh=need)
+        logits = eng.forward(x, coords, genes, onehots, need_grad=need, fresh=need, clinical=clinical)
         ctx.module, ctx.call = module, (eng.last_call if need else None)
         return logits.clone()
 
@@ -77,17 +77,18 @@ class _ModelFn(torch.autograd.Function):
         for k, p in params.items():
             if p.grad is None:
                 p.grad = store.grads[k]
-        return torch.zeros(1, device=dlogits.device), None, None, None, None, None, None
+        return torch.zeros(1, device=dlogits.device), None, None, None, None, None, None, None
 
 
 @Aggregator.register("longnetvit_gene_adapter")
 class LongNetGeneAdapter(Aggregator):
     """LongNet-ViT + Modal Adapter (reference LongNetGeneAdapter, longvit_adapter.py:30-347) on the HIP engine."""
+    CLINICAL = False
 
     def __init__(self, gene_group_defination: Dict[Any, Sequence[str]] = None, multi_task: int = 1, device="cuda", **kwargs):
         super().__init__()
         gene_group_defination = gene_group_defination or {}
-        cfg = ModelConfig.from_json(kwargs, multi_task=multi_task)
+        cfg = ModelConfig.from_json(kwargs, multi_task=multi_task, clinical=self.CLINICAL)
         self.cfg = cfg
         self.is_multi = multi_task > 1                       # longvit_adapter.py:88 (read at TM:174)
         self.engine = Engine(cfg, [len(v) for v in gene_group_defination.values()], device)
@@ -126,19 +127,28 @@ class LongNetGeneAdapter(Aggregator):
 
     # ---- forward (longvit_adapter.py:205-215 signature)
     def forward(self, x, coords, genes, task_token=None, attn_mask=None, multiway_split_position=None,
-                incremental_state=None, **kwargs):
+                incremental_state=None, clinical=None, **kwargs):
         if self.is_multi:
             if task_token is None:
                 raise ValueError("task_token is required when multi_task > 1")
             onehots = task_token.reshape(1, -1)
         else:
             onehots = torch.zeros(1, 1, device=self.engine.device)
-        return self.forward_tasks(x, coords, genes, onehots)
+        return self.forward_tasks(x, coords, genes, onehots, clinical=clinical)
 
-    def forward_tasks(self, x, coords, genes, task_onehots):
+    def forward_tasks(self, x, coords, genes, task_onehots, clinical=None):
         """All task passes of one slide in one batched engine call: logits [B, output_dim]."""
         self._sync_weight_caches()
         if isinstance(genes, dict):
             genes = [genes[k] for k in sorted(genes.keys())] if all(isinstance(k, int) for k in genes) else list(genes.values())
         need = torch.is_grad_enabled() and self.training_grad     # (grad mode is off inside Function.forward)
-        return _ModelFn.apply(self._dummy, self, x, coords, genes, task_onehots.to(self.engine.device, F32), need)
+        if not self.CLINICAL:
+            clinical = None                      # the base adapter ignores `clinical` like the reference's **kwargs
+        return _ModelFn.apply(self._dummy, self, x, coords, genes, task_onehots.to(self.engine.device, F32), need, clinical)
+
+
+@Aggregator.register("longnetvit_gene_clinical_adapter")
+class LongNetGeneSimpleClinicalAdapter(LongNetGeneAdapter):
+    """Clinical-prior variant (reference longvit_adapter.py:350-672): one extra token clinical_mlp(clinical[1, 5])
+    in front of the task / gene tokens (T = 66), and its outcome added (sum) / concatenated (cat) in the head."""
+    CLINICAL = True

@@ -62,6 +62,7 @@ class ModelConfig:
     pretrained: bool = True
     clinfeat_dim: int = 5
     multi_task: int = 3
+    clinical: bool = False      # LongNetGeneSimpleClinicalAdapter (longvit_adapter.py:350-672): + 1 clinical token
     gene: GeneConfig = dataclasses.field(default_factory=GeneConfig)
 
     # ---- derived ----
@@ -82,8 +83,8 @@ class ModelConfig:
         return self.multi_task > 1
 
     @property
-    def num_tokens(self) -> int:           # T = final_groups + task token (longvit_adapter.py:152-154)
-        return self.gene.final_groups + int(self.is_multi)
+    def num_tokens(self) -> int:           # T = final_groups + task token (+ clinical token) (longvit_adapter.py:152-154,475-477)
+        return self.gene.final_groups + int(self.is_multi) + int(self.clinical)
 
     def validate(self):
         if self.embed_dim != 768 or self.head_dim != 48:

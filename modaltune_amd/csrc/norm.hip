@@ -163,7 +163,9 @@ int ln_fwd_types(const LnFwdArgs& a, int in_dt, int out_dt, int gelu, hipStream_
 template <int D, typename DyT, typename InT, typename DxT, bool GELU>
 int ln_bwd_launch(const LnBwdArgs& a, hipStream_t s) {
   if (a.dw) {
-    if constexpr (D <= 768 && !GELU) {
+    if constexpr (!GELU && sizeof(DyT) == 4) {            // trainable norms: token side (fp32) ...
+      hipLaunchKernelGGL((ln_bwd_kernel<D, DyT, InT, DxT, GELU, true>), dim3(min(ln_grid(a.M), 512)), dim3(256), 0, s, a);
+    } else if constexpr (D <= 768 && !GELU) {           // ... and the adapters' 768-wide norms over the patch rows
       hipLaunchKernelGGL((ln_bwd_kernel<D, DyT, InT, DxT, GELU, true>), dim3(min(ln_grid(a.M), 512)), dim3(256), 0, s, a);
     } else {
       return MT_ERR_UNSUPPORTED;

@@ -217,7 +217,8 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, coords, genes: Sequence[torch.Tensor], task_onehots: torch.Tensor,
-                need_grad: bool = True, fresh: bool = False, staged: bool = False, geometry=None) -> torch.Tensor:
+                need_grad: bool = True, fresh: bool = False, staged: bool = False, geometry=None,
+                clinical: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [L, in_chans] (or [1,L,in]); coords [L,2] (host or device); genes: list of [1, n_i]; task_onehots [B, num_tasks].
         Returns logits [B, output_dim] (fp32, device).  fresh=True gives this call its own tape and workspace so that
         several forwards can precede one backward (the reference calls the model 3x before loss.backward(), TM:175-177);
@@ -255,7 +256,7 @@ class Engine:
 
         # ---- token side: gene encoder (shared) + task token per pass (LVA:257-266)
         gene = self._gene_encoder(genes)                                   # Var [1, G64, D]
-        c = self._assemble_tokens(gene, task_onehots)                      # Var [B, T, D]
+        c = self._assemble_tokens(gene, task_onehots, clinical)            # Var [B, T, D]
         pe = P("gene_pe")
 
         # ---- interaction blocks (LVA:294-307, AM:484-523)
@@ -348,29 +349,40 @@ class Engine:
         z = tape.linear(z, P(p + f"{g.depth + 1}.weight"), P(p + f"{g.depth + 1}.bias"))          # [1, G, D]
         return tape.axis_linear(z, P("gene_encoder.pathway_compression.weight"), P("gene_encoder.pathway_compression.bias"))
 
-    def _assemble_tokens(self, gene: Var, onehots: torch.Tensor) -> Var:
-        """c[b] = cat(task_weight(onehot_b), gene_embedding) (LVA:263-266)."""
+    def _assemble_tokens(self, gene: Var, onehots: torch.Tensor, clinical: Optional[torch.Tensor] = None) -> Var:
+        """c[b] = cat([clinical_mlp(clinical)], task_weight(onehot_b), gene_embedding) (LVA:263-266; 572-580 for the
+        clinical variant: the clinical token goes first)."""
         tape, P, D, T = self.tape, self.store.param, self.cfg.embed_dim, self.T
         B = onehots.shape[0]
         G64 = gene.data.shape[1]
         c = Var(tape.new(B, T, D))
-        nt = int(self.cfg.is_multi)
-        task = None
+        nt, ncl = int(self.cfg.is_multi), int(self.cfg.clinical)
+        task = clin = None
+        if ncl:
+            if clinical is None:
+                raise ValueError("this model variant needs `clinical` features [1, clinfeat_dim]")
+            cv = Var(clinical.to(self.device, F32).reshape(1, -1).contiguous(), needs_grad=False)
+            h1 = tape.linear(cv, P("clinical_mlp.0.weight"), P("clinical_mlp.0.bias"), act=ops.ACT_RELU)
+            clin = tape.layernorm(tape.linear(h1, P("clinical_mlp.2.weight"), P("clinical_mlp.2.bias")),
+                                  P("clinical_mlp.3.weight"), P("clinical_mlp.3.bias"))                  # [1, D], shared by the passes
+            ops.copy_rows(clin.data, c.data, B, D, smap=rowmap(1, 0, 0), dmap=rowmap(1, T, 0))
         if nt:
             oh = Var(onehots.to(self.device, F32).contiguous(), needs_grad=False)
             task = tape.layernorm(tape.linear(oh, P("task_weight.0.weight"), P("task_weight.0.bias")),
                                   P("task_weight.1.weight"), P("task_weight.1.bias"))                  # [B, D]
-            ops.copy_rows(task.data, c.data, B, D, dmap=rowmap(1, T, 0))
-        ops.copy_rows(gene.data.view(G64, D), c.data, B * G64, D, smap=rowmap(G64, 0, 0), dmap=rowmap(G64, T, nt))
+            ops.copy_rows(task.data, c.data, B, D, dmap=rowmap(1, T, ncl))
+        ops.copy_rows(gene.data.view(G64, D), c.data, B * G64, D, smap=rowmap(G64, 0, 0), dmap=rowmap(G64, T, ncl + nt))
 
         def bwd():
             if c.grad is None:
                 return
             if task is not None:
-                ops.copy_rows(c.grad, task.g(), B, D, smap=rowmap(1, T, 0), accumulate=True)
+                ops.copy_rows(c.grad, task.g(), B, D, smap=rowmap(1, T, ncl), accumulate=True)
             gg = gene.g().view(G64, D)
-            for b in range(B):      # d gene_embedding = sum over the passes
-                ops.copy_rows(c.grad, gg, G64, D, smap=rowmap(G64, T, b * T + nt), accumulate=True)
+            for b in range(B):      # d gene_embedding (and d clinical token) = sum over the passes
+                ops.copy_rows(c.grad, gg, G64, D, smap=rowmap(G64, T, b * T + ncl + nt), accumulate=True)
+                if clin is not None:
+                    ops.copy_rows(c.grad, clin.g(), 1, D, smap=rowmap(1, T, b * T), accumulate=True)
         tape.record(bwd)
         return c
 
@@ -553,17 +565,21 @@ class Engine:
     def _head(self, c: Var, hout: torch.Tensor) -> Var:
         cfg, ctx, tape, P = self.cfg, self._ctx, self.tape, self.store.param
         B, N, D, T, ws = ctx["B"], ctx["N"], cfg.embed_dim, self.T, ctx["ws"]
-        nt = int(cfg.is_multi)
-        G64 = T - nt
+        nt, ncl = int(cfg.is_multi), int(cfg.clinical)
+        off = ncl + nt                              # token order: [clinical], [task], genes (LVA:572-580)
+        G64 = T - off
         cls = Var(tape.new(B, D))
         ops.copy_rows(hout, cls.data, B, D, smap=rowmap(1, N, 0))
         gene = Var(tape.new(B, D))
-        # mean over the gene tokens: gene[b, d] = sum_t (1/G64) c[b, nt + t, d]
-        ops.sgemm(self._mean_w, (0, 1), c.data[:, nt:], (1, D), gene.data, (D, 1), 1, D, G64, batch=B, b_bs=T * D, c_bs=D)
-        task = None
+        # mean over the gene tokens: gene[b, d] = sum_t (1/G64) c[b, off + t, d]
+        ops.sgemm(self._mean_w, (0, 1), c.data[:, off:], (1, D), gene.data, (D, 1), 1, D, G64, batch=B, b_bs=T * D, c_bs=D)
+        task = clin = None
         if nt:
             task = Var(tape.new(B, D))
-            ops.copy_rows(c.data, task.data, B, D, smap=rowmap(1, T, 0))
+            ops.copy_rows(c.data, task.data, B, D, smap=rowmap(1, T, ncl))
+        if ncl:
+            clin = Var(tape.new(B, D))
+            ops.copy_rows(c.data, clin.data, B, D, smap=rowmap(1, T, 0))
 
         def bwd_gather():
             dh = ws["dh"]
@@ -571,18 +587,22 @@ class Engine:
             if cls.grad is not None:
                 ops.copy_rows(cls.grad, dh, B, D, dmap=rowmap(1, N, 0))
             cg = c.g()
-            if gene.grad is not None:   # dc[b, nt + t, :] += dgene[b, :] / G64
-                ops.sgemm(self._mean_w, (1, 0), gene.grad, (1, 0), cg[:, nt:], (D, 1), G64, D, 1, accumulate=True, batch=B,
+            if gene.grad is not None:   # dc[b, off + t, :] += dgene[b, :] / G64
+                ops.sgemm(self._mean_w, (1, 0), gene.grad, (1, 0), cg[:, off:], (D, 1), G64, D, 1, accumulate=True, batch=B,
                           b_bs=D, c_bs=T * D)
             if task is not None and task.grad is not None:
-                ops.copy_rows(task.grad, cg, B, D, dmap=rowmap(1, T, 0), accumulate=True)
+                ops.copy_rows(task.grad, cg, B, D, dmap=rowmap(1, T, ncl), accumulate=True)
+            if clin is not None and clin.grad is not None:
+                ops.copy_rows(clin.grad, cg, B, D, dmap=rowmap(1, T, 0), accumulate=True)
         tape.record(bwd_gather)
-        if cfg.token_agg == "sum":
+        if cfg.token_agg == "sum":                  # LVA:328-333 / 645-653
             outc = tape.add(cls, gene)
             if task is not None:
                 outc = tape.add(outc, task)
-        else:
-            parts = [cls, task, gene] if task is not None else [cls, gene]
+            if clin is not None:
+                outc = tape.add(outc, clin)
+        else:                                       # cat order: img, task, gene, clinical (LVA:334-340 / 654-664)
+            parts = [cls] + ([task] if task is not None else []) + [gene] + ([clin] if clin is not None else [])
             outc = Var(tape.new(B, D * len(parts)))
             for j, pv in enumerate(parts):
                 ops.copy_rows(pv.data, outc.data[:, j * D:], B, D, ldd=D * len(parts))

@@ -115,7 +115,11 @@ def param_specs(cfg: ModelConfig, group_sizes: Sequence[int]) -> List[Tuple[str,
     if cfg.is_multi:
         add([("task_weight.0.weight", (D, cfg.multi_task), "w"), ("task_weight.0.bias", (D,), "b"),
              ("task_weight.1.weight", (D,), "lnw"), ("task_weight.1.bias", (D,), "lnb")], True)
-    fin = D * ((2 + int(cfg.is_multi)) if cfg.token_agg == "cat" else 1)
+    if cfg.clinical:      # clinical_mlp (longvit_adapter.py:486-491): Linear(5, 384) -> ReLU -> Linear(384, 768) -> LayerNorm
+        add([("clinical_mlp.0.weight", (D // 2, cfg.clinfeat_dim), "w"), ("clinical_mlp.0.bias", (D // 2,), "b"),
+             ("clinical_mlp.2.weight", (D, D // 2), "w"), ("clinical_mlp.2.bias", (D,), "b"),
+             ("clinical_mlp.3.weight", (D,), "lnw"), ("clinical_mlp.3.bias", (D,), "lnb")], True)
+    fin = D * ((2 + int(cfg.is_multi) + int(cfg.clinical)) if cfg.token_agg == "cat" else 1)
     add([("final_norm.weight", (fin,), "lnw"), ("final_norm.bias", (fin,), "lnb"),
          ("final_project.weight", (O, fin), "w"), ("final_project.bias", (O,), "b")], True)
     return s
@@ -175,7 +179,8 @@ def synth_inputs(L: int, group_sizes: Sequence[int], seed: int = 0, grid: int = 
     coords = (np.stack([rows, cols], 1) * 256 + jitter).astype(np.float32)[None]
     genes = [r.standard_normal((1, int(n))).astype(np.float32) for n in group_sizes]
     text = r.standard_normal((4, text_dim)).astype(np.float32)
-    return {"x": x, "coords": coords, "genes": genes, "text": text}
+    clinical = r.standard_normal((1, 5)).astype(np.float32)      # z-scored clinical features [1, clinfeat_dim]
+    return {"x": x, "coords": coords, "genes": genes, "text": text, "clinical": clinical}
 
 
 def projector_state(seed: int = 0, in_dim: int = 512, out_dim: int = 256) -> Dict[str, np.ndarray]:

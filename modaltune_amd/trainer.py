@@ -65,12 +65,12 @@ class TrainStep:
         tape.grad_enabled = was
         return out
 
-    def step(self, x, coords, genes, text, update: bool = True) -> torch.Tensor:
+    def step(self, x, coords, genes, text, update: bool = True, clinical=None) -> torch.Tensor:
         """One train step on one slide.  Returns the (device) loss scalar; no host sync happens here."""
         eng = self.engine
         target = self.project_text(text)
         eng.store.flat_grad.zero_()
-        logits = eng.forward(x, coords, genes, self.onehots, need_grad=True)
+        logits = eng.forward(x, coords, genes, self.onehots, need_grad=True, clinical=clinical)
         self.last_logits = logits
         R, O = logits.shape
         dlogits = torch.empty_like(logits)
@@ -81,7 +81,7 @@ class TrainStep:
         return self.loss
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
-    def step_graphed(self, x, coords, genes, text) -> torch.Tensor:
+    def step_graphed(self, x, coords, genes, text, clinical=None) -> torch.Tensor:
         """Same arithmetic as step(), replayed from a captured hipGraph: the ~900 kernel launches of a step are
         recorded once (after two eager warm-up steps) and replayed with one host call; inputs are uploaded into static
         buffers first.  With world_size > 1 the forward+backward graph and the optimiser graph are separate and the
@@ -95,16 +95,20 @@ class TrainStep:
             self._gkey, self._graphs, self._gwarm = key, None, 0
             self._sgenes = [torch.empty(1, int(g.numel()), dtype=F32, device=self.dev) for g in genes]
             self._stext = torch.empty(tuple(text.shape), dtype=F32, device=self.dev)
+            self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
         eng.stage_inputs(x, coords, B=B)
         for dst, g in zip(self._sgenes, genes):
             dst.copy_(g.reshape(1, -1))
         self._stext.copy_(text)
+        if self._sclin is not None:
+            self._sclin.copy_(clinical.reshape(1, -1))
         world = torch.distributed.get_world_size(self.pg) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
 
         def fwd_bwd():
             target = self.project_text(self._stext)
             eng.store.flat_grad.zero_()
-            logits = eng.forward(None, None, self._sgenes, self.onehots, need_grad=True, staged=True, geometry=(B, L))
+            logits = eng.forward(None, None, self._sgenes, self.onehots, need_grad=True, staged=True, geometry=(B, L),
+                                 clinical=self._sclin)
             self.last_logits = logits
             R, O = logits.shape
             dlogits = torch.empty_like(logits)

@@ -228,7 +228,7 @@ def pos_embed_rows(coords, embed_dim, ngrids, dtype):
 # Full model forward (models/aggregators/longvit_adapter.py:205-347) and train-step loss
 # ------------------------------------------------------------------------------------------------
 def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token, seg_lengths,
-                  taps: Optional[dict] = None):
+                  taps: Optional[dict] = None, clinical=None):
     """x [1,L,in], coords [1,L,2], genes list of [1,n_i], task_token [num_tasks] -> [1, output_dim]."""
     heads = cfg.num_heads
     ratios = (1, 2, 4, 8, 16)
@@ -239,6 +239,10 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token
     if cfg.is_multi:                                                                     # LVA:263-266
         t = _ln(_linear(task_token.unsqueeze(0), sd, "task_weight.0"), sd, "task_weight.1")
         c = torch.cat((t.unsqueeze(0), c), dim=1)
+    ncl = int(getattr(cfg, "clinical", False))
+    if ncl:                                                                              # LVA:578-580 (clinical variant)
+        ce = _linear(F.relu(_linear(clinical, sd, "clinical_mlp.0")), sd, "clinical_mlp.2")
+        c = torch.cat((_ln(ce, sd, "clinical_mlp.3").unsqueeze(0), c), dim=1)
     pe = sd["gene_pe"]
     if taps is not None:
         taps["x0"] = x.detach().clone(); taps["c0"] = c.detach().clone()
@@ -258,11 +262,13 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token
             taps[f"cls{i}"] = cls.detach().clone(); taps[f"c{i}"] = c.detach().clone()
             taps[f"x{i}_head"] = x[:, :8].detach().clone()
     nt = int(cfg.is_multi)
-    task_out, gene_out = c[:, :nt], c[:, nt:].mean(dim=1, keepdim=True)                  # LVA:321-325
+    clin_out, task_out = c[:, :ncl], c[:, ncl:ncl + nt]                                  # LVA:321-325 / 632-641
+    gene_out = c[:, ncl + nt:].mean(dim=1, keepdim=True)
     if cfg.token_agg == "sum":
-        out = cls + gene_out + (task_out if nt else 0)
+        out = cls + gene_out + (task_out if nt else 0) + (clin_out if ncl else 0)
     else:
-        out = torch.cat(((cls, task_out, gene_out) if nt else (cls, gene_out)), dim=-1)
+        parts = [cls] + ([task_out] if nt else []) + [gene_out] + ([clin_out] if ncl else [])
+        out = torch.cat(parts, dim=-1)
     out = _ln(out, sd, "final_norm")
     return _linear(out.squeeze(1), sd, "final_project")
 
@@ -283,22 +289,22 @@ def distill_loss(logits, text_proj, temperature=1.0):
     return F.kl_div(logp, p, reduction="sum") * (temperature ** 2) * 10
 
 
-def multitask_logits(sd, cfg, x, coords, genes, seg_lengths, task_ids=(0, 1, 2), taps=None):
+def multitask_logits(sd, cfg, x, coords, genes, seg_lengths, task_ids=(0, 1, 2), taps=None, clinical=None):
     """multitask_forward (train_modaltune.py:156-179)."""
     eye = torch.eye(cfg.multi_task, dtype=x.dtype)
     outs = []
     for t in task_ids:
         tp = {} if taps is not None else None
-        outs.append(model_forward(sd, cfg, x, coords, genes, eye[t], seg_lengths, taps=tp))
+        outs.append(model_forward(sd, cfg, x, coords, genes, eye[t], seg_lengths, taps=tp, clinical=clinical))
         if taps is not None:
             taps[t] = tp
     return torch.cat(outs, dim=0)
 
 
-def train_step_loss_and_grads(sd, cfg, trainable: Sequence[str], x, coords, genes, text, psd, seg_lengths):
+def train_step_loss_and_grads(sd, cfg, trainable: Sequence[str], x, coords, genes, text, psd, seg_lengths, clinical=None):
     """Forward x3 + loss + backward (train_modaltune.py:211-235). Returns logits, loss, {key: grad}."""
     sd = {k: (v.clone().requires_grad_(True) if k in set(trainable) else v) for k, v in sd.items()}
-    logits = multitask_logits(sd, cfg, x, coords, genes, seg_lengths)
+    logits = multitask_logits(sd, cfg, x, coords, genes, seg_lengths, clinical=clinical)
     loss = distill_loss(logits, projector_forward(text, psd))
     loss.backward()
     grads = {k: sd[k].grad for k in trainable}

@@ -127,19 +127,24 @@ GRAD_KEYS_FULL = ["interactions.0.injector.gamma", "interactions.1.injector.gamm
                   "gene_encoder.pathway_compression.weight", "interactions.2.extractor.ffn.linear1.bias"]
 
 
-def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32), ngrids=128, time_it=False):
+def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32), ngrids=128, time_it=False, clinical=False,
+               token_agg=None):
     cfg_kw = dict(REF_CFG)
     cfg_kw.update(depth=depth, interaction_indexes=inter, slide_ngrids=ngrids, pretrained=False)
-    cfg = ModelConfig.from_json(cfg_kw)
+    if token_agg:
+        cfg_kw["token_agg"] = token_agg
+    cfg = ModelConfig.from_json(cfg_kw, clinical=clinical)
     sizes = synth.toy_group_sizes(6)
     groups = {i: ["g"] * n for i, n in enumerate(sizes)}
     sd = synth.synth_state_dict(cfg, sizes, seed)
     inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
     psd = synth.projector_state(seed)
-    out = {"L": L, "depth": depth, "inter": np.array(inter), "seed": seed, "ngrids": ngrids, "sizes": np.array(sizes)}
+    out = {"L": L, "depth": depth, "inter": np.array(inter), "seed": seed, "ngrids": ngrids, "sizes": np.array(sizes),
+           "clinical": int(clinical), "token_agg": cfg.token_agg}
     for dt in dtypes:
         tag = "f64" if dt == torch.float64 else "f32"
-        model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, **cfg_kw, multi_task=3)
+        model = Aggregator.create("longnetvit_gene_clinical_adapter" if clinical else "longnetvit_gene_adapter",
+                                  gene_group_defination=groups, **cfg_kw, multi_task=3)
         model.load_state_dict({k: tt(v, torch.float32) for k, v in sd.items()}, strict=True)
         model = model.to(dt)
         ref_shims.zero_dropout(model)
@@ -160,7 +165,8 @@ def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32
         genes = {i: tt(g, dt) for i, g in enumerate(inp["genes"])}
         t0 = time.time()
         text = proj(tt(inp["text"], dt)); text = text / text.norm(dim=-1, keepdim=True)
-        logits = torch.cat([model(x=x, coords=coords, genes=genes, clinical=[], task_token=torch.eye(3, dtype=dt)[t])
+        clin = tt(inp["clinical"], dt) if clinical else []
+        logits = torch.cat([model(x=x, coords=coords, genes=genes, clinical=clin, task_token=torch.eye(3, dtype=dt)[t])
                             for t in (0, 1, 2)], dim=0)
         t1 = time.time()
         logit = logits / logits.norm(dim=-1, keepdim=True)
@@ -196,7 +202,11 @@ def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["adapter", "layer", "gene", "m37", "m1500", "m512"]
+    which = sys.argv[1:] or ["adapter", "layer", "gene", "m37", "m1500", "m512", "clin"]
+    if "clin" in which:   # clinical-prior variant (T = 66), sum and cat fusion heads
+        model_case("L37_d3_clin", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=14, clinical=True)
+        model_case("L37_d3_clin_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=15, clinical=True, token_agg="cat")
+        model_case("L37_d3_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=16, token_agg="cat")
     if "adapter" in which:
         unit_adapter()
     if "layer" in which:

@@ -87,7 +87,8 @@ def _run_model_case(path, dtype):
     L, depth, seed, ngrids = int(g["L"]), int(g["depth"]), int(g["seed"]), int(g["ngrids"])
     sizes = [int(s) for s in g["sizes"]]
     cfg = ModelConfig(depth=depth, interaction_indexes=tuple(tuple(int(i) for i in p) for p in g["inter"]),
-                      slide_ngrids=ngrids)
+                      slide_ngrids=ngrids, clinical=bool(int(g["clinical"])) if "clinical" in g.files else False,
+                      token_agg=str(g["token_agg"]) if "token_agg" in g.files else "sum")
     cfg.validate()
     sd = _sd(cfg, sizes, seed, dtype)
     inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
@@ -96,11 +97,13 @@ def _run_model_case(path, dtype):
     genes = [torch.from_numpy(a).to(dtype) for a in inp["genes"]]
     text = torch.from_numpy(inp["text"]).to(dtype)
     trainable = synth.trainable_keys(cfg, sizes)
-    logits, loss, grads = O.train_step_loss_and_grads(sd, cfg, trainable, x, coords, genes, text, psd, segment_lengths())
+    clin = torch.from_numpy(inp["clinical"]).to(dtype) if cfg.clinical else None
+    logits, loss, grads = O.train_step_loss_and_grads(sd, cfg, trainable, x, coords, genes, text, psd, segment_lengths(),
+                                                      clinical=clin)
     return g, cfg, logits, loss, grads
 
 
-@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12"])
+@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12", "L37_d3_clin", "L37_d3_clin_cat", "L37_d3_cat"])
 def test_full_train_step_f64(golden_dir, name):
     path = os.path.join(golden_dir, f"model_{name}.npz")
     if not os.path.exists(path):
