@@ -173,3 +173,43 @@ def test_graph_replay_matches_eager(golden_dir):
     for k in ("interactions.0.injector.gamma", "final_project.weight", "gene_pe"):
         a, b = eng_a.store.tensors[k], eng_b.store.tensors[k]
         assert float((a - b).abs().max()) <= 2.5 * 5 * ts_a.lr, k
+
+
+def test_clinical_module_and_pancancer_task_width(golden_dir):
+    """(a) registry name longnetvit_gene_clinical_adapter through the nn.Module API vs the reference golden;
+    (b) pan-cancer trainer shape (train_modaltune_pancancer.py:537-542: num_tasks = 4, task ids 0..2) vs the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    from modaltune_amd.config import segment_lengths
+    from modaltune_amd.engine import Engine
+    from oracle import modaltune_oracle as O
+    g = np.load(os.path.join(golden_dir, "model_L37_d3_clin.npz"))
+    L, seed, ngrids = int(g["L"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("longnetvit_gene_clinical_adapter", gene_group_defination=groups, depth=3, slide_ngrids=ngrids,
+                              interaction_indexes=[[0, 0], [1, 1], [2, 2]], token_agg="sum", multi_task=3)
+    cfg = model.cfg
+    assert cfg.clinical and cfg.num_tokens == 66
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, sizes, seed).items()}, strict=True)
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    x, coords = torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda()
+    genes = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    clin = torch.from_numpy(inp["clinical"]).cuda()
+    with torch.no_grad():
+        logits = torch.cat([model(x=x, coords=coords, genes=genes, clinical=clin, task_token=torch.eye(3)[t].cuda()) for t in (0, 1, 2)])
+    assert _rel(logits.cpu().numpy(), g["f64_logits"]) < 1e-3
+    # (b) multi_task = 4, three task passes
+    cfg4 = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)), slide_ngrids=ngrids, multi_task=4)
+    sd4 = synth.synth_state_dict(cfg4, sizes, 21)
+    eng = Engine(cfg4, sizes, "cuda")
+    eng.load_state_dict(sd4)
+    oh = torch.eye(4)[[0, 1, 2]].cuda()
+    out = eng.forward(x, inp["coords"], [torch.from_numpy(a).cuda() for a in inp["genes"]], oh, need_grad=False)
+    torch.cuda.synchronize()
+    sdt = {k: torch.from_numpy(v) for k, v in sd4.items()}
+    with torch.no_grad():
+        ref = O.multitask_logits(sdt, cfg4, torch.from_numpy(inp["x"]), torch.from_numpy(inp["coords"]),
+                                 [torch.from_numpy(a) for a in inp["genes"]], segment_lengths(), task_ids=(0, 1, 2))
+    assert _rel(out.cpu().numpy(), ref.numpy()) < 1e-3
