@@ -87,6 +87,11 @@ MT_DEVINL WorkItem decode(const Plan& p, int bid) {
   const int r = gid / H;
   w.j = r % p.nseg[w.br];
   w.b = r / p.nseg[w.br];
+  // the divisions above run on the VALU: pin the (wave-uniform) results in SGPRs so everything derived from them --
+  // base pointers, tile counts, loop bounds -- stays scalar
+  w.br = __builtin_amdgcn_readfirstlane(w.br); w.qt = __builtin_amdgcn_readfirstlane(w.qt);
+  w.h = __builtin_amdgcn_readfirstlane(w.h); w.j = __builtin_amdgcn_readfirstlane(w.j);
+  w.b = __builtin_amdgcn_readfirstlane(w.b);
   return w;
 }
 
@@ -123,12 +128,28 @@ struct Seq {
   // always-in-bounds row for unconditional loads (the value is discarded with a select when !valid(i)):
   // a branch around each load would make hipcc wait for every load separately (guide §5 trap (c))
   MT_DEVINL long row_clamped(int i) const { return min(row(i), row_base + (long)N - 1); }
+  // valid(i) holds exactly for i < nvalid(): r + i dr < min(s, N - seg_base)
+  MT_DEVINL int nvalid() const {
+    const int lim = min(s, N - seg_base) - r;
+    return lim <= 0 ? 0 : min(n, (lim + dr - 1) / dr);
+  }
 };
 
 // q / k / v are HEAD-MAJOR: [which = q|k|v][head][B*N rows][48] (written that way by the QKV GEMM epilogue), so a
 // head's dilated key walk touches rows 96 * r bytes apart (contiguous for r = 1) instead of 4608 * r in the
 // token-major [B*N, 2304] layout; dmixed is head-major too ([head][B*N][48]).
 MT_DEVINL const h16* hm_ptr(const h16* base, long M, int slab, long row) { return base + ((long)slab * M + row) * HD; }
+
+// uniform base + 32-bit byte offset: one VGPR of address state per thread (global_load ... v_off, s[base]), no 64-bit
+// per-lane arithmetic in the tile loops
+MT_DEVINL h16x8 ldg8_off(const h16* base, uint32_t byte_off) {
+  return *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+MT_DEVINL float ldf_off(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+MT_DEVINL f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+MT_DEVINL f32x2 pk_exp2(f32x2 a) { return (f32x2){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])}; }
 
 MT_DEVINL h16x8 sel8(bool ok, h16x8 v) {
   const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -143,7 +164,7 @@ MT_DEVINL long ws_slot(const Plan& p, const WorkItem& w, int i) {
 MT_DEVINL Seq make_seq(const Plan& p, const WorkItem& w) {
   Seq q;
   q.n = p.n[w.br]; q.s = p.seg[w.br]; q.dr = p.ratio[w.br];
-  q.r = w.h / (H / q.dr);
+  q.r = __builtin_amdgcn_readfirstlane(w.h / (H / q.dr));
   q.seg_base = w.j * q.s; q.N = p.N; q.row_base = (long)w.b * p.N;
   return q;
 }
@@ -200,28 +221,50 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
 
   const StageIdx st(tid);
   const int ntile = (sq.n + 63) / 64;
+  // tiles [0, nfull) hold only real rows: loaded with a uniform base + constant 32-bit lane offset, no clamp, no select
+  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);
+  const h16* kbase = hm_ptr(qkv, M, H + w.h, sq.row(0));
+  const h16* vbase = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
+  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
+  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
   h16x8 rk0, rk1, rv0, rv1;
   bool kok0 = false, kok1 = false, vok0 = false, vok1 = false;
-  // unconditional loads (clamped rows); padded rows are zeroed by a select when the tile is written to LDS
-  auto gload_k = [&](int kb) {
-    const int i0 = kb + st.row0, i1 = kb + st.row1;
-    rk0 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
-    rk1 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
-    kok0 = sq.valid(i0); kok1 = sq.valid(i1);
+  // ragged tiles: unconditional loads of clamped rows; padded rows are zeroed by a select when the tile goes to LDS
+  auto gload_k = [&](int t, auto full_tag) {
+    const int kb = t * 64;
+    if (decltype(full_tag)::value) {
+      const h16* b = kbase + (long)kb * sq.dr * HD;
+      rk0 = ldg8_off(b, c0); rk1 = ldg8_off(b, c1);
+    } else {
+      const int i0 = kb + st.row0, i1 = kb + st.row1;
+      rk0 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
+      rk1 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
+      kok0 = sq.valid(i0); kok1 = sq.valid(i1);
+    }
   };
-  auto gload_v = [&](int kb) {
-    const int i0 = kb + st.row0, i1 = kb + st.row1;
-    rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
-    rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
-    vok0 = sq.valid(i0); vok1 = sq.valid(i1);
+  auto gload_v = [&](int t, auto full_tag) {
+    const int kb = t * 64;
+    if (decltype(full_tag)::value) {
+      const h16* b = vbase + (long)kb * sq.dr * HD;
+      rv0 = ldg8_off(b, c0); rv1 = ldg8_off(b, c1);
+    } else {
+      const int i0 = kb + st.row0, i1 = kb + st.row1;
+      rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
+      rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
+      vok0 = sq.valid(i0); vok1 = sq.valid(i1);
+    }
   };
-  auto lstore_k = [&](int buf) {
-    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = sel8(kok0, rk0);
-    if (st.has1) *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = sel8(kok1, rk1);
+  auto lstore_k = [&](int buf, auto full_tag) {
+    h16x8 a = rk0, b = rk1;
+    if (!decltype(full_tag)::value) { a = sel8(kok0, a); b = sel8(kok1, b); }
+    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = a;
+    if (st.has1) *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = b;
   };
-  auto lstore_v = [&](int buf) {
-    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = sel8(vok0, rv0);
-    if (st.has1) *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = sel8(vok1, rv1);
+  auto lstore_v = [&](int buf, auto full_tag) {
+    h16x8 a = rv0, b = rv1;
+    if (!decltype(full_tag)::value) { a = sel8(vok0, a); b = sel8(vok1, b); }
+    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = a;
+    if (st.has1) *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = b;
   };
   auto qk = [&](int buf, f32x16 (&s)[2]) {      // raw scores of one 64-key tile: s[sub][reg] (key = row, query = lane)
 #pragma unroll
@@ -242,16 +285,17 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   float m_run = NEG_BIG;      // running row maximum of the RAW logits q.k (scale c folded into the exp2 argument)
 
   // prologue: tile 0 -> LDS
-  gload_k(0); gload_v(0);
-  lstore_k(0); lstore_v(0);
+  gload_k(0, std::false_type{}); gload_v(0, std::false_type{});
+  lstore_k(0, std::false_type{}); lstore_v(0, std::false_type{});
   __syncthreads();
 
   // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  auto tile = [&](int t, auto last_tag, auto tail_tag) {
+  // next_tag: tile t + 1 is a full tile (fast loads, no selects)
+  auto tile = [&](int t, auto last_tag, auto tail_tag, auto next_tag) {
     constexpr bool LAST = decltype(last_tag)::value, TAIL = decltype(tail_tag)::value;
     const int kb = t * 64, buf = t & 1;
-    if (!LAST) { gload_k(kb + 64); gload_v(kb + 64); }
+    if (!LAST) { gload_k(t + 1, next_tag); gload_v(t + 1, next_tag); }
     f32x16 s_cur[2];
     qk(buf, s_cur);
     // keys >= n are tile padding (excluded, last tile only); zero-padded keys keep logit 0 (DA:98-101)
@@ -276,7 +320,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
       m_run = m_new;
     }
-    const float mc = m_run * c;
+    const f32x2 c2 = {c, c}, nmc2 = {-m_run * c, -m_run * c};
     // O^T += V^T . P^T ; A fragment element e of lane half hh = V[key 16 s2 + 8 (e>>2) + 4 hh + (e&3)][d = lane & 31]
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -284,7 +328,10 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       for (int s2 = 0; s2 < 2; ++s2) {
         h16x8 pf;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[e] = (h16)__builtin_amdgcn_exp2f(fmaf(s_cur[sub][8 * s2 + e], c, -mc));
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 a = pk_exp2(pk_fma((f32x2){s_cur[sub][8 * s2 + e], s_cur[sub][8 * s2 + e + 1]}, c2, nmc2));
+          pf[e] = (h16)a[0]; pf[e + 1] = (h16)a[1];
+        }
         const h16* vrow = &Vs[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
         const h16x8 v0 = cat8(lds_tr4(vrow), lds_tr4(vrow + 8 * VSTR));
         const h16x8 v1 = cat8(lds_tr4(vrow + 32), lds_tr4(vrow + 8 * VSTR + 32));
@@ -292,13 +339,15 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf, o1, 0, 0, 0);
       }
     if (!LAST) {
-      lstore_k(buf ^ 1); lstore_v(buf ^ 1);
+      lstore_k(buf ^ 1, next_tag); lstore_v(buf ^ 1, next_tag);
       __syncthreads();
     }
   };
-  for (int t = 0; t < ntile - 1; ++t) tile(t, std::false_type{}, std::false_type{});
-  if (sq.n & 63) tile(ntile - 1, std::true_type{}, std::true_type{});
-  else tile(ntile - 1, std::true_type{}, std::false_type{});
+  int t = 0;
+  for (; t + 1 < nfull; ++t) tile(t, std::false_type{}, std::false_type{}, std::true_type{});
+  for (; t < ntile - 1; ++t) tile(t, std::false_type{}, std::false_type{}, std::false_type{});
+  if (sq.n & 63) tile(ntile - 1, std::true_type{}, std::true_type{}, std::false_type{});
+  else tile(ntile - 1, std::true_type{}, std::false_type{}, std::false_type{});
 
   if (qvalid) {
     const float l = o1[8];           // O^T row 48 (lane half 0) / row 52 (lane half 1): both carry sum(P)
@@ -462,11 +511,16 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // backward, kernel Q: dQ.  Same decomposition as the forward (query = lane).
-//   P~^T = exp2(c S^T - L2[q])            (L2 = lse_tot * log2e; equals w_b * P_b)
-//   dP^T[key,q] = V . dO^T                 V rows from LDS, dO^T in registers
-//   dS^T = P~^T (dP^T - delta_b[q]) / sqrt(48)
-//   dQ^T[d,q] += K^T[d,key] . dS^T         K^T via transposed LDS reads
+//   P'^T = exp2(c S^T - L2[q] + log2(scale))   (L2 = lse_tot * log2e; P' = w_b * P_b / sqrt(48))
+//   dP^T[key,q] = V . dO^T                      V rows from LDS, dO^T in registers
+//   dS^T = P'^T (dP^T - delta_b[q])             (the 1/sqrt(48) of dS rides inside P')
+//   dQ^T[d,q] += K^T[d,key] . dS^T              K^T via transposed LDS reads
+// The elementwise block is written with packed fp32 ops (v_pk_fma/add/mul_f32): these kernels issue about as many
+// VALU cycles as MFMA cycles, and the two did not overlap (PMC: VALU 49 %, MFMA 37 % busy before this form).
 // ------------------------------------------------------------------------------------------------
+constexpr float LOG2_SCALE = -2.7924812503605781f;   // log2(48^-1/2)
+constexpr float INV_SCALE = 6.9282032302755092f;     // sqrt(48)
+
 __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                  const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
                                                                  Plan p, h16* __restrict__ ws) {
@@ -478,7 +532,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
-  const float scale = 0.14433756729740643f, c = scale * LOG2E;
+  const float c = 0.14433756729740643f * LOG2E;
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   if (tid < 128) {   // zero the never-written columns 48..63 of the transposed-layout tile (read as d rows 48..63)
@@ -496,28 +550,43 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
     qf[ks] = sel8(qvalid, ldg8(hm_ptr(qkv, M, w.h, qrow) + ks * 16 + hh * 8));
     dof[ks] = sel8(qvalid, ldg8(hm_ptr(dmixed, M, w.h, qrow) + ks * 16 + hh * 8));
   }
-  // invalid queries: L2 = +big -> P~ = 0
+  // invalid queries: -L2 = -big -> P' = 0
   const float L2raw = lse_tot[qrow * H + w.h], dlraw = delta_br[((long)w.br * M + qrow) * H + w.h];
-  const float L2 = qvalid ? L2raw * LOG2E : 1.0e30f;
-  const float delta = qvalid ? dlraw : 0.f;
+  const float nl2 = qvalid ? fmaf(-L2raw, LOG2E, LOG2_SCALE) : -1.0e30f;
+  const float ndl = qvalid ? -dlraw : 0.f;
+  const f32x2 c2 = {c, c}, nl22 = {nl2, nl2}, ndl2 = {ndl, ndl};
 
   const StageIdx st(tid);
+  const int ntile = (sq.n + 63) / 64;
+  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);   // tiles [0, nfull) hold only real rows
+  const h16* kbase = hm_ptr(qkv, M, H + w.h, sq.row(0));
+  const h16* vbase = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
+  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
+  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
   h16x8 rk0, rk1, rv0, rv1;
   bool ok0 = false, ok1 = false;
-  auto gload = [&](int kb) {      // unconditional loads, first touched in lstore() (latency hides under the MFMAs)
-    const int i0 = kb + st.row0, i1 = kb + st.row1;
-    const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1);
-    rk0 = ldg8(hm_ptr(qkv, M, H + w.h, r0) + st.part0 * 8); rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r0) + st.part0 * 8);
-    rk1 = ldg8(hm_ptr(qkv, M, H + w.h, r1) + st.part1 * 8); rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r1) + st.part1 * 8);
-    ok0 = sq.valid(i0); ok1 = sq.valid(i1);
+  auto gload = [&](int t, auto full_tag) {      // first touched in lstore() (latency hides under the MFMAs)
+    const int kb = t * 64;
+    if (decltype(full_tag)::value) {
+      const long adv = (long)kb * sq.dr * HD;
+      rk0 = ldg8_off(kbase + adv, c0); rv0 = ldg8_off(vbase + adv, c0);
+      rk1 = ldg8_off(kbase + adv, c1); rv1 = ldg8_off(vbase + adv, c1);
+    } else {      // ragged tile: clamped rows, zeroed by a select in lstore()
+      const int i0 = kb + st.row0, i1 = kb + st.row1;
+      const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1);
+      rk0 = ldg8(hm_ptr(qkv, M, H + w.h, r0) + st.part0 * 8); rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r0) + st.part0 * 8);
+      rk1 = ldg8(hm_ptr(qkv, M, H + w.h, r1) + st.part1 * 8); rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r1) + st.part1 * 8);
+      ok0 = sq.valid(i0); ok1 = sq.valid(i1);
+    }
   };
-  auto lstore = [&](int buf) {
-    const h16x8 k0 = sel8(ok0, rk0), v0 = sel8(ok0, rv0);
+  auto lstore = [&](int buf, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const h16x8 k0 = FULL ? rk0 : sel8(ok0, rk0), v0 = FULL ? rv0 : sel8(ok0, rv0);
     *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = k0;
     *reinterpret_cast<h16x8*>(&Kt[buf][st.row0 * VSTR + st.part0 * 8]) = k0;
     *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * KSTR + st.part0 * 8]) = v0;
     if (st.has1) {
-      const h16x8 k1 = sel8(ok1, rk1), v1 = sel8(ok1, rv1);
+      const h16x8 k1 = FULL ? rk1 : sel8(ok1, rk1), v1 = FULL ? rv1 : sel8(ok1, rv1);
       *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = k1;
       *reinterpret_cast<h16x8*>(&Kt[buf][st.row1 * VSTR + st.part1 * 8]) = k1;
       *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * KSTR + st.part1 * 8]) = v1;
@@ -527,15 +596,15 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   f32x16 dq0, dq1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq0[i] = 0.f; dq1[i] = 0.f; }
-  const int ntile = (sq.n + 63) / 64;
-  gload(0);
-  lstore(0);
+  gload(0, std::false_type{});
+  lstore(0, std::false_type{});
   __syncthreads();
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  auto tile = [&](int t, auto tail_tag) {
+  // tail_tag: the tile holds keys >= n (tile padding, excluded); next_tag: tile t + 1 is a full tile
+  auto tile = [&](int t, auto tail_tag, auto next_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = t & 1, kb = t * 64;
-    if (t + 1 < ntile) gload(kb + 64);
+    if (t + 1 < ntile) gload(t + 1, next_tag);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -550,13 +619,16 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
       }
       h16x8 dsf[2];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float pt = __builtin_amdgcn_exp2f(fmaf(s[i], c, -L2));
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 pt = pk_exp2(pk_fma((f32x2){s[i], s[i + 1]}, c2, nl22));
         if (TAIL) {
           const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (kidx >= sq.n) pt = 0.f;
+          if (kidx >= sq.n) pt[0] = 0.f;
+          if (kidx + 1 >= sq.n) pt[1] = 0.f;
         }
-        dsf[i >> 3][i & 7] = (h16)(pt * (dp[i] - delta) * scale);
+        const f32x2 d = pt * ((f32x2){dp[i], dp[i + 1]} + ndl2);
+        dsf[i >> 3][i & 7] = (h16)d[0];
+        dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -567,12 +639,14 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
         dq1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, dsf[s2], dq1, 0, 0, 0);
       }
     }
-    if (t + 1 < ntile) lstore(buf ^ 1);
+    if (t + 1 < ntile) lstore(buf ^ 1, next_tag);
     __syncthreads();
   };
-  const int nfull = (sq.n & 63) ? ntile - 1 : ntile;
-  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
-  if (nfull < ntile) tile(ntile - 1, std::true_type{});
+  int t = 0;
+  for (; t + 1 < nfull; ++t) tile(t, std::false_type{}, std::true_type{});
+  const int nmask = (sq.n & 63) ? ntile - 1 : ntile;          // tiles >= nmask contain keys >= n
+  for (; t < nmask; ++t) tile(t, std::false_type{}, std::false_type{});
+  for (; t < ntile; ++t) tile(t, std::true_type{}, std::false_type{});
   if (qvalid) {
     h16* out = ws + ws_slot(p, w, iq);
 #pragma unroll
@@ -593,8 +667,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 // sweeping the queries of the same sparse sequence in tiles of 64.
 //   S[q,key]  = Q . K^T            Q rows from LDS, K^T in registers
 //   dP[q,key] = dO . V^T           dO rows from LDS, V^T in registers
-//   P~ = exp2(c S - L2[q]) ; dS = P~ (dP - delta[q]) / sqrt(48)
-//   dV^T[d,key] += dO^T[d,q] . P~   ; dK^T[d,key] += Q^T[d,q] . dS      (transposed LDS reads of dO / Q)
+//   P' = exp2(c S - L2[q] + log2(scale)) ; dS = P' (dP - delta[q])        (P' = P~ / sqrt(48))
+//   dV^T[d,key] += dO^T[d,q] . P'  (rescaled by sqrt(48) once at the end) ; dK^T[d,key] += Q^T[d,q] . dS
+// LDS holds -L2 + log2(scale) and -delta per query so the elementwise block is 2 packed fma/add, 2 exp, 1 packed mul
+// and 2 packed converts per element pair.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
@@ -610,7 +686,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
-  const float scale = 0.14433756729740643f, c = scale * LOG2E;
+  const float c = 0.14433756729740643f * LOG2E;
+  const f32x2 c2 = {c, c};
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   if (tid < 64) {
@@ -630,47 +707,65 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   }
 
   const StageIdx st(tid);
+  const int ntile = (sq.n + 63) / 64;
+  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);   // tiles [0, nfull) hold only real rows
+  const h16* qbase = hm_ptr(qkv, M, w.h, sq.row(0));
+  const h16* dbase = hm_ptr(dmixed, M, w.h, sq.row(0));
+  const float* lbase = lse_tot + sq.row(0) * H + w.h;
+  const float* dlbase = delta_br + ((long)w.br * M + sq.row(0)) * H + w.h;
+  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
+  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
+  const uint32_t cl = (uint32_t)(lane * sq.dr * H) * 4u;
   h16x8 rq0, rq1, rd0, rd1;
   float rl2 = 0.f, rdl = 0.f;
   bool ok0 = false, ok1 = false, ok2 = false;
-  auto gload = [&](int qb) {      // unconditional loads, first touched in lstore()
-    const int i0 = qb + st.row0, i1 = qb + st.row1, i2 = qb + (tid & 63);
-    const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1), r2 = sq.row_clamped(i2);
-    rq0 = ldg8(hm_ptr(qkv, M, w.h, r0) + st.part0 * 8); rd0 = ldg8(hm_ptr(dmixed, M, w.h, r0) + st.part0 * 8);
-    rq1 = ldg8(hm_ptr(qkv, M, w.h, r1) + st.part1 * 8); rd1 = ldg8(hm_ptr(dmixed, M, w.h, r1) + st.part1 * 8);
-    rl2 = lse_tot[r2 * H + w.h]; rdl = delta_br[((long)w.br * M + r2) * H + w.h];
-    ok0 = sq.valid(i0); ok1 = sq.valid(i1); ok2 = sq.valid(i2);
+  auto gload = [&](int t, auto full_tag) {      // first touched in lstore()
+    const int qb = t * 64;
+    if (decltype(full_tag)::value) {
+      const long adv = (long)qb * sq.dr * HD, advl = (long)qb * sq.dr * H;
+      rq0 = ldg8_off(qbase + adv, c0); rd0 = ldg8_off(dbase + adv, c0);
+      rq1 = ldg8_off(qbase + adv, c1); rd1 = ldg8_off(dbase + adv, c1);
+      rl2 = ldf_off(lbase + advl, cl); rdl = ldf_off(dlbase + advl, cl);
+    } else {      // ragged tile: clamped rows, neutralised in lstore()
+      const int i0 = qb + st.row0, i1 = qb + st.row1, i2 = qb + lane;
+      const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1), r2 = sq.row_clamped(i2);
+      rq0 = ldg8(hm_ptr(qkv, M, w.h, r0) + st.part0 * 8); rd0 = ldg8(hm_ptr(dmixed, M, w.h, r0) + st.part0 * 8);
+      rq1 = ldg8(hm_ptr(qkv, M, w.h, r1) + st.part1 * 8); rd1 = ldg8(hm_ptr(dmixed, M, w.h, r1) + st.part1 * 8);
+      rl2 = lse_tot[r2 * H + w.h]; rdl = delta_br[((long)w.br * M + r2) * H + w.h];
+      ok0 = sq.valid(i0); ok1 = sq.valid(i1); ok2 = sq.valid(i2);
+    }
   };
-  auto lstore = [&]() {
-    const h16x8 q0 = sel8(ok0, rq0), d0 = sel8(ok0, rd0);
+  auto lstore = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const h16x8 q0 = FULL ? rq0 : sel8(ok0, rq0), d0 = FULL ? rd0 : sel8(ok0, rd0);
     *reinterpret_cast<h16x8*>(&Qs[st.row0 * KSTR + st.part0 * 8]) = q0;
     *reinterpret_cast<h16x8*>(&Qt[st.row0 * VSTR + st.part0 * 8]) = q0;
     *reinterpret_cast<h16x8*>(&Ds[st.row0 * KSTR + st.part0 * 8]) = d0;
     *reinterpret_cast<h16x8*>(&Dt[st.row0 * VSTR + st.part0 * 8]) = d0;
     if (st.has1) {
-      const h16x8 q1 = sel8(ok1, rq1), d1 = sel8(ok1, rd1);
+      const h16x8 q1 = FULL ? rq1 : sel8(ok1, rq1), d1 = FULL ? rd1 : sel8(ok1, rd1);
       *reinterpret_cast<h16x8*>(&Qs[st.row1 * KSTR + st.part1 * 8]) = q1;
       *reinterpret_cast<h16x8*>(&Qt[st.row1 * VSTR + st.part1 * 8]) = q1;
       *reinterpret_cast<h16x8*>(&Ds[st.row1 * KSTR + st.part1 * 8]) = d1;
       *reinterpret_cast<h16x8*>(&Dt[st.row1 * VSTR + st.part1 * 8]) = d1;
     }
-    if (tid < 64) {      // padded / out-of-range queries contribute nothing: L2 = +big -> P~ = 0
-      L2s[tid] = ok2 ? rl2 * LOG2E : 1.0e30f;
-      Dls[tid] = ok2 ? rdl : 0.f;
+    if (tid < 64) {      // padded / out-of-range queries contribute nothing: -L2 = -big -> P' = 0
+      const bool ok = FULL || ok2;
+      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) : -1.0e30f;
+      Dls[tid] = ok ? -rdl : 0.f;
     }
   };
 
   f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
-  const int ntile = (sq.n + 63) / 64;
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  gload(0);
-  for (int t = 0; t < ntile; ++t) {
+  // cur_tag: tile t (in registers) is a full tile; next_tag: tile t + 1 is
+  auto tile = [&](int t, auto cur_tag, auto next_tag) {
     __syncthreads();            // previous tile fully consumed
-    lstore();
+    lstore(cur_tag);
     __syncthreads();
-    if (t + 1 < ntile) gload((t + 1) * 64);
+    if (t + 1 < ntile) gload(t + 1, next_tag);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -687,14 +782,15 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
       h16x8 pf[2], dsf[2];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 l2 = *reinterpret_cast<const f32x4*>(&L2s[sub * 32 + 8 * g4 + 4 * hh]);
-        const f32x4 dl = *reinterpret_cast<const f32x4*>(&Dls[sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 nl2 = *reinterpret_cast<const f32x4*>(&L2s[sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 ndl = *reinterpret_cast<const f32x4*>(&Dls[sub * 32 + 8 * g4 + 4 * hh]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; e += 2) {
           const int i = 4 * g4 + e;
-          const float pt = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l2[e]));
-          pf[i >> 3][i & 7] = (h16)pt;
-          dsf[i >> 3][i & 7] = (h16)(pt * (dp[i] - dl[e]) * scale);
+          const f32x2 pt = pk_exp2(pk_fma((f32x2){s[i], s[i + 1]}, c2, (f32x2){nl2[e], nl2[e + 1]}));
+          const f32x2 d = pt * ((f32x2){dp[i], dp[i + 1]} + (f32x2){ndl[e], ndl[e + 1]});
+          pf[i >> 3][i & 7] = (h16)pt[0]; pf[i >> 3][(i & 7) + 1] = (h16)pt[1];
+          dsf[i >> 3][i & 7] = (h16)d[0]; dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
         }
       }
 #pragma unroll
@@ -710,21 +806,29 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, dsf[s2], dk1, 0, 0, 0);
       }
     }
-  }
+  };
+  if (nfull > 0) gload(0, std::true_type{});
+  else gload(0, std::false_type{});
+  int t = 0;
+  for (; t + 1 < nfull; ++t) tile(t, std::true_type{}, std::true_type{});
+  if (t < nfull) { tile(t, std::true_type{}, std::false_type{}); ++t; }     // last full tile, ragged successor
+  for (; t < ntile; ++t) tile(t, std::false_type{}, std::false_type{});
   if (kvalid) {
     h16* outk = ws + ws_slot(p, w, ik) + HD;
     h16* outv = outk + HD;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const h16x4 a = {(h16)dk0[4 * gq], (h16)dk0[4 * gq + 1], (h16)dk0[4 * gq + 2], (h16)dk0[4 * gq + 3]};
-      const h16x4 b = {(h16)dv0[4 * gq], (h16)dv0[4 * gq + 1], (h16)dv0[4 * gq + 2], (h16)dv0[4 * gq + 3]};
+      const h16x4 b = {(h16)(dv0[4 * gq] * INV_SCALE), (h16)(dv0[4 * gq + 1] * INV_SCALE), (h16)(dv0[4 * gq + 2] * INV_SCALE),
+                       (h16)(dv0[4 * gq + 3] * INV_SCALE)};
       *reinterpret_cast<h16x4*>(outk + 8 * gq + 4 * hh) = a;
       *reinterpret_cast<h16x4*>(outv + 8 * gq + 4 * hh) = b;
     }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
       const h16x4 a = {(h16)dk1[4 * gq], (h16)dk1[4 * gq + 1], (h16)dk1[4 * gq + 2], (h16)dk1[4 * gq + 3]};
-      const h16x4 b = {(h16)dv1[4 * gq], (h16)dv1[4 * gq + 1], (h16)dv1[4 * gq + 2], (h16)dv1[4 * gq + 3]};
+      const h16x4 b = {(h16)(dv1[4 * gq] * INV_SCALE), (h16)(dv1[4 * gq + 1] * INV_SCALE), (h16)(dv1[4 * gq + 2] * INV_SCALE),
+                       (h16)(dv1[4 * gq + 3] * INV_SCALE)};
       *reinterpret_cast<h16x4*>(outk + 32 + 8 * gq + 4 * hh) = a;
       *reinterpret_cast<h16x4*>(outv + 32 + 8 * gq + 4 * hh) = b;
     }
