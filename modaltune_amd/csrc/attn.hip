@@ -12,172 +12,9 @@
 //   S^T[key, q] = K . Q^T           v_mfma_f32_32x32x16_f16, K rows from LDS (ds_read_b128), Q^T in registers
 //   O^T[d, q]  += V^T[d, key] . P^T  P^T taken straight from the S accumulators (no LDS round trip),
 //                                    V^T via ds_read_b64_tr_b16; V carries a ones column so O^T row 48 = sum(P)
-#include <stdlib.h>
-#include <type_traits>
-
-#include "common.h"
+#include "attn_common.h"
 
 namespace {
-
-constexpr int H = 16, HD = 48, DM = 768, QKV_LD = 2304;
-constexpr int KSTR = 56;    // halves per K-layout LDS row (112 B: conflict-free ds_read_b128 row reads)
-constexpr int VSTR = 96;    // halves per V-layout LDS row (192 B: conflict-free ds_read_b64_tr_b16)
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-constexpr float NEG_BIG = -1.0e30f;
-constexpr float RESCALE_LOG2 = 8.0f;
-
-struct Plan {
-  int nbranch, N, B;
-  int seg[MT_MAX_BRANCHES], ratio[MT_MAX_BRANCHES], nseg[MT_MAX_BRANCHES], n[MT_MAX_BRANCHES];
-  int order[MT_MAX_BRANCHES], qtiles[MT_MAX_BRANCHES], blk_off[MT_MAX_BRANCHES + 1];
-  long ws_off[MT_MAX_BRANCHES + 1];   // backward workspace: per-branch compact [pass][seg][head][i][q|k|v][48] fp16
-};
-
-Plan make_plan(const MtDilatedPlan* p, int qtile) {
-  Plan d;
-  d.nbranch = p->nbranch; d.N = p->N; d.B = p->B;
-  for (int i = 0; i < p->nbranch; ++i) {
-    d.seg[i] = p->seg[i]; d.ratio[i] = p->ratio[i]; d.nseg[i] = p->nseg[i]; d.n[i] = p->n[i];
-    d.order[i] = i;
-    d.qtiles[i] = cdiv(p->n[i], qtile);
-  }
-  // longest sparse sequences first (their workgroups run longest)
-  for (int i = 0; i < d.nbranch; ++i)
-    for (int j = i + 1; j < d.nbranch; ++j)
-      if (d.n[d.order[j]] > d.n[d.order[i]]) { int t = d.order[i]; d.order[i] = d.order[j]; d.order[j] = t; }
-  d.blk_off[0] = 0;
-  for (int i = 0; i < d.nbranch; ++i) {
-    const int b = d.order[i];
-    d.blk_off[i + 1] = d.blk_off[i] + d.B * d.nseg[b] * H * d.qtiles[b];
-  }
-  d.ws_off[0] = 0;
-  for (int b = 0; b < d.nbranch; ++b) d.ws_off[b + 1] = d.ws_off[b] + (long)d.B * d.nseg[b] * H * d.n[b] * 3 * HD;
-  return d;
-}
-
-bool plan_ok(const MtDilatedPlan* p) {
-  if (!p || p->nbranch < 1 || p->nbranch > MT_MAX_BRANCHES || p->N < 1 || p->B < 1) return false;
-  for (int i = 0; i < p->nbranch; ++i) {
-    const int r = p->ratio[i], s = p->seg[i];
-    if (r < 1 || r > H || (H % r) != 0 || s < 1 || s > p->N) return false;
-    if (p->nseg[i] != cdiv(p->N, s) || p->n[i] != cdiv(s, r)) return false;
-  }
-  return true;
-}
-
-struct WorkItem { int br, b, j, h, qt; };
-
-// Workgroup -> work item.  Blocks b and b + 8 share an XCD (round-robin dispatch), so XCD x = bid % 8 walks its own
-// list j = bid / 8: per branch (longest sequences first) the (pass, segment, head) groups x, x + 8, x + 16, ... and,
-// inside a group, the query tiles back to back.  All query tiles of a group -- which re-read the same K/V rows --
-// therefore run on ONE XCD's L2, and every XCD gets the same mix of long and short sequences (each branch has a
-// multiple of 8 groups because there are 16 heads).  Placement only affects speed, never results.
-MT_DEVINL WorkItem decode(const Plan& p, int bid) {
-  const int x = bid & 7, j = bid >> 3;
-  int oi = 0;
-#pragma unroll
-  for (int i = 1; i < MT_MAX_BRANCHES; ++i)
-    if (i < p.nbranch && j >= (p.blk_off[i] >> 3)) oi = i;
-  WorkItem w;
-  w.br = p.order[oi];
-  int local = j - (p.blk_off[oi] >> 3);
-  w.qt = local % p.qtiles[w.br];
-  const int gid = (local / p.qtiles[w.br]) * 8 + x;     // group index inside the branch
-  w.h = gid % H;
-  const int r = gid / H;
-  w.j = r % p.nseg[w.br];
-  w.b = r / p.nseg[w.br];
-  // the divisions above run on the VALU: pin the (wave-uniform) results in SGPRs so everything derived from them --
-  // base pointers, tile counts, loop bounds -- stays scalar
-  w.br = __builtin_amdgcn_readfirstlane(w.br); w.qt = __builtin_amdgcn_readfirstlane(w.qt);
-  w.h = __builtin_amdgcn_readfirstlane(w.h); w.j = __builtin_amdgcn_readfirstlane(w.j);
-  w.b = __builtin_amdgcn_readfirstlane(w.b);
-  return w;
-}
-
-// single-branch launches (backward): same XCD-balanced walk over one branch
-MT_DEVINL WorkItem decode_branch(const Plan& p, int br, int bid) {
-  const int x = bid & 7, j = bid >> 3;
-  WorkItem w;
-  w.br = br;
-  w.qt = j % p.qtiles[br];
-  const int gid = (j / p.qtiles[br]) * 8 + x;
-  w.h = gid % H;
-  const int r = gid / H;
-  w.j = r % p.nseg[br];
-  w.b = r / p.nseg[br];
-  return w;
-}
-
-MT_DEVINL h16x4 lds_tr4(const h16* p) {
-  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)p);
-  return __builtin_bit_cast(h16x4, r);
-}
-MT_DEVINL h16x8 cat8(h16x4 lo, h16x4 hi) { return (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
-
-// geometry of one (branch, segment, head) sparse sequence
-struct Seq {
-  int n, s, dr, r, seg_base, N;
-  long row_base;   // b * N
-  MT_DEVINL bool valid(int i) const {
-    const int loc = r + i * dr;
-    return i < n && loc < s && seg_base + loc < N;
-  }
-  MT_DEVINL long row(int i) const { return row_base + seg_base + r + (long)i * dr; }
-  // always-in-bounds row for unconditional loads (the value is discarded with a select when !valid(i)):
-  // a branch around each load would make hipcc wait for every load separately (guide §5 trap (c))
-  MT_DEVINL long row_clamped(int i) const { return min(row(i), row_base + (long)N - 1); }
-  // valid(i) holds exactly for i < nvalid(): r + i dr < min(s, N - seg_base)
-  MT_DEVINL int nvalid() const {
-    const int lim = min(s, N - seg_base) - r;
-    return lim <= 0 ? 0 : min(n, (lim + dr - 1) / dr);
-  }
-};
-
-// q / k / v are HEAD-MAJOR: [which = q|k|v][head][B*N rows][48] (written that way by the QKV GEMM epilogue), so a
-// head's dilated key walk touches rows 96 * r bytes apart (contiguous for r = 1) instead of 4608 * r in the
-// token-major [B*N, 2304] layout; dmixed is head-major too ([head][B*N][48]).
-MT_DEVINL const h16* hm_ptr(const h16* base, long M, int slab, long row) { return base + ((long)slab * M + row) * HD; }
-
-// uniform base + 32-bit byte offset: one VGPR of address state per thread (global_load ... v_off, s[base]), no 64-bit
-// per-lane arithmetic in the tile loops
-MT_DEVINL h16x8 ldg8_off(const h16* base, uint32_t byte_off) {
-  return *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-MT_DEVINL float ldf_off(const float* base, uint32_t byte_off) {
-  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-MT_DEVINL f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-MT_DEVINL f32x2 pk_exp2(f32x2 a) { return (f32x2){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])}; }
-
-MT_DEVINL h16x8 sel8(bool ok, h16x8 v) {
-  const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-  return ok ? v : z;
-}
-
-// backward workspace slot of sparse entry i of work item w: 3 x 48 halves (dq | dk | dv)
-MT_DEVINL long ws_slot(const Plan& p, const WorkItem& w, int i) {
-  return p.ws_off[w.br] + ((((long)w.b * p.nseg[w.br] + w.j) * H + w.h) * p.n[w.br] + i) * (3 * HD);
-}
-
-MT_DEVINL Seq make_seq(const Plan& p, const WorkItem& w) {
-  Seq q;
-  q.n = p.n[w.br]; q.s = p.seg[w.br]; q.dr = p.ratio[w.br];
-  q.r = __builtin_amdgcn_readfirstlane(w.h / (H / q.dr));
-  q.seg_base = w.j * q.s; q.N = p.N; q.row_base = (long)w.b * p.N;
-  return q;
-}
-
-// Per-thread staging slots for a 64-row x 48-col fp16 tile = 384 chunks of 16 B: chunk tid, and (tid < 128) chunk 256+tid.
-struct StageIdx {
-  int row0, part0, row1, part1; bool has1;
-  MT_DEVINL StageIdx(int tid) {
-    row0 = tid / 6; part0 = tid - row0 * 6;
-    const int c = 256 + tid;
-    row1 = c / 6; part1 = c - row1 * 6; has1 = tid < 128;
-  }
-};
 
 // ------------------------------------------------------------------------------------------------
 // forward.  K and V tiles are double-buffered in LDS, one barrier per tile; the global loads of tile t+1 are issued
@@ -518,9 +355,6 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
 // The elementwise block is written with packed fp32 ops (v_pk_fma/add/mul_f32): these kernels issue about as many
 // VALU cycles as MFMA cycles, and the two did not overlap (PMC: VALU 49 %, MFMA 37 % busy before this form).
 // ------------------------------------------------------------------------------------------------
-constexpr float LOG2_SCALE = -2.7924812503605781f;   // log2(48^-1/2)
-constexpr float INV_SCALE = 6.9282032302755092f;     // sqrt(48)
-
 __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                  const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
                                                                  Plan p, h16* __restrict__ ws) {

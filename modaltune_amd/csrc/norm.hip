@@ -30,6 +30,12 @@ template <int D, typename InT, typename OutT, bool GELU>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   constexpr int NC = D / 256;   // 4-element chunks per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 wr[NC], br[NC];         // a lane always owns the same columns: affine parameters stay in registers across rows
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    wr[c] = Vec4<float>::load(a.w + c * 256 + lane * 4);
+    br[c] = Vec4<float>::load(a.b + c * 256 + lane * 4);
+  }
   for (int m = blockIdx.x * 4 + wave; m < a.M; m += gridDim.x * 4) {
     const InT* x = reinterpret_cast<const InT*>(a.x) + a.xmap.map(m) * a.ldx;
     f32x4 v[NC];
@@ -55,10 +61,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int col = c * 256 + lane * 4;
-      const f32x4 w = Vec4<float>::load(a.w + col), b = Vec4<float>::load(a.b + col);
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * w[e] + b[e];
+      for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * wr[c][e] + br[c][e];
       if (add) { const f32x4 p = Vec4<float>::load(add + col); o += p; }
       Vec4<OutT>::store(y + col, o);
     }
@@ -82,6 +87,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   f32x4 gw[NP], gb[NP];
 #pragma unroll
   for (int c = 0; c < NP; ++c) { gw[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; gb[c] = gw[c]; }
+  f32x4 wr[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) wr[c] = Vec4<float>::load(a.w + c * 256 + lane * 4);
   for (int m = blockIdx.x * 4 + wave; m < a.M; m += gridDim.x * 4) {
     const DyT* dy = reinterpret_cast<const DyT*>(a.dy) + a.dymap.map(m) * a.lddy;
     const InT* x = reinterpret_cast<const InT*>(a.x) + a.xmap.map(m) * a.ldx;
@@ -98,11 +106,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         for (int e = 0; e < 4; ++e) xv[e] = gelu_erf(xv[e]);
       }
       const f32x4 d = Vec4<DyT>::load(dy + col);
-      const f32x4 w = Vec4<float>::load(a.w + col);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         xh[c][e] = (xv[e] - mean) * rstd;
-        g[c][e] = d[e] * w[e];
+        g[c][e] = d[e] * wr[c][e];
         s1 += g[c][e];
         s2 += g[c][e] * xh[c][e];
       }
@@ -143,6 +150,172 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------- FFN sub-LayerNorm ---------------
+// y = LN(gelu(a1)) over D = 3072 (feedforward_network.py:136-139) and its backward, fp16 in / fp16 out.  These two
+// launches stream 0.37 / 0.55 GB per layer and were co-bound by the VALU (erf twice per element, scalar fp32 ops, the
+// affine vectors re-read per row): here a lane owns 8 consecutive columns per chunk (16-byte loads/stores), keeps
+// gamma/beta in registers across rows, evaluates erf ONCE for both gelu and gelu', and does the arithmetic with packed
+// fp32 instructions (v_pk_fma/mul/add_f32).
+MT_DEVINL f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+MT_DEVINL f32x2 splat2(float v) { return (f32x2){v, v}; }
+
+// gelu(x) and d gelu / dx for two values; A&S 7.1.26 erf as in common.h (|err| <= 1.5e-7)
+template <bool WANT_GRAD>
+MT_DEVINL void gelu_pair(f32x2 x, f32x2& g, f32x2& dg) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 z = ax * splat2(0.70710678118654752440f);
+  const f32x2 den = pk_fma2(z, splat2(0.3275911f), splat2(1.0f));
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 poly = pk_fma2(t, splat2(1.061405429f), splat2(-1.453152027f));
+  poly = pk_fma2(poly, t, splat2(1.421413741f));
+  poly = pk_fma2(poly, t, splat2(-0.284496736f));
+  poly = pk_fma2(poly, t, splat2(0.254829592f));
+  poly = poly * t;
+  const f32x2 ea = z * z * splat2(-1.4426950408889634f);
+  const f32x2 e = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+  const f32x2 r = pk_fma2(-poly, e, splat2(1.0f));                 // erf(|x| / sqrt 2)
+  const f32x2 er = {copysignf(r[0], x[0]), copysignf(r[1], x[1])};
+  const f32x2 h = pk_fma2(er, splat2(0.5f), splat2(0.5f));          // Phi(x)
+  g = x * h;
+  if (WANT_GRAD) dg = pk_fma2(x * splat2(0.39894228040143267794f), e, h);   // Phi(x) + x phi(x)
+}
+
+MT_DEVINL void cvt8(h16x8 v, f32x2 (&o)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (f32x2){(float)v[2 * i], (float)v[2 * i + 1]};
+}
+MT_DEVINL h16x8 pack8(const f32x2 (&o)[4]) {
+  h16x8 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = (h16)o[i][0]; v[2 * i + 1] = (h16)o[i][1]; }
+  return v;
+}
+MT_DEVINL void ldf8(const float* p, f32x2 (&o)[4]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  o[0] = (f32x2){a[0], a[1]}; o[1] = (f32x2){a[2], a[3]}; o[2] = (f32x2){b[0], b[1]}; o[3] = (f32x2){b[2], b[3]};
+}
+
+// Two waves per row (a lane owns D / 128 columns in chunks of 8): ~100 VGPRs, 4-5 waves per SIMD of loads in flight.
+// Row statistics cross the wave pair through LDS.
+template <int D>
+__global__ __launch_bounds__(256) void ln_gelu_fwd_kernel(LnFwdArgs a) {
+  constexpr int NC = D / 1024;   // 8-element chunks per lane
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = wave & 1, rsel = wave >> 1;
+  const int col0 = half * (D / 2) + lane * 8;
+  f32x2 wr[NC][4], br[NC][4];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { ldf8(a.w + col0 + c * 512, wr[c]); ldf8(a.b + col0 + c * 512, br[c]); }
+  for (int base = blockIdx.x * 2; base < a.M; base += gridDim.x * 2) {
+    const int m = base + rsel;
+    const bool valid = m < a.M;
+    const int mc = valid ? m : a.M - 1;
+    const h16* x = reinterpret_cast<const h16*>(a.x) + a.xmap.map(mc) * a.ldx;
+    h16x8 raw[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) raw[c] = ldg8(x + col0 + c * 512);
+    f32x2 v[NC][4];
+    f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x2 xv[4];
+      cvt8(raw[c], xv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f32x2 dg; gelu_pair<false>(xv[i], v[c][i], dg); s2 += v[c][i]; }
+    }
+    const float ps = wave_sum(s2[0] + s2[1]);
+    if (lane == 0) red[0][wave] = ps;
+    __syncthreads();
+    const float mean = (red[0][2 * rsel] + red[0][2 * rsel + 1]) * (1.0f / D);
+    f32x2 q2 = {0.f, 0.f};
+    const f32x2 nm = splat2(-mean);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[c][i] += nm; q2 = pk_fma2(v[c][i], v[c][i], q2); }
+    const float pq = wave_sum(q2[0] + q2[1]);
+    if (lane == 0) red[1][wave] = pq;
+    __syncthreads();
+    const float rstd = rsqrtf((red[1][2 * rsel] + red[1][2 * rsel + 1]) * (1.0f / D) + 1e-5f);
+    if (valid) {
+      h16* y = reinterpret_cast<h16*>(a.y) + a.ymap.map(m) * a.ldy;
+      const f32x2 rs = splat2(rstd);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        f32x2 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pk_fma2(v[c][i] * rs, wr[c][i], br[c][i]);
+        stg8(y + col0 + c * 512, pack8(o));
+      }
+      if (a.stats && lane == 0 && half == 0) { a.stats[2 * (long)m] = mean; a.stats[2 * (long)m + 1] = rstd; }
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(LnBwdArgs a) {
+  constexpr int NC = D / 1024;
+  __shared__ float red[2][2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = wave & 1, rsel = wave >> 1;
+  const int col0 = half * (D / 2) + lane * 8;
+  f32x2 wr[NC][4];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) ldf8(a.w + col0 + c * 512, wr[c]);
+  int it = 0;
+  for (int base = blockIdx.x * 2; base < a.M; base += gridDim.x * 2, it ^= 1) {
+    const int m = base + rsel;
+    const bool valid = m < a.M;
+    const int mc = valid ? m : a.M - 1;
+    const h16* dy = reinterpret_cast<const h16*>(a.dy) + a.dymap.map(mc) * a.lddy;
+    const h16* x = reinterpret_cast<const h16*>(a.x) + a.xmap.map(mc) * a.ldx;
+    h16x8 rx[NC], rd[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { rx[c] = ldg8(x + col0 + c * 512); rd[c] = ldg8(dy + col0 + c * 512); }
+    const float mean = a.stats[2 * (long)mc], rstd = a.stats[2 * (long)mc + 1];
+    const f32x2 rs = splat2(rstd), nmr = splat2(-mean * rstd);
+    f32x2 xh[NC][4], g[NC][4], dgl[NC][4];
+    f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x2 xv[4], dv[4];
+      cvt8(rx[c], xv); cvt8(rd[c], dv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x2 gl;
+        gelu_pair<true>(xv[i], gl, dgl[c][i]);
+        xh[c][i] = pk_fma2(gl, rs, nmr);
+        g[c][i] = dv[i] * wr[c][i];
+        s1 += g[c][i];
+        s2 = pk_fma2(g[c][i], xh[c][i], s2);
+      }
+    }
+    const float p1 = wave_sum(s1[0] + s1[1]), p2 = wave_sum(s2[0] + s2[1]);
+    if (lane == 0) { red[it][0][wave] = p1; red[it][1][wave] = p2; }      // double-buffered: one barrier per row pair
+    __syncthreads();
+    const float c1 = (red[it][0][2 * rsel] + red[it][0][2 * rsel + 1]) * (1.0f / D);
+    const float c2 = (red[it][1][2 * rsel] + red[it][1][2 * rsel + 1]) * (1.0f / D);
+    if (valid) {
+      h16* dx = reinterpret_cast<h16*>(a.dx) + a.dxmap.map(m) * a.lddx;
+      const f32x2 nc1 = splat2(-c1), nc2 = splat2(-c2);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        f32x2 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (pk_fma2(xh[c][i], nc2, g[c][i]) + nc1) * (dgl[c][i] * rs);
+        if (a.accumulate) {
+          f32x2 old[4];
+          cvt8(ldg8(dx + col0 + c * 512), old);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] += old[i];
+        }
+        stg8(dx + col0 + c * 512, pack8(o));
+      }
+    }
+  }
+}
+
+int ln_gelu_grid(int M) { return max(1, min(cdiv(M, 2), 8192)); }
 int ln_grid(int M) { return max(1, min(cdiv(M, 4), 4096)); }
 
 template <int D, typename InT, typename OutT>
@@ -154,6 +327,13 @@ int ln_fwd_dispatch(const LnFwdArgs& a, int gelu, hipStream_t s) {
 }
 template <int D>
 int ln_fwd_types(const LnFwdArgs& a, int in_dt, int out_dt, int gelu, hipStream_t s) {
+  if constexpr (D % 1024 == 0) {
+    if (gelu && in_dt == MT_OUT_F16 && out_dt == MT_OUT_F16 && !a.add_rows && !(a.ldx & 7) && !(a.ldy & 7)) {
+      hipLaunchKernelGGL((ln_gelu_fwd_kernel<D>), dim3(ln_gelu_grid(a.M)), dim3(256), 0, s, a);
+      MT_CHECK_LAUNCH();
+      return MT_OK;
+    }
+  }
   if (in_dt == MT_OUT_F32 && out_dt == MT_OUT_F16) return ln_fwd_dispatch<D, float, h16>(a, gelu, s);
   if (in_dt == MT_OUT_F32 && out_dt == MT_OUT_F32) return ln_fwd_dispatch<D, float, float>(a, gelu, s);
   if (in_dt == MT_OUT_F16 && out_dt == MT_OUT_F16) return ln_fwd_dispatch<D, h16, h16>(a, gelu, s);
@@ -317,6 +497,13 @@ template <int D>
 static int ln_bwd_types(const LnBwdArgs& a, int dy_dt, int in_dt, int dx_dt, int gelu, hipStream_t s) {
   const bool dyh = dy_dt == MT_OUT_F16, inh = in_dt == MT_OUT_F16, dxh = dx_dt == MT_OUT_F16;
   if (gelu) {
+    if constexpr (D % 1024 == 0) {
+      if (dyh && inh && dxh && !a.dw && !(a.lddy & 7) && !(a.ldx & 7) && !(a.lddx & 7)) {
+        hipLaunchKernelGGL((ln_gelu_bwd_kernel<D>), dim3(ln_gelu_grid(a.M)), dim3(256), 0, s, a);
+        MT_CHECK_LAUNCH();
+        return MT_OK;
+      }
+    }
     if (dyh && inh && dxh) return ln_bwd_launch<D, h16, h16, h16, true>(a, s);
     return MT_ERR_UNSUPPORTED;
   }

@@ -6,6 +6,7 @@ the current HIP stream.  No arithmetic happens here.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -268,7 +269,8 @@ extract_attn_fwd = _timed(lambda *a, **k: "extract_attn_fwd")(extract_attn_fwd)
 extract_attn_bwd = _timed(lambda *a, **k: "extract_attn_bwd")(extract_attn_bwd)
 inject_resid_bwd = _timed(lambda *a, **k: "inject_resid_bwd")(inject_resid_bwd)
 colsum = _timed(lambda *a, **k: "colsum")(colsum)
-sgemm = _timed(lambda *a, **k: "token_side")(sgemm)
+_DETAIL = bool(os.environ.get("MT_TIMER_DETAIL"))
+sgemm = _timed(lambda A, a_str, B, b_str, Cm, c_str, M, N, K, **k: (f"sgemm[{M}x{N}x{K} b{k.get('batch', 1)}]" if _DETAIL else "token_side"))(sgemm)
 adamw_step = _timed(lambda *a, **k: "adamw")(adamw_step)
 
 
