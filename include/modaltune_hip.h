@@ -73,7 +73,7 @@ int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_ha
 int mt_gemm_tn_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* B, long ldb, const MtRowMap* bmap,
                    int M, int N1, int N2, float* C, long ldc, mt_stream_t stream);
 
-/* out[n] (fp32) += sum_m A[m,n]: bias gradient of a big-M nn.Linear */
+/* out[n] (fp32) += sum_m A[m,n]: bias gradient of a big-M nn.Linear.  N % 8 == 0, lda % 8 == 0 (16-byte loads). */
 int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, int M, int N, float* out, mt_stream_t stream);
 
 /* Generic small strided fp32 GEMM for the token-side ops (T <= 66 rows; gene encoder GE:194-223, prompt
@@ -96,11 +96,13 @@ int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, int in_dtype
 
 /* dx (+)= LN backward.  dy fp16 or fp32 [M,D]; x as in forward (gelu_in: also backprop through the GELU).
  * dx_dtype F32 with accumulate=1 adds into the fp32 residual-gradient stream (ENC:137-154 backward);
- * dw/db (fp32 [D], atomically accumulated) may be NULL for frozen norms (selective backward). */
+ * dw/db (fp32 [D], atomically accumulated) may be NULL for frozen norms (selective backward).
+ * dx_f16 (dense fp16 [M,D], or NULL): a second, half-precision copy of the final dx -- the operand of the next dX GEMM
+ * of the frozen layer below, written here instead of by a separate cast pass over the fp32 stream. */
 int mt_layernorm_bwd(const void* dy, long lddy, const MtRowMap* dymap, int dy_dtype, const void* x, long ldx,
                      const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w, const float* stats, void* dx,
-                     long lddx, const MtRowMap* dxmap, int dx_dtype, int accumulate, float* dw, float* db, int M, int D,
-                     mt_stream_t stream);
+                     long lddx, const MtRowMap* dxmap, int dx_dtype, int accumulate, float* dw, float* db,
+                     mt_half* dx_f16, int M, int D, mt_stream_t stream);
 
 /* ------------------------------------------------------- dilated attention ------------------------- */
 #define MT_MAX_BRANCHES 8

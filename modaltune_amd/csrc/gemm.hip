@@ -282,19 +282,32 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     }
 }
 
+// block = 32 column groups of 8 (16-byte loads) x 8 row lanes over a slab of rows; one atomic per column per block
 __global__ __launch_bounds__(256) void colsum_kernel(const h16* A, long lda, RowMap amap, int M, int N,
                                                      int rows_per_block, float* out) {
-  // block = 64 columns x 4 row-lanes; each thread strides rows
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + cg * 8;
   const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
-  float s = 0.f;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
   if (col < N)
-    for (int m = mbeg + rl; m < mend; m += 4) s += (float)A[amap.map(m) * lda + col];
-  __shared__ float red[256];
-  red[threadIdx.x] = s;
+    for (int m = mbeg + rl; m < mend; m += 8) {
+      const h16x8 v = ldg8(A + amap.map(m) * lda + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+  __shared__ float red[8][256 + 8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = s[e];
   __syncthreads();
-  if (rl == 0 && col < N) atomicAdd(&out[col], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
+    atomicAdd(&out[blockIdx.x * 256 + c], t);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,9 +430,9 @@ extern "C" int mt_gemm_tn_f16(const mt_half* A, long lda, const MtRowMap* amap, 
 
 extern "C" int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, int M, int N, float* out,
                              mt_stream_t stream) {
-  if (!A || !out || M <= 0 || N <= 0) return MT_ERR_BAD_ARG;
-  const int rows_per_block = 512;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream,
+  if (!A || !out || M <= 0 || N <= 0 || (N & 7) || (lda & 7)) return MT_ERR_BAD_ARG;
+  const int rows_per_block = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream,
                      (const h16*)A, lda, make_rowmap(amap), M, N, rows_per_block, out);
   MT_CHECK_LAUNCH();
   return MT_OK;

@@ -76,7 +76,7 @@ struct LnBwdArgs {
   const void* x; long ldx; RowMap xmap;
   const float* w; const float* stats;
   void* dx; long lddx; RowMap dxmap; int accumulate;
-  float* dw; float* db; int M;
+  float* dw; float* db; h16* dx16; int M;
 };
 
 template <int D, typename DyT, typename InT, typename DxT, bool GELU, bool PARAM>
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
       }
       if (a.accumulate) { const f32x4 old = Vec4<DxT>::load(dx + col); o += old; }
       Vec4<DxT>::store(dx + col, o);
+      if (a.dx16) Vec4<h16>::store(a.dx16 + (long)m * D + col, o);
     }
   }
   if (PARAM) {
@@ -516,9 +517,11 @@ static int ln_bwd_types(const LnBwdArgs& a, int dy_dt, int in_dt, int dx_dt, int
 extern "C" int mt_layernorm_bwd(const void* dy, long lddy, const MtRowMap* dymap, int dy_dtype, const void* x,
                                 long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w,
                                 const float* stats, void* dx, long lddx, const MtRowMap* dxmap, int dx_dtype,
-                                int accumulate, float* dw, float* db, int M, int D, mt_stream_t stream) {
+                                int accumulate, float* dw, float* db, mt_half* dx_f16, int M, int D, mt_stream_t stream) {
   if (!dy || !x || !w || !stats || !dx || M <= 0 || (!dw) != (!db)) return MT_ERR_BAD_ARG;
-  LnBwdArgs a{dy, lddy, make_rowmap(dymap), x, ldx, make_rowmap(xmap), w, stats, dx, lddx, make_rowmap(dxmap), accumulate, dw, db, M};
+  if (dx_f16 && gelu_in) return MT_ERR_UNSUPPORTED;
+  LnBwdArgs a{dy, lddy, make_rowmap(dymap), x, ldx, make_rowmap(xmap), w, stats, dx, lddx, make_rowmap(dxmap), accumulate, dw, db,
+              (h16*)dx_f16, M};
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
     case 256: return ln_bwd_types<256>(a, dy_dtype, in_dtype, dx_dtype, gelu_in, s);

@@ -203,6 +203,7 @@ class Engine:
         w["t16"] = e16(M, Fd)
         w["dh"] = e32(M, D)
         w["dy16"] = e16(M, D)
+        w["dh16"] = e16(M, D)
         w["dt16"] = e16(M, Fd)
         w["da1"] = e16(M, Fd)
         w["dmixed"] = e16(M, D)
@@ -497,21 +498,29 @@ class Engine:
         ops.layernorm_fwd(a1, t[p + "ffn.ffn_layernorm.weight"], t[p + "ffn.ffn_layernorm.bias"], t16, stf, M, Fd, gelu_in=True)
         ops.gemm_nt(t16, f16[p + "fc2"].w, out, M, D, Fd, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "ffn.fc2.bias"], resid=hmid, ldr=D)
 
+        # nothing else touches dh between two layers of one interaction block: the lower layer can take fp16(dh) from here
+        feeds_lower = all(l != a for a, _ in cfg.interaction_indexes)
+
         def bwd():
             dh, dy16, dt16, da1 = ws["dh"], ws["dy16"], ws["dt16"], ws["da1"]
             # FFN: out = hmid + fc2(LN(gelu(fc1(LN(hmid)))))
-            ops.cast_f32_to_f16(dh, dy16)
-            ops.gemm_nt(dy16, f16[p + "fc2"].wt, dt16, M, Fd, D)
+            if ctx.get("dh16_valid"):             # the layer above left fp16(dh) behind (LN backward's second output)
+                src16 = ws["dh16"]
+            else:
+                ops.cast_f32_to_f16(dh, dy16)
+                src16 = dy16
+            ops.gemm_nt(src16, f16[p + "fc2"].wt, dt16, M, Fd, D)
             ops.layernorm_bwd(dt16, a1, t[p + "ffn.ffn_layernorm.weight"], stf, da1, M, Fd, gelu_in=True)
             ops.gemm_nt(da1, f16[p + "fc1"].wt, dy16, M, D, Fd)
-            ops.layernorm_bwd(dy16, hmid, t[p + "final_layer_norm.weight"], st2, dh, M, D, accumulate=True)
+            ops.layernorm_bwd(dy16, hmid, t[p + "final_layer_norm.weight"], st2, dh, M, D, accumulate=True, dx16=ws["dh16"])
             # attention: hmid = hin + out_proj(LN(mix(dilated(qkv(LN(hin))))))
-            ops.cast_f32_to_f16(dh, dy16)
-            ops.gemm_nt(dy16, f16[p + "out"].wt, u16, M, D, D)
+            ops.gemm_nt(ws["dh16"], f16[p + "out"].wt, u16, M, D, D)
             ops.dilated_mix_ln_bwd(u16, obr, lsebr, lsetot, plan, t[p + "self_attn.inner_attn_ln.weight"], stin, ws["dmixed"], ws["delta"])
             ops.dilated_attn_bwd(qkv, ws["dmixed"], lsetot, ws["delta"], plan, ws["attn_ws"], ws["dqkv16"])
             ops.gemm_nt(ws["dqkv16"], f16[p + "qkv"].wt, dy16, M, D, 3 * D)
-            ops.layernorm_bwd(dy16, hin, t[p + "self_attn_layer_norm.weight"], st1, dh, M, D, accumulate=True)
+            ops.layernorm_bwd(dy16, hin, t[p + "self_attn_layer_norm.weight"], st1, dh, M, D, accumulate=True,
+                              dx16=ws["dh16"] if feeds_lower else None)
+            ctx["dh16_valid"] = feeds_lower
         self.tape.record(bwd)
 
     # ------------------------------------------------------------------ extractor (A.2)
@@ -584,6 +593,7 @@ class Engine:
         def bwd_gather():
             dh = ws["dh"]
             dh.zero_()                       # start of the patch-side backward: only the cls rows carry gradient
+            ctx["dh16_valid"] = False
             if cls.grad is not None:
                 ops.copy_rows(cls.grad, dh, B, D, dmap=rowmap(1, N, 0))
             cg = c.g()

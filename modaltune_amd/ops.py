@@ -95,11 +95,11 @@ def layernorm_fwd(x, w, b, y, stats, M, D, *, ldx=None, xmap=None, ldy=None, yma
 
 
 def layernorm_bwd(dy, x, w, stats, dx, M, D, *, lddy=None, dymap=None, ldx=None, xmap=None, lddx=None, dxmap=None,
-                  gelu_in=False, accumulate=False, dw=None, db=None):
+                  gelu_in=False, accumulate=False, dw=None, db=None, dx16=None):
     check(_lib.load().mt_layernorm_bwd(_p(dy), lddy if lddy is not None else D, _rm(dymap), _dt(dy), _p(x),
                                        ldx if ldx is not None else D, _rm(xmap), _dt(x), int(gelu_in), _p(w), _p(stats),
                                        _p(dx), lddx if lddx is not None else D, _rm(dxmap), _dt(dx), int(accumulate),
-                                       _p(dw), _p(db), M, D, _s()), "layernorm_bwd")
+                                       _p(dw), _p(db), _p(dx16), M, D, _s()), "layernorm_bwd")
 
 
 def dilated_attn_fwd(qkv, plan, o_br, lse_br):

@@ -219,7 +219,11 @@ def test_layernorm_gelu_f16_and_accumulate(ops):
     ops.layernorm_fwd(x.to(DEV), w2.to(DEV), torch.zeros(D2, device=DEV), yy, st, B * L, D2, xmap=xm)
     accd = acc0.to(DEV).clone()
     ops.layernorm_bwd(dyh.to(DEV), x.to(DEV), w2.to(DEV), st, accd, B * L, D2, xmap=xm, dxmap=xm, accumulate=True)
+    # second output: dense fp16 copy of the accumulated dx (operand of the next dX GEMM)
+    acc2, d16 = acc0.to(DEV)[:B * L].clone(), torch.zeros(B * L, D2, device=DEV, dtype=torch.float16)
+    ops.layernorm_bwd(dyh.to(DEV), x.to(DEV), w2.to(DEV), st, acc2, B * L, D2, xmap=xm, accumulate=True, dx16=d16)
     torch.cuda.synchronize()
+    assert torch.equal(d16, acc2.half())
     assert rel(yy.view(B, L, D2), r2) < 2e-3
     want = acc0.double().view(B, N_, D2).clone()
     want[:, 1:] += xd.grad
