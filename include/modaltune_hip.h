@@ -147,12 +147,15 @@ int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* 
 
 /* ------------------------------------------------------------ adapter ops -------------------------- */
 /* Injector attention core (AM:225-229 inside AM:359-369): for each of M patch rows and 12 heads (dim 16):
- * a = softmax(q k^T / 4) v over the T modal tokens of the row's pass.  q fp16 [M,192]; k,v fp32 [B,T,192]. */
+ * a = softmax(q k^T / 4) v over the T modal tokens of the row's pass.  q fp16 [M,192]; k,v fp32 [B,T,192];
+ * lse fp32 [M,12] (log-sum-exp of the scaled logits, saved for the backward; may be NULL for inference). */
 int mt_inject_attn_fwd(const mt_half* q, int M, int rows_per_pass, const float* k, const float* v, int T,
-                       mt_half* a, mt_stream_t stream);
-/* backward: dq fp16 [M,192]; dk, dv fp32 [B,T,192] accumulated with atomics (pre-zeroed by the caller) */
-int mt_inject_attn_bwd(const mt_half* q, const mt_half* da, int M, int rows_per_pass, const float* k, const float* v,
-                       int T, mt_half* dq, float* dk, float* dv, mt_stream_t stream);
+                       mt_half* a, float* lse, mt_stream_t stream);
+/* backward (a, lse from the forward): dq fp16 [M,192]; dk, dv fp32 [B,T,192] accumulated with atomics (pre-zeroed
+ * by the caller).  The reductions over the patch rows run on MFMA. */
+int mt_inject_attn_bwd(const mt_half* q, const mt_half* a, const float* lse, const mt_half* da, int M,
+                       int rows_per_pass, const float* k, const float* v, int T, mt_half* dq, float* dk, float* dv,
+                       mt_stream_t stream);
 
 /* Extractor attention core (AM:225-229 inside AM:321-335): T token queries attend over the L patch rows of their
  * pass.  q fp32 [B,T,192]; kv fp16 [B*L, 384] (k | v).  Split over L (flash-decoding style): part_* are

@@ -26,7 +26,8 @@ MT_DEVINL void store16(h16* p, const float* v) {
 // ---------------------------------------------------------------- injector -----------------------
 // grid (ceil(rows/256), 12 heads, B passes); thread = one patch row of the pass, K/V of (pass, head) in LDS.
 __global__ __launch_bounds__(256) void inject_attn_fwd_kernel(const h16* __restrict__ q, int rows_per_pass, const float* __restrict__ k,
-                                                              const float* __restrict__ v, int T, h16* __restrict__ a) {
+                                                              const float* __restrict__ v, int T, h16* __restrict__ a,
+                                                              float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) float ks[TMAX * AD], vs[TMAX * AD];
   const int h = blockIdx.y, b = blockIdx.z;
   for (int i = threadIdx.x; i < T * AD; i += 256) {
@@ -58,85 +59,106 @@ __global__ __launch_bounds__(256) void inject_attn_fwd_kernel(const h16* __restr
 #pragma unroll
   for (int d = 0; d < AD; ++d) acc[d] *= inv;
   store16(a + m * AE + h * AD, acc);
+  if (lse) lse[m * AH + h] = mx + __logf(l);      // of the scaled logits (q carries the 1/4)
 }
 
-// backward: workgroup = 128 rows x one head.  Phase 1 (thread = row): recompute p, dp = da . v, delta, ds and
-// dq; stage p / ds (fp16) in LDS.  Phase 2 (thread = (token, dim)): dk[t,d] = sum_rows ds q, dv[t,d] = sum_rows p da,
-// one atomic per (token, dim) per workgroup.  LDS is sized by the actual T (about 52 KB at T = 65: 3 workgroups/CU).
-constexpr int IBR = 128;
-__global__ __launch_bounds__(IBR) void inject_attn_bwd_kernel(const h16* __restrict__ q, const h16* __restrict__ da, int rows_per_pass,
-                                                              const float* __restrict__ k, const float* __restrict__ v, int T,
-                                                              h16* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
+// backward: workgroup = ITILES x 128 rows of one (pass, head).
+// Phase 1 (thread = row, one sweep over the tokens): p = exp(s/4 - lse), dp = da . v, delta = a . da (flash identity),
+// ds = p (dp - delta) / 4, dq += ds k; p / ds / q / da go to LDS TRANSPOSED ([token][row], [dim][row], fp16).
+// Phase 2 (MFMA): dk[t,d] += sum_rows ds[row,t] q[row,d] and dv[t,d] += sum_rows p[row,t] da[row,d] are 32x32x16
+// products with the row index as the reduction dimension -- both operands are plain 16-byte row reads of the
+// transposed images (wave 0 owns dk, wave 1 owns dv).  The accumulators live across the row tiles: one atomic per
+// (token, dim) per workgroup at the very end.
+constexpr int IBR = 128, ITILES = 4, RSTR = IBR + 8;   // RSTR: halves per transposed row (272 B: conflict-free b128)
+__global__ __launch_bounds__(IBR) void inject_attn_bwd_kernel(const h16* __restrict__ q, const h16* __restrict__ a,
+                                                              const float* __restrict__ lse, const h16* __restrict__ da,
+                                                              int rows_per_pass, const float* __restrict__ k,
+                                                              const float* __restrict__ v, int T, h16* __restrict__ dq,
+                                                              float* __restrict__ dk, float* __restrict__ dv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int TP = T + 2;                   // h16 row stride of the p / ds images (odd dword stride: no bank conflicts)
-  float* ks = smem;                       // [T][16]
-  float* vs = ks + T * AD;                // [T][16]
-  float* qs = vs + T * AD;                // [IBR][17]
-  float* das = qs + IBR * 17;             // [IBR][17]
-  h16* ps = reinterpret_cast<h16*>(das + IBR * 17);   // [IBR][TP]
-  h16* dss = ps + IBR * TP;               // [IBR][TP]
+  float* ks = smem;                                   // [T][16]
+  float* vs = ks + T * AD;                            // [T][16]
+  h16* psT = reinterpret_cast<h16*>(vs + T * AD);     // [T][RSTR]
+  h16* dssT = psT + T * RSTR;                         // [T][RSTR]
+  h16* qT = dssT + T * RSTR;                          // [16][RSTR]
+  h16* daT = qT + AD * RSTR;                          // [16][RSTR]
   const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
   for (int i = tid; i < T * AD; i += IBR) {
     const int t = i / AD, d = i % AD;
     ks[i] = k[((long)b * T + t) * AE + h * AD + d];
     vs[i] = v[((long)b * T + t) * AE + h * AD + d];
   }
+  const int ntb = (T + 31) / 32;
+  f32x16 acc[TMAX / 32];
+#pragma unroll
+  for (int tb = 0; tb < TMAX / 32; ++tb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[tb][i] = 0.f;
   __syncthreads();
-  const int r = blockIdx.x * IBR + tid;
-  const bool valid = r < rows_per_pass;
-  const long m = (long)b * rows_per_pass + (valid ? r : 0);
-  float qv[AD], dav[AD];
-  load16(q + m * AE + h * AD, qv);
-  load16(da + m * AE + h * AD, dav);
-  if (!valid) {
+  for (int tile = 0; tile < ITILES; ++tile) {
+    const int r0 = (blockIdx.x * ITILES + tile) * IBR;
+    if (r0 >= rows_per_pass) break;                   // uniform
+    const int r = r0 + tid;
+    const bool valid = r < rows_per_pass;
+    const long m = (long)b * rows_per_pass + (valid ? r : 0);
+    float qv[AD], dav[AD], av[AD];
+    load16(q + m * AE + h * AD, qv);
+    load16(da + m * AE + h * AD, dav);
+    load16(a + m * AE + h * AD, av);
+    const float ls = lse[m * AH + h];
+    float delta = 0.f;
 #pragma unroll
-    for (int d = 0; d < AD; ++d) { qv[d] = 0.f; dav[d] = 0.f; }
-  }
-#pragma unroll
-  for (int d = 0; d < AD; ++d) { qs[tid * 17 + d] = qv[d]; das[tid * 17 + d] = dav[d]; }
-  // pass 1: row maximum; pass 2: normaliser and delta = sum_t p_t dp_t
-  float mx = -1.0e30f;
-  for (int t = 0; t < T; ++t) {
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[t * AD + d], s);
-    mx = fmaxf(mx, s * ASCALE);
-  }
-  float l = 0.f, dsum = 0.f;
-  for (int t = 0; t < T; ++t) {
-    float s = 0.f, dp = 0.f;
-#pragma unroll
-    for (int d = 0; d < AD; ++d) { s = fmaf(qv[d], ks[t * AD + d], s); dp = fmaf(dav[d], vs[t * AD + d], dp); }
-    const float p = __expf(s * ASCALE - mx);
-    l += p;
-    dsum = fmaf(p, dp, dsum);
-  }
-  const float inv = 1.0f / l, delta = dsum * inv;
-  float dqv[AD];
-#pragma unroll
-  for (int d = 0; d < AD; ++d) dqv[d] = 0.f;
-  for (int t = 0; t < T; ++t) {
-    float s = 0.f, dp = 0.f;
-#pragma unroll
-    for (int d = 0; d < AD; ++d) { s = fmaf(qv[d], ks[t * AD + d], s); dp = fmaf(dav[d], vs[t * AD + d], dp); }
-    const float p = valid ? __expf(s * ASCALE - mx) * inv : 0.f;
-    const float ds = p * (dp - delta) * ASCALE;
-    ps[tid * TP + t] = (h16)p;
-    dss[tid * TP + t] = (h16)ds;
-#pragma unroll
-    for (int d = 0; d < AD; ++d) dqv[d] = fmaf(ds, ks[t * AD + d], dqv[d]);
-  }
-  if (valid) store16(dq + m * AE + h * AD, dqv);
-  __syncthreads();
-  for (int i = tid; i < T * AD; i += IBR) {
-    const int t = i / AD, d = i % AD;
-    float sk = 0.f, sv = 0.f;
-    for (int rr = 0; rr < IBR; ++rr) {
-      sk = fmaf((float)dss[rr * TP + t], qs[rr * 17 + d], sk);
-      sv = fmaf((float)ps[rr * TP + t], das[rr * 17 + d], sv);
+    for (int d = 0; d < AD; ++d) {
+      if (!valid) { qv[d] = 0.f; dav[d] = 0.f; }
+      delta = fmaf(av[d], dav[d], delta);
+      qT[d * RSTR + tid] = (h16)qv[d];                // exact: q and da are fp16 values
+      daT[d * RSTR + tid] = (h16)dav[d];
     }
-    atomicAdd(&dk[((long)b * T + t) * AE + h * AD + d], sk);
-    atomicAdd(&dv[((long)b * T + t) * AE + h * AD + d], sv);
+    float dqv[AD];
+#pragma unroll
+    for (int d = 0; d < AD; ++d) dqv[d] = 0.f;
+    for (int t = 0; t < T; ++t) {
+      float sc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) { sc = fmaf(qv[d], ks[t * AD + d], sc); dp = fmaf(dav[d], vs[t * AD + d], dp); }
+      const float p = valid ? __expf(fmaf(sc, ASCALE, -ls)) : 0.f;
+      const float ds = p * (dp - delta) * ASCALE;
+      psT[t * RSTR + tid] = (h16)p;
+      dssT[t * RSTR + tid] = (h16)ds;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) dqv[d] = fmaf(ds, ks[t * AD + d], dqv[d]);
+    }
+    if (valid) store16(dq + m * AE + h * AD, dqv);
+    __syncthreads();
+    const h16* Asrc = wave ? psT : dssT;
+    const h16* Bsrc = wave ? daT : qT;
+#pragma unroll
+    for (int tb = 0; tb < TMAX / 32; ++tb) {
+      if (tb < ntb) {
+        const int trow = min(tb * 32 + l31, T - 1);   // rows >= T: valid memory, results never flushed
+#pragma unroll
+        for (int kk = 0; kk < IBR / 16; ++kk) {
+          const h16x8 af = *reinterpret_cast<const h16x8*>(&Asrc[trow * RSTR + kk * 16 + hh * 8]);
+          const h16x8 bf = *reinterpret_cast<const h16x8*>(&Bsrc[(l31 & 15) * RSTR + kk * 16 + hh * 8]);
+          acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[tb], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // accumulator rows are tokens: row(i) = (i&3) + 8 (i>>2) + 4 hh; column = lane & 31 = dim (16 valid)
+  float* dst = wave ? dv : dk;
+  if (l31 < AD) {
+#pragma unroll
+    for (int tb = 0; tb < TMAX / 32; ++tb)
+      if (tb < ntb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (t < T) atomicAdd(&dst[((long)b * T + t) * AE + h * AD + l31], acc[tb][i]);
+        }
+      }
   }
 }
 
@@ -213,22 +235,24 @@ __global__ void extract_attn_reduce_kernel(const float* __restrict__ part_acc, c
   lse[((long)b * T + t) * AH + h] = mx + __logf(l);
 }
 
-// backward: grid (ceil(L/128), 12, B); thread = key.  q, dout, lse, delta of the (pass, head) live in LDS.
-// Phase 1: per key loop over tokens -> dk, dv (written as fp16 rows), stage ds[key][t].  Phase 2: thread = (t, d):
-// dq[t,d] += sum_keys ds[key][t] * k[key][d] (one atomic per (t,d) per workgroup).
-constexpr int EBK = 128;
+// backward: workgroup = ETILES x 128 keys of one (pass, head); thread = key.  q, dout, lse, delta of the (pass, head)
+// live in LDS.  Phase 1: per key sweep the tokens -> dk, dv (fp16 rows); ds and k go to LDS transposed (fp16).
+// Phase 2 (MFMA, as in the injector backward): dq[t,d] += sum_keys ds[key,t] k[key,d]; the two waves split the
+// 32-token blocks; one atomic per (token, dim) per workgroup at the end.
+constexpr int EBK = 128, ETILES = 4;
 __global__ __launch_bounds__(EBK) void extract_attn_bwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv,
                                                                const float* __restrict__ out, const float* __restrict__ lse,
                                                                const float* __restrict__ dout, int T, int L, float* __restrict__ dq,
                                                                h16* __restrict__ dkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qs = smem;                 // [T][16] (pre-scaled)
-  float* dos = qs + TMAX * AD;      // [T][16]
-  float* ls = dos + TMAX * AD;      // [T]
+  float* dos = qs + T * AD;         // [T][16]
+  float* ls = dos + T * AD;         // [T]
   float* dl = ls + TMAX;            // [T]
-  float* kk = dl + TMAX;            // [EBK][17]
-  float* dss = kk + EBK * 17;       // [EBK][T+1]
+  h16* dssT = reinterpret_cast<h16*>(dl + TMAX);    // [T][RSTR]
+  h16* kT = dssT + T * RSTR;                        // [16][RSTR]
   const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
   for (int i = tid; i < T * AD; i += EBK) {
     const int t = i / AD, d = i % AD;
     qs[i] = q[((long)b * T + t) * AE + h * AD + d] * ASCALE;
@@ -240,39 +264,70 @@ __global__ __launch_bounds__(EBK) void extract_attn_bwd_kernel(const float* __re
     for (int e = 0; e < AD; ++e) d = fmaf(dout[((long)b * T + t) * AE + h * AD + e], out[((long)b * T + t) * AE + h * AD + e], d);
     dl[t] = d;
   }
+  const int ntb = (T + 31) / 32;
+  f32x16 acc[TMAX / 64];            // this wave's token blocks: wave, wave + 2
+#pragma unroll
+  for (int j = 0; j < TMAX / 64; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
   __syncthreads();
-  const int key = blockIdx.x * EBK + tid;
-  const bool valid = key < L;
-  float kvv[AD], vv[AD], dkv_[AD], dvv[AD];
-  if (valid) {
-    load16(kv + ((long)b * L + key) * (2 * AE) + h * AD, kvv);
-    load16(kv + ((long)b * L + key) * (2 * AE) + AE + h * AD, vv);
-  } else {
+  for (int tile = 0; tile < ETILES; ++tile) {
+    const int k0 = (blockIdx.x * ETILES + tile) * EBK;
+    if (k0 >= L) break;             // uniform
+    const int key = k0 + tid;
+    const bool valid = key < L;
+    float kvv[AD], vv[AD], dkv_[AD], dvv[AD];
+    if (valid) {
+      load16(kv + ((long)b * L + key) * (2 * AE) + h * AD, kvv);
+      load16(kv + ((long)b * L + key) * (2 * AE) + AE + h * AD, vv);
+    } else {
 #pragma unroll
-    for (int d = 0; d < AD; ++d) { kvv[d] = 0.f; vv[d] = 0.f; }
+      for (int d = 0; d < AD; ++d) { kvv[d] = 0.f; vv[d] = 0.f; }
+    }
+#pragma unroll
+    for (int d = 0; d < AD; ++d) { kT[d * RSTR + tid] = (h16)kvv[d]; dkv_[d] = 0.f; dvv[d] = 0.f; }
+    for (int t = 0; t < T; ++t) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) { s = fmaf(qs[t * AD + d], kvv[d], s); dp = fmaf(dos[t * AD + d], vv[d], dp); }
+      const float p = valid ? __expf(s - ls[t]) : 0.f;
+      const float ds = p * (dp - dl[t]);
+      dssT[t * RSTR + tid] = (h16)(ds * ASCALE);
+#pragma unroll
+      for (int d = 0; d < AD; ++d) { dkv_[d] = fmaf(ds, qs[t * AD + d], dkv_[d]); dvv[d] = fmaf(p, dos[t * AD + d], dvv[d]); }
+    }
+    if (valid) {
+      store16(dkv + ((long)b * L + key) * (2 * AE) + h * AD, dkv_);        // qs already carries the 1/4 scale
+      store16(dkv + ((long)b * L + key) * (2 * AE) + AE + h * AD, dvv);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TMAX / 64; ++j) {
+      const int tb = wave + 2 * j;
+      if (tb < ntb) {
+        const int trow = min(tb * 32 + l31, T - 1);
+#pragma unroll
+        for (int kk = 0; kk < EBK / 16; ++kk) {
+          const h16x8 af = *reinterpret_cast<const h16x8*>(&dssT[trow * RSTR + kk * 16 + hh * 8]);
+          const h16x8 bf = *reinterpret_cast<const h16x8*>(&kT[(l31 & 15) * RSTR + kk * 16 + hh * 8]);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
   }
+  if (l31 < AD) {
 #pragma unroll
-  for (int d = 0; d < AD; ++d) { kk[tid * 17 + d] = kvv[d]; dkv_[d] = 0.f; dvv[d] = 0.f; }
-  for (int t = 0; t < T; ++t) {
-    float s = 0.f, dp = 0.f;
+    for (int j = 0; j < TMAX / 64; ++j) {
+      const int tb = wave + 2 * j;
+      if (tb < ntb) {
 #pragma unroll
-    for (int d = 0; d < AD; ++d) { s = fmaf(qs[t * AD + d], kvv[d], s); dp = fmaf(dos[t * AD + d], vv[d], dp); }
-    const float p = valid ? __expf(s - ls[t]) : 0.f;
-    const float ds = p * (dp - dl[t]);
-    dss[tid * (T + 1) + t] = ds * ASCALE;
-#pragma unroll
-    for (int d = 0; d < AD; ++d) { dkv_[d] = fmaf(ds, qs[t * AD + d], dkv_[d]); dvv[d] = fmaf(p, dos[t * AD + d], dvv[d]); }
-  }
-  if (valid) {
-    store16(dkv + ((long)b * L + key) * (2 * AE) + h * AD, dkv_);        // qs already carries the 1/4 scale
-    store16(dkv + ((long)b * L + key) * (2 * AE) + AE + h * AD, dvv);
-  }
-  __syncthreads();
-  for (int i = tid; i < T * AD; i += EBK) {
-    const int t = i / AD, d = i % AD;
-    float s = 0.f;
-    for (int kx = 0; kx < EBK; ++kx) s = fmaf(dss[kx * (T + 1) + t], kk[kx * 17 + d], s);
-    atomicAdd(&dq[((long)b * T + t) * AE + h * AD + d], s);
+        for (int i = 0; i < 16; ++i) {
+          const int t = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (t < T) atomicAdd(&dq[((long)b * T + t) * AE + h * AD + l31], acc[j][i]);
+        }
+      }
+    }
   }
 }
 
@@ -374,28 +429,30 @@ __global__ __launch_bounds__(128) void token_mha_bwd_kernel(const float* __restr
 }  // namespace
 
 extern "C" int mt_inject_attn_fwd(const mt_half* q, int M, int rows_per_pass, const float* k, const float* v, int T,
-                                  mt_half* a, mt_stream_t stream) {
+                                  mt_half* a, float* lse, mt_stream_t stream) {
   if (!q || !k || !v || !a || M <= 0 || rows_per_pass <= 0 || M % rows_per_pass || T < 1 || T > TMAX) return MT_ERR_BAD_ARG;
   const int B = M / rows_per_pass;
   hipLaunchKernelGGL(inject_attn_fwd_kernel, dim3(cdiv(rows_per_pass, 256), AH, B), dim3(256), 0, (hipStream_t)stream,
-                     (const h16*)q, rows_per_pass, k, v, T, (h16*)a);
+                     (const h16*)q, rows_per_pass, k, v, T, (h16*)a, lse);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
 
-extern "C" int mt_inject_attn_bwd(const mt_half* q, const mt_half* da, int M, int rows_per_pass, const float* k,
-                                  const float* v, int T, mt_half* dq, float* dk, float* dv, mt_stream_t stream) {
-  if (!q || !da || !k || !v || !dq || !dk || !dv || M <= 0 || rows_per_pass <= 0 || M % rows_per_pass || T < 1 || T > TMAX)
+extern "C" int mt_inject_attn_bwd(const mt_half* q, const mt_half* a, const float* lse, const mt_half* da, int M,
+                                  int rows_per_pass, const float* k, const float* v, int T, mt_half* dq, float* dk,
+                                  float* dv, mt_stream_t stream) {
+  if (!q || !a || !lse || !da || !k || !v || !dq || !dk || !dv || M <= 0 || rows_per_pass <= 0 || M % rows_per_pass || T < 1 ||
+      T > TMAX)
     return MT_ERR_BAD_ARG;
   const int B = M / rows_per_pass;
-  const size_t shm = sizeof(float) * (2 * T * AD + 2 * IBR * 17) + sizeof(h16) * 2 * IBR * (T + 2);
+  const size_t shm = sizeof(float) * (2 * T * AD) + sizeof(h16) * (2 * T + 2 * AD) * RSTR;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)inject_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(inject_attn_bwd_kernel, dim3(cdiv(rows_per_pass, IBR), AH, B), dim3(IBR), shm, (hipStream_t)stream,
-                     (const h16*)q, (const h16*)da, rows_per_pass, k, v, T, (h16*)dq, dk, dv);
+  hipLaunchKernelGGL(inject_attn_bwd_kernel, dim3(cdiv(rows_per_pass, IBR * ITILES), AH, B), dim3(IBR), shm, (hipStream_t)stream,
+                     (const h16*)q, (const h16*)a, lse, (const h16*)da, rows_per_pass, k, v, T, (h16*)dq, dk, dv);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
@@ -416,13 +473,13 @@ extern "C" int mt_extract_attn_fwd(const float* q, const mt_half* kv, int B, int
 extern "C" int mt_extract_attn_bwd(const float* q, const mt_half* kv, const float* out, const float* lse,
                                    const float* dout, int B, int T, int L, float* dq, mt_half* dkv, mt_stream_t stream) {
   if (!q || !kv || !out || !lse || !dout || !dq || !dkv || B < 1 || T < 1 || T > TMAX || L < 1) return MT_ERR_BAD_ARG;
-  const size_t shm = sizeof(float) * (2 * TMAX * AD + 2 * TMAX + EBK * 17 + EBK * (T + 1));
+  const size_t shm = sizeof(float) * (2 * T * AD + 2 * TMAX) + sizeof(h16) * (T + AD) * RSTR;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)extract_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(extract_attn_bwd_kernel, dim3(cdiv(L, EBK), AH, B), dim3(EBK), shm, (hipStream_t)stream, q,
+  hipLaunchKernelGGL(extract_attn_bwd_kernel, dim3(cdiv(L, EBK * ETILES), AH, B), dim3(EBK), shm, (hipStream_t)stream, q,
                      (const h16*)kv, out, lse, dout, T, L, dq, (h16*)dkv);
   MT_CHECK_LAUNCH();
   return MT_OK;

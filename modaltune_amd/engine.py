@@ -434,7 +434,8 @@ class Engine:
         bqi = t[ap + "multihead_attn.in_proj_bias"][:E]
         ops.gemm_nt(q1, w16[ap + "q_in"].w, q2, Mp, E, E, bias=bqi)
         a = torch.empty(Mp, E, dtype=H16, device=dev)
-        ops.inject_attn_fwd(q2, k.data, v.data, a, Mp, L, T)
+        alse = torch.empty(Mp, 12, dtype=F32, device=dev)
+        ops.inject_attn_fwd(q2, k.data, v.data, a, Mp, L, T, lse=alse)
         o1 = torch.empty(Mp, E, dtype=H16, device=dev)
         ops.gemm_nt(a, w16[ap + "out_in"].w, o1, Mp, E, E, bias=t[ap + "multihead_attn.out_proj.bias"])
         ops.gemm_nt(o1, w16[ap + "output_proj"].w, hin, Mp, D, E, cmap=pm, epilogue=ops.EPI_INJECT, bias=t[ap + "output_proj.bias"],
@@ -459,7 +460,7 @@ class Engine:
             da = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.gemm_nt(do1, w16[ap + "out_in"].wt, da, Mp, E, E)
             dq2 = torch.empty(Mp, E, dtype=H16, device=dev)
-            ops.inject_attn_bwd(q2, da, k.data, v.data, dq2, k.g(), v.g(), Mp, L, T)
+            ops.inject_attn_bwd(q2, a, alse, da, k.data, v.data, dq2, k.g(), v.g(), Mp, L, T)
             ops.gemm_tn(dq2, q1, g[ap + "multihead_attn.q_proj_weight"], Mp, E, E)
             ops.colsum(dq2, g[ap + "multihead_attn.in_proj_bias"][:E], Mp, E)
             dq1 = torch.empty(Mp, E, dtype=H16, device=dev)

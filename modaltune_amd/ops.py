@@ -142,13 +142,13 @@ def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
         TIMER.setdefault(name, []).append((e0, e1))
 
 
-def inject_attn_fwd(q, k, v, a, M, rows_per_pass, T):
-    check(_lib.load().mt_inject_attn_fwd(_p(q), M, rows_per_pass, _p(k), _p(v), T, _p(a), _s()), "inject_attn_fwd")
+def inject_attn_fwd(q, k, v, a, M, rows_per_pass, T, lse=None):
+    check(_lib.load().mt_inject_attn_fwd(_p(q), M, rows_per_pass, _p(k), _p(v), T, _p(a), _p(lse), _s()), "inject_attn_fwd")
 
 
-def inject_attn_bwd(q, da, k, v, dq, dk, dv, M, rows_per_pass, T):
-    check(_lib.load().mt_inject_attn_bwd(_p(q), _p(da), M, rows_per_pass, _p(k), _p(v), T, _p(dq), _p(dk), _p(dv), _s()),
-          "inject_attn_bwd")
+def inject_attn_bwd(q, a, lse, da, k, v, dq, dk, dv, M, rows_per_pass, T):
+    check(_lib.load().mt_inject_attn_bwd(_p(q), _p(a), _p(lse), _p(da), M, rows_per_pass, _p(k), _p(v), T, _p(dq), _p(dk),
+                                         _p(dv), _s()), "inject_attn_bwd")
 
 
 def extract_attn_fwd(q, kv, out, lse, part_acc, part_ml, B, T, L, nsplit):
