@@ -163,22 +163,27 @@ __global__ __launch_bounds__(IBR) void inject_attn_bwd_kernel(const h16* __restr
 }
 
 // ---------------------------------------------------------------- extractor ----------------------
-// forward: grid (nsplit, 12, B); thread = modal token t; the split's keys are streamed through LDS in tiles of 64.
-constexpr int EKT = 64;
-__global__ __launch_bounds__(128) void extract_attn_fwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv, int T, int L,
+// forward: grid (nsplit, 12, B); 256 threads = nsub key-lanes x T tokens (nsub = min(256 / T, 8)): thread (t, sub)
+// sweeps keys sub, sub + nsub, ... of each 64-key LDS tile with an online softmax; the nsub partials of a token are
+// merged through LDS at the end, so the partial buffers keep one entry per (split, token).
+constexpr int EKT = 64, EFT = 256;
+__global__ __launch_bounds__(EFT) void extract_attn_fwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv, int T, int L,
                                                                int keys_per_split, float* __restrict__ part_acc, float* __restrict__ part_ml) {
   __shared__ __attribute__((aligned(16))) float ks[EKT * AD], vs[EKT * AD];
+  __shared__ float mrg[EFT][AD + 3];
   const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int nsplit = gridDim.x;
+  const int nsub = min(EFT / T, 8);
+  const int sub = tid / T, t = tid - sub * T;
+  const bool tv = sub < nsub;
   float qv[AD], acc[AD];
-  const bool tv = tid < T;
 #pragma unroll
-  for (int d = 0; d < AD; ++d) { qv[d] = tv ? q[((long)b * T + tid) * AE + h * AD + d] * ASCALE : 0.f; acc[d] = 0.f; }
+  for (int d = 0; d < AD; ++d) { qv[d] = tv ? q[((long)b * T + t) * AE + h * AD + d] * ASCALE : 0.f; acc[d] = 0.f; }
   float mx = -1.0e30f, l = 0.f;
   const int kbeg = sp * keys_per_split, kend = min(L, kbeg + keys_per_split);
   for (int k0 = kbeg; k0 < kend; k0 += EKT) {
     __syncthreads();
-    {   // 64 keys x (16 k + 16 v) halves: 128 threads, thread -> (key, k|v)
+    if (tid < 2 * EKT) {   // 64 keys x (16 k + 16 v) halves: thread -> (key, k|v)
       const int key = tid >> 1, which = tid & 1;
       float tmp[AD];
       if (k0 + key < kend) load16(kv + ((long)b * L + k0 + key) * (2 * AE) + which * AE + h * AD, tmp);
@@ -192,23 +197,42 @@ __global__ __launch_bounds__(128) void extract_attn_fwd_kernel(const float* __re
     }
     __syncthreads();
     const int nk = min(EKT, kend - k0);
-    for (int j = 0; j < nk; ++j) {
-      float s = 0.f;
+    if (tv)
+      for (int j = sub; j < nk; j += nsub) {
+        float s = 0.f;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[j * AD + d], s);
-      const float mn = fmaxf(mx, s);
-      const float al = __expf(mx - mn), p = __expf(s - mn);
-      l = l * al + p;
+        for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[j * AD + d], s);
+        const float mn = fmaxf(mx, s);
+        const float al = __expf(mx - mn), p = __expf(s - mn);
+        l = l * al + p;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) acc[d] = fmaf(acc[d], al, p * vs[j * AD + d]);
-      mx = mn;
-    }
+        for (int d = 0; d < AD; ++d) acc[d] = fmaf(acc[d], al, p * vs[j * AD + d]);
+        mx = mn;
+      }
   }
+  // merge the nsub partials of each token
   if (tv) {
+#pragma unroll
+    for (int d = 0; d < AD; ++d) mrg[tid][d] = acc[d];
+    mrg[tid][AD] = mx; mrg[tid][AD + 1] = l;
+  }
+  __syncthreads();
+  if (tid < T) {
+    float m2 = -1.0e30f;
+    for (int s = 0; s < nsub; ++s) m2 = fmaxf(m2, mrg[s * T + tid][AD]);
+    float l2 = 0.f, a2[AD];
+#pragma unroll
+    for (int d = 0; d < AD; ++d) a2[d] = 0.f;
+    for (int s = 0; s < nsub; ++s) {
+      const float wgt = __expf(mrg[s * T + tid][AD] - m2);
+      l2 = fmaf(wgt, mrg[s * T + tid][AD + 1], l2);
+#pragma unroll
+      for (int d = 0; d < AD; ++d) a2[d] = fmaf(wgt, mrg[s * T + tid][d], a2[d]);
+    }
     const long o = (((long)b * AH + h) * nsplit + sp) * T + tid;
 #pragma unroll
-    for (int d = 0; d < AD; ++d) part_acc[o * AD + d] = acc[d];
-    part_ml[o * 2] = mx; part_ml[o * 2 + 1] = l;
+    for (int d = 0; d < AD; ++d) part_acc[o * AD + d] = a2[d];
+    part_ml[o * 2] = m2; part_ml[o * 2 + 1] = l2;
   }
 }
 
@@ -462,7 +486,7 @@ extern "C" int mt_extract_attn_fwd(const float* q, const mt_half* kv, int B, int
   if (!q || !kv || !out || !lse || !part_acc || !part_ml || B < 1 || T < 1 || T > TMAX || L < 1 || nsplit < 1) return MT_ERR_BAD_ARG;
   const int kps = cdiv(cdiv(L, nsplit), EKT) * EKT;
   if ((long)kps * (nsplit - 1) >= L && nsplit > 1) return MT_ERR_BAD_ARG;   // every split must own >= 1 key
-  hipLaunchKernelGGL(extract_attn_fwd_kernel, dim3(nsplit, AH, B), dim3(128), 0, (hipStream_t)stream, q, (const h16*)kv, T, L,
+  hipLaunchKernelGGL(extract_attn_fwd_kernel, dim3(nsplit, AH, B), dim3(EFT), 0, (hipStream_t)stream, q, (const h16*)kv, T, L,
                      kps, part_acc, part_ml);
   hipLaunchKernelGGL(extract_attn_reduce_kernel, dim3(B * AH), dim3(TMAX), 0, (hipStream_t)stream, part_acc, part_ml, T,
                      nsplit, out, lse);
