@@ -205,48 +205,76 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// branch mix + inner_attn_ln (forward) : one wave per token row (16 heads x 48)
-// lane handles 12 consecutive columns -> exactly one head (4 lanes per head)
+// branch mix + inner_attn_ln (forward / backward): one wave per token row (16 heads x 48); a lane owns 12 consecutive
+// columns = a quarter of one head.  HBM-bound passes over the covered branch outputs, so the row loop is kept
+// branch-free: a lane's group id per branch is computed once, the row's residue per branch is wave-uniform, and a
+// branch that does not cover (position, head) reads the (always covered) ratio-1 branch's line instead -- an L1 hit --
+// and is discarded with a select.  (A branch around each load made hipcc wait for every load separately.)
 // ------------------------------------------------------------------------------------------------
-MT_DEVINL bool covers(const Plan& p, int br, int pos, int h) {
-  const int dr = p.ratio[br];
-  const int loc = pos % p.seg[br];
-  return (loc % dr) == h / (H / dr);
+struct MixGeom {
+  int grp[MT_MAX_BRANCHES];     // this lane's head group per branch: h / (16 / ratio)
+  MT_DEVINL MixGeom(const Plan& p, int h) {
+#pragma unroll
+    for (int b = 0; b < MT_MAX_BRANCHES; ++b) grp[b] = b < p.nbranch ? h / (H / p.ratio[b]) : -1;
+  }
+};
+// residue of position pos inside its segment, modulo the dilation (wave-uniform)
+MT_DEVINL int residue(const Plan& p, int b, int pos) {
+  const int sg = p.seg[b], dr = p.ratio[b];
+  const int loc = sg >= p.N ? pos : pos % sg;
+  return (dr & (dr - 1)) == 0 ? (loc & (dr - 1)) : loc % dr;
 }
+MT_DEVINL int dense_branch(const Plan& p) {      // a branch with ratio 1 covers every (position, head)
+  int d = 0;
+#pragma unroll
+  for (int b = 0; b < MT_MAX_BRANCHES; ++b) if (b < p.nbranch && p.ratio[b] == 1) d = b;
+  return d;
+}
+struct H12 { h16x4 a, b, c; };
+MT_DEVINL H12 ld12(const h16* p) {
+  return H12{*reinterpret_cast<const h16x4*>(p), *reinterpret_cast<const h16x4*>(p + 4), *reinterpret_cast<const h16x4*>(p + 8)};
+}
+MT_DEVINL float h12(const H12& v, int e) { return (float)(e < 4 ? v.a[e & 3] : e < 8 ? v.b[e & 3] : v.c[e & 3]); }
 
+template <int NB>
 __global__ __launch_bounds__(256) void mix_ln_fwd_kernel(const h16* __restrict__ o_br, const float* __restrict__ lse_br, Plan p,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          h16* __restrict__ y, float* __restrict__ stats, float* __restrict__ lse_tot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long M = (long)p.B * p.N;
   const int h = lane >> 2, c0 = lane * 12;
+  const MixGeom geo(p, h);
+  const int db = dense_branch(p);
+  float w[12], bb[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) { w[e] = ln_w[c0 + e]; bb[e] = ln_b[c0 + e]; }
   for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
     const int pos = (int)(m % p.N);
-    float lse[MT_MAX_BRANCHES];
+    bool cov[NB];
+    float lse[NB];
+    H12 ob[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      cov[b] = b < p.nbranch && geo.grp[b] == residue(p, b, pos);
+      const int sb = cov[b] ? b : db;
+      lse[b] = lse_br[((long)sb * M + m) * H + h];
+      ob[b] = ld12(o_br + ((long)sb * M + m) * DM + c0);
+    }
     float mx = NEG_BIG;
 #pragma unroll
-    for (int b = 0; b < MT_MAX_BRANCHES; ++b) {
-      lse[b] = NEG_BIG;
-      if (b < p.nbranch && covers(p, b, pos, h)) lse[b] = lse_br[((long)b * M + m) * H + h];
-      mx = fmaxf(mx, lse[b]);
-    }
+    for (int b = 0; b < NB; ++b) { lse[b] = cov[b] ? lse[b] : NEG_BIG; mx = fmaxf(mx, lse[b]); }
     float den = 0.f;
 #pragma unroll
-    for (int b = 0; b < MT_MAX_BRANCHES; ++b) den += (lse[b] > -1.0e29f) ? __expf(lse[b] - mx) : 0.f;
+    for (int b = 0; b < NB; ++b) den += cov[b] ? __expf(lse[b] - mx) : 0.f;
     const float tot = mx + __logf(den);
     float v[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) v[e] = 0.f;
 #pragma unroll
-    for (int b = 0; b < MT_MAX_BRANCHES; ++b) {
-      if (b < p.nbranch && lse[b] > -1.0e29f) {
-        const float wgt = __expf(lse[b] - tot);
-        const h16* src = o_br + ((long)b * M + m) * DM + c0;
-        const h16x4 a0 = *reinterpret_cast<const h16x4*>(src), a1 = *reinterpret_cast<const h16x4*>(src + 4),
-                    a2 = *reinterpret_cast<const h16x4*>(src + 8);
+    for (int b = 0; b < NB; ++b) {
+      const float wgt = cov[b] ? __expf(lse[b] - tot) : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += wgt * (float)a0[e]; v[4 + e] += wgt * (float)a1[e]; v[8 + e] += wgt * (float)a2[e]; }
-      }
+      for (int e = 0; e < 12; ++e) v[e] = fmaf(wgt, cov[b] ? h12(ob[b], e) : 0.f, v[e]);
     }
     float s = 0.f;
 #pragma unroll
@@ -261,7 +289,7 @@ __global__ __launch_bounds__(256) void mix_ln_fwd_kernel(const h16* __restrict__
     for (int k = 0; k < 3; ++k) {
       h16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (h16)((v[4 * k + e] - mean) * rstd * ln_w[c0 + 4 * k + e] + ln_b[c0 + 4 * k + e]);
+      for (int e = 0; e < 4; ++e) o[e] = (h16)((v[4 * k + e] - mean) * rstd * w[4 * k + e] + bb[4 * k + e]);
       *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
     }
     if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
@@ -270,7 +298,8 @@ __global__ __launch_bounds__(256) void mix_ln_fwd_kernel(const h16* __restrict__
 }
 
 // backward of mix + LN: recompute mixed from the branch outputs, LayerNorm backward (frozen affine: no dw/db),
-// dmixed (fp16) and delta_b = sum_d dmixed * O_b per (row, head, branch).
+// dmixed (fp16, head-major) and delta_b = sum_d dmixed * O_b per (row, head, branch).
+template <int NB>
 __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__ dy, const h16* __restrict__ o_br,
                                                          const float* __restrict__ lse_br, const float* __restrict__ lse_tot, Plan p,
                                                          const float* __restrict__ ln_w, const float* __restrict__ stats,
@@ -278,42 +307,42 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long M = (long)p.B * p.N;
   const int h = lane >> 2, c0 = lane * 12;
+  const MixGeom geo(p, h);
+  const int db = dense_branch(p);
+  float w[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) w[e] = ln_w[c0 + e];
   for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
     const int pos = (int)(m % p.N);
     const float tot = lse_tot[m * H + h];
-    float ob[MT_MAX_BRANCHES][12];
-    bool cov[MT_MAX_BRANCHES];
+    const float mean = stats[2 * m], rstd = stats[2 * m + 1];
+    const H12 dyv = ld12(dy + m * DM + c0);
+    bool cov[NB];
+    float lse[NB];
+    H12 ob[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      cov[b] = b < p.nbranch && geo.grp[b] == residue(p, b, pos);
+      const int sb = cov[b] ? b : db;
+      lse[b] = lse_br[((long)sb * M + m) * H + h];
+      ob[b] = ld12(o_br + ((long)sb * M + m) * DM + c0);
+    }
     float v[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) v[e] = 0.f;
 #pragma unroll
-    for (int b = 0; b < MT_MAX_BRANCHES; ++b) {
-      cov[b] = b < p.nbranch && covers(p, b, pos, h);
-      if (cov[b]) {
-        const float wgt = __expf(lse_br[((long)b * M + m) * H + h] - tot);
-        const h16* src = o_br + ((long)b * M + m) * DM + c0;
-        const h16x4 a0 = *reinterpret_cast<const h16x4*>(src), a1 = *reinterpret_cast<const h16x4*>(src + 4),
-                    a2 = *reinterpret_cast<const h16x4*>(src + 8);
+    for (int b = 0; b < NB; ++b) {
+      const float wgt = cov[b] ? __expf(lse[b] - tot) : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ob[b][e] = (float)a0[e]; ob[b][4 + e] = (float)a1[e]; ob[b][8 + e] = (float)a2[e]; }
-#pragma unroll
-        for (int e = 0; e < 12; ++e) v[e] += wgt * ob[b][e];
-      }
+      for (int e = 0; e < 12; ++e) v[e] = fmaf(wgt, cov[b] ? h12(ob[b], e) : 0.f, v[e]);
     }
-    const float mean = stats[2 * m], rstd = stats[2 * m + 1];
-    const h16* dyr = dy + m * DM + c0;
     float g[12], xh[12];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const h16x4 d = *reinterpret_cast<const h16x4*>(dyr + 4 * k);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * k + e;
-        xh[i] = (v[i] - mean) * rstd;
-        g[i] = (float)d[e] * ln_w[c0 + i];
-        s1 += g[i]; s2 += g[i] * xh[i];
-      }
+    for (int i = 0; i < 12; ++i) {
+      xh[i] = (v[i] - mean) * rstd;
+      g[i] = h12(dyv, i) * w[i];
+      s1 += g[i]; s2 = fmaf(g[i], xh[i], s2);
     }
     const float c1 = wave_sum(s1) * (1.0f / DM), c2 = wave_sum(s2) * (1.0f / DM);
     float dm[12];
@@ -324,24 +353,19 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * k + e;
-        dm[i] = rstd * (g[i] - c1 - xh[i] * c2);
-        o[e] = (h16)dm[i];
+        o[e] = (h16)(rstd * (g[i] - c1 - xh[i] * c2));
         dm[i] = (float)o[e];          // delta must match the fp16 dmixed the attention backward consumes
       }
       *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
     }
 #pragma unroll
-    for (int b = 0; b < MT_MAX_BRANCHES; ++b) {
-      if (b < p.nbranch) {          // uniform over the wave
-        float d = 0.f;
-        if (cov[b]) {
+    for (int b = 0; b < NB; ++b) {
+      float d = 0.f;
 #pragma unroll
-          for (int e = 0; e < 12; ++e) d += dm[e] * ob[b][e];
-        }
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        if ((lane & 3) == 0 && cov[b]) delta_br[((long)b * M + m) * H + h] = d;
-      }
+      for (int e = 0; e < 12; ++e) d = fmaf(dm[e], h12(ob[b], e), d);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      if ((lane & 3) == 0 && cov[b]) delta_br[((long)b * M + m) * H + h] = d;
     }
   }
 }
@@ -731,8 +755,13 @@ extern "C" int mt_dilated_mix_ln_fwd(const mt_half* o_br, const float* lse_br, c
   if (!o_br || !lse_br || !ln_w || !ln_b || !y || !stats || !lse_tot || !plan_ok(plan)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
   const long M = (long)p.B * p.N;
-  hipLaunchKernelGGL(mix_ln_fwd_kernel, dim3((int)min((M + 3) / 4, 8192L)), dim3(256), 0, (hipStream_t)stream,
-                     (const h16*)o_br, lse_br, p, ln_w, ln_b, (h16*)y, stats, lse_tot);
+  const dim3 grid((int)min((M + 3) / 4, 8192L));
+  if (p.nbranch <= 5)
+    hipLaunchKernelGGL(mix_ln_fwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)o_br, lse_br, p, ln_w, ln_b,
+                       (h16*)y, stats, lse_tot);
+  else
+    hipLaunchKernelGGL(mix_ln_fwd_kernel<MT_MAX_BRANCHES>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)o_br, lse_br, p,
+                       ln_w, ln_b, (h16*)y, stats, lse_tot);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
@@ -743,8 +772,13 @@ extern "C" int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, con
   if (!dy || !o_br || !lse_br || !lse_tot || !ln_w || !stats || !dmixed || !delta_br || !plan_ok(plan)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
   const long M = (long)p.B * p.N;
-  hipLaunchKernelGGL(mix_ln_bwd_kernel, dim3((int)min((M + 3) / 4, 8192L)), dim3(256), 0, (hipStream_t)stream,
-                     (const h16*)dy, (const h16*)o_br, lse_br, lse_tot, p, ln_w, stats, (h16*)dmixed, delta_br);
+  const dim3 grid((int)min((M + 3) / 4, 8192L));
+  if (p.nbranch <= 5)
+    hipLaunchKernelGGL(mix_ln_bwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)dy, (const h16*)o_br, lse_br,
+                       lse_tot, p, ln_w, stats, (h16*)dmixed, delta_br);
+  else
+    hipLaunchKernelGGL(mix_ln_bwd_kernel<MT_MAX_BRANCHES>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)dy,
+                       (const h16*)o_br, lse_br, lse_tot, p, ln_w, stats, (h16*)dmixed, delta_br);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
