@@ -1,0 +1,78 @@
+"""Eval / embedding-extraction pass: the forward kernels of the train step without the backward.
+
+Reference: train_modaltune.py:156-179 (`multitask_forward`: one model call per task id, concatenated) and
+train_modaltune.py:252-327 (`get_features`: eval mode, no_grad, logits [3, 256] per case for train / val / test,
+stacked on the host for the CPU-side probes).  Here the task passes of a slide are ONE batched engine call (B = len
+(task_ids)) with need_grad = False (no activations are saved), optionally replayed from a captured hipGraph.
+The probes themselves (sklearn LogisticRegression / lifelines Cox, TM:329-458) are host code and out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .engine import Engine, F32
+
+
+def multitask_forward(model, task_ids: Optional[Sequence[int]] = None, num_tasks: Optional[int] = None, **kwargs) -> torch.Tensor:
+    """Drop-in for the trainer's `multitask_forward` (TM:156-179): logits [len(task_ids), output_dim].
+    kwargs as the reference passes them: x, coords, genes, clinical."""
+    if not model.is_multi:
+        return model(**kwargs)
+    num_tasks = num_tasks or model.cfg.multi_task
+    onehots = torch.eye(num_tasks, dtype=F32)[list(task_ids)]
+    return model.forward_tasks(kwargs["x"], kwargs["coords"], kwargs["genes"], onehots, clinical=kwargs.get("clinical"))
+
+
+class EmbeddingExtractor:
+    """Forward-only pass over slides with static buffers + hipGraph replay per bag geometry."""
+
+    def __init__(self, engine: Engine, task_ids: Sequence[int] = (0, 1, 2), graphed: bool = True):
+        self.engine, self.dev, self.graphed = engine, engine.device, graphed
+        nt = max(1, engine.cfg.multi_task)
+        self.onehots = torch.eye(nt, dtype=F32, device=self.dev)[list(task_ids)].contiguous()
+        self._key = None
+
+    @torch.no_grad()
+    def __call__(self, x, coords, genes: Sequence[torch.Tensor], clinical=None) -> torch.Tensor:
+        """Logits (= the slide embeddings the probes consume) [len(task_ids), output_dim], on the device."""
+        eng = self.engine
+        x = x.reshape(-1, x.shape[-1])
+        L, B = x.shape[0], self.onehots.shape[0]
+        if isinstance(genes, dict):
+            genes = [genes[k] for k in sorted(genes.keys())]
+        if not self.graphed:
+            return eng.forward(x, coords, list(genes), self.onehots, need_grad=False, clinical=clinical)
+        key = (L, tuple(int(g.numel()) for g in genes))
+        if key != self._key:
+            self._key, self._graph, self._warm = key, None, 0
+            self._sgenes = [torch.empty(1, int(g.numel()), dtype=F32, device=self.dev) for g in genes]
+            self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
+        eng.stage_inputs(x, coords, B=B)
+        for dst, g in zip(self._sgenes, genes):
+            dst.copy_(g.reshape(1, -1))
+        if self._sclin is not None:
+            self._sclin.copy_(clinical.reshape(1, -1))
+        run = lambda: eng.forward(None, None, self._sgenes, self.onehots, need_grad=False, staged=True, geometry=(B, L),
+                                  clinical=self._sclin)
+        if self._graph is None and self._warm < 1:
+            self._warm += 1
+            return run()
+        if self._graph is None:
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                self._out = run()
+        self._graph.replay()
+        return self._out
+
+
+def get_features(extractor: EmbeddingExtractor, slides: Iterable[Dict]) -> Tuple[np.ndarray, List]:
+    """Host-side collection as TM:262-327 does per split: returns (features [n, tasks, O], case ids)."""
+    feats, ids = [], []
+    for s in slides:
+        feats.append(extractor(s["x"], s["coords"], s["genes"], s.get("clinical")).float().cpu().numpy())
+        ids.append(s.get("case_id"))
+    return np.stack(feats) if feats else np.zeros((0,)), ids

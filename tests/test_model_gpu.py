@@ -213,3 +213,31 @@ def test_clinical_module_and_pancancer_task_width(golden_dir):
         ref = O.multitask_logits(sdt, cfg4, torch.from_numpy(inp["x"]), torch.from_numpy(inp["coords"]),
                                  [torch.from_numpy(a) for a in inp["genes"]], segment_lengths(), task_ids=(0, 1, 2))
     assert _rel(out.cpu().numpy(), ref.numpy()) < 1e-3
+
+
+def test_eval_embedding_path_matches_training_forward(golden_dir):
+    """the forward-only pass (batched task passes, hipGraph replay) gives the train step's logits
+    (reference: the same model call under eval()/no_grad, train_modaltune.py:252-327)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.evaluate import EmbeddingExtractor, get_features
+    g = np.load(os.path.join(golden_dir, "model_L1500_d3.npz"))
+    L, seed, ngrids = int(g["L"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)), slide_ngrids=ngrids)
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed))
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    ex = EmbeddingExtractor(eng)
+    outs = [ex(x, inp["coords"], genes).clone() for _ in range(3)]          # eager warm-up, capture, replay
+    torch.cuda.synchronize()
+    for o in outs:
+        assert _rel(o.cpu().numpy(), g["f64_logits"]) < 1e-3
+    assert torch.equal(outs[1], outs[2])
+    feats, ids = get_features(EmbeddingExtractor(eng, graphed=False),
+                              [dict(x=x, coords=inp["coords"], genes=genes, case_id="c0")])
+    assert feats.shape == (1, 3, 256) and ids == ["c0"]
+    assert _rel(feats[0], g["f64_logits"]) < 1e-3
