@@ -50,6 +50,11 @@ def cpu_baseline_leg(cfg, sizes, L, seed, max_seconds=20.0):
                       f"step = 36 layer passes (3 tasks x 12 layers) -> {36 * t:.1f} s/slide"}
 
 
+# HBM bytes per launch of the dominant kernel from PMC passes that cannot run inside this script (separate rocprofv3
+# runs, one counter per pass): {(patches, tokens): bytes}.  FETCH_SIZE 373 139 KB, WRITE_SIZE 174 393 KB at L = 10 000.
+RECORDED_KV_TRAFFIC = {(10000, 65): 2 * 373139 * 1024 + 174393 * 1024}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,8 +171,12 @@ def main():
             "loss": loss, "skipped_steps": skipped,
             "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / world / 1e12 / PEAK_F16_MFMA_TFLOPS,
             "roofline": {"kernel": "dilated_attn_bwd_kv_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS,
+                         "traffic": RECORDED_KV_TRAFFIC.get((L, T)),
                          "avg_launch_ms": ms / n_l, "flops_per_launch": launch_flops,
+                         "traffic_source": ("recorded rocprofv3 --pmc passes (profiles/r01_pmc_hbm_attn_bwd.txt): 2 x FETCH_SIZE "
+                                            "(gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, bytes per launch"
+                                            if (L, T) in RECORDED_KV_TRAFFIC else None),
                          "measured": f"HIP events around each launch, eager instrumented pass of {prof_steps} steps after the timed region"},
             "launch": "eager" if args.eager else "hipGraph replay",
             "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]},
