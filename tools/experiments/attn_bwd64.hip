@@ -1,6 +1,12 @@
-// EXPERIMENT (not built): measured on MI355X at L = 10000 this form ran the dK/dV pass 9 % SLOWER than the 32-key kernel in
-// attn.hip (1.00 vs 0.92 ms): with one wave per SIMD the compiler-made schedule leaves the exp/convert block exposed.
-// Kept as the starting point for a hand-scheduled version.
+// EXPERIMENT (not built).  Measured on MI355X at L = 10000:
+//   * first form (straight per-sub loop): 9 % SLOWER than the 32-key kernel in attn.hip (1.00 vs 0.92 ms): with one wave
+//     per SIMD the compiler-made schedule left the exp/convert block exposed;
+//   * this form (software pipeline A(u+1), V(u), C(u-1) over the (sub, key-block) steps, row constants as initial
+//     accumulators): on par with the 32-key kernel (10.79 vs 10.75 ms/step; LDS pipe 23 % busy instead of 50 %, MFMA 37 %,
+//     VALU 36 %, wave 25 % in issue stalls + 25 % parked) -- the LDS pressure is gone but one wave per SIMD does not
+//     overlap its own MFMA and VALU streams well enough; forcing an interleave with sched_group_barrier (-DMT_SGB) spills
+//     into AGPR copies and is 1-2 % slower.
+// Kept as the starting point for a hand-placed schedule.
 // Dilated attention backward, dK/dV kernel with 64 keys per wave (see attn.hip for the algorithm and the 32-key form).
 //
 // Why a second form: PMC counters on the 32-keys-per-wave kernel (profiles/r01_pmc_attn_bwd.txt) show the LDS pipe as
@@ -98,7 +104,7 @@ void dilated_attn_bwd_kv64_kernel(const h16* __restrict__ qkv, const h16* __rest
     }
     if (tid < 64) {      // padded / out-of-range queries contribute nothing: -L2 = -big -> P' = 0
       const bool ok = FULL || ok2;
-      L2s[buf][tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) : -1.0e30f;
+      L2s[buf][tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) * (1.0f / c) : -1.0e30f;     // initial accumulator of the S chain
       Dls[buf][tid] = ok ? -rdl : 0.f;
     }
   };
@@ -112,59 +118,89 @@ void dilated_attn_bwd_kv64_kernel(const h16* __restrict__ qkv, const h16* __rest
 
   // tile t sits in LDS buffer t & 1; tile t + 1 travels global -> registers during the MFMAs and registers -> the other
   // buffer after them: one barrier per tile.  next_tag: tile t + 1 is a full tile.
+  // Software pipeline over the four (sub, kb) steps u of a tile: A(u) = S / dP chains of 32 queries x 32 keys,
+  // V(u) = the exp / convert block, C(u) = the dV / dK products.  Program order is A(u+1), V(u), C(u-1): the VALU block
+  // of step u has the MFMAs of its two neighbours to hide under (they do not depend on it).
   auto tile = [&](int t, auto next_tag) {
     const int buf = t & 1;
     if (t + 1 < ntile) gload(t + 1, next_tag);
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      f32x16 s[2], dp[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
+    f32x16 s[2], dp[2];            // two pipeline slots: step u in slot u & 1
+    h16x8 pf[2][2], dsf[2][2];     // slot u & 1
+    h16x8 qa[3], da[3];
+    h16x8 d0[2], d1[2], q0[2], q1[2];
+    auto load_rows = [&](int sub) {
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qs[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
-        const h16x8 da = *reinterpret_cast<const h16x8*>(&Ds[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[kb][ks], s[kb], 0, 0, 0);
-          dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[kb][ks], dp[kb], 0, 0, 0);
-        }
+        qa[ks] = *reinterpret_cast<const h16x8*>(&Qs[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        da[ks] = *reinterpret_cast<const h16x8*>(&Ds[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
       }
-      // rows of the accumulators are queries: row(i) = (i&3) + 8 (i>>2) + 4 hh
-      h16x8 pf[2][2], dsf[2][2];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 nl2 = *reinterpret_cast<const f32x4*>(&L2s[buf][sub * 32 + 8 * g4 + 4 * hh]);
-        const f32x4 ndl = *reinterpret_cast<const f32x4*>(&Dls[buf][sub * 32 + 8 * g4 + 4 * hh]);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const int i = 4 * g4 + e;
-            const f32x2 pt = pk_exp2(pk_fma((f32x2){s[kb][i], s[kb][i + 1]}, c2, (f32x2){nl2[e], nl2[e + 1]}));
-            const f32x2 d = pt * ((f32x2){dp[kb][i], dp[kb][i + 1]} + (f32x2){ndl[e], ndl[e + 1]});
-            pf[kb][i >> 3][i & 7] = (h16)pt[0]; pf[kb][i >> 3][(i & 7) + 1] = (h16)pt[1];
-            dsf[kb][i >> 3][i & 7] = (h16)d[0]; dsf[kb][i >> 3][(i & 7) + 1] = (h16)d[1];
-          }
-      }
+    };
+    auto load_tr = [&](int sub) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int roff = (sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp;
-        const h16x8 d0 = cat8(lds_tr4(&Dt[buf][roff]), lds_tr4(&Dt[buf][roff + 8 * VSTR]));
-        const h16x8 d1 = cat8(lds_tr4(&Dt[buf][roff + 32]), lds_tr4(&Dt[buf][roff + 8 * VSTR + 32]));
-        const h16x8 q0 = cat8(lds_tr4(&Qt[buf][roff]), lds_tr4(&Qt[buf][roff + 8 * VSTR]));
-        const h16x8 q1 = cat8(lds_tr4(&Qt[buf][roff + 32]), lds_tr4(&Qt[buf][roff + 8 * VSTR + 32]));
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          dv0[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, pf[kb][s2], dv0[kb], 0, 0, 0);
-          dv1[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, pf[kb][s2], dv1[kb], 0, 0, 0);
-          dk0[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, dsf[kb][s2], dk0[kb], 0, 0, 0);
-          dk1[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, dsf[kb][s2], dk1[kb], 0, 0, 0);
-        }
+        d0[s2] = cat8(lds_tr4(&Dt[buf][roff]), lds_tr4(&Dt[buf][roff + 8 * VSTR]));
+        d1[s2] = cat8(lds_tr4(&Dt[buf][roff + 32]), lds_tr4(&Dt[buf][roff + 8 * VSTR + 32]));
+        q0[s2] = cat8(lds_tr4(&Qt[buf][roff]), lds_tr4(&Qt[buf][roff + 8 * VSTR]));
+        q1[s2] = cat8(lds_tr4(&Qt[buf][roff + 32]), lds_tr4(&Qt[buf][roff + 8 * VSTR + 32]));
       }
+    };
+    auto stepA = [&](int u) {      // S, dP of step u; row constants ride in as the initial accumulators
+      const int sub = u >> 1, kb = u & 1, sl = u & 1;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&L2s[buf][sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Dls[buf][sub * 32 + 8 * g4 + 4 * hh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[sl][4 * g4 + e] = a[e]; dp[sl][4 * g4 + e] = b[e]; }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        s[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kf[kb][ks], s[sl], 0, 0, 0);
+        dp[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(da[ks], vf[kb][ks], dp[sl], 0, 0, 0);
+      }
+    };
+    auto stepV = [&](int u) {
+      const int sl = u & 1;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 pt = pk_exp2((f32x2){s[sl][i], s[sl][i + 1]} * c2);
+        const f32x2 d = pt * (f32x2){dp[sl][i], dp[sl][i + 1]};
+        pf[sl][i >> 3][i & 7] = (h16)pt[0]; pf[sl][i >> 3][(i & 7) + 1] = (h16)pt[1];
+        dsf[sl][i >> 3][i & 7] = (h16)d[0]; dsf[sl][i >> 3][(i & 7) + 1] = (h16)d[1];
+      }
+    };
+    auto stepC = [&](int u) {
+      const int kb = u & 1, sl = u & 1;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        dv0[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0[s2], pf[sl][s2], dv0[kb], 0, 0, 0);
+        dv1[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1[s2], pf[sl][s2], dv1[kb], 0, 0, 0);
+        dk0[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0[s2], dsf[sl][s2], dk0[kb], 0, 0, 0);
+        dk1[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1[s2], dsf[sl][s2], dk1[kb], 0, 0, 0);
+      }
+    };
+    // sub 0
+    load_rows(0);
+    stepA(0);
+    load_tr(0);
+    stepA(1); stepV(0);
+    load_rows(1);
+    stepA(2); stepV(1); stepC(0);
+    stepC(1);
+    // sub 1 (tr fragments of sub 0 are dead after C(1))
+    load_tr(1);
+    stepA(3); stepV(2);
+    stepV(3); stepC(2);
+    stepC(3);
+#ifdef MT_SGB
+#pragma unroll
+    for (int i = 0; i < 56; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
     }
+#endif
     if (t + 1 < ntile) lstore(buf ^ 1, next_tag);
     __syncthreads();
   };
