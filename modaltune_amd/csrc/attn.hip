@@ -527,8 +527,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 //   dP[q,key] = dO . V^T           dO rows from LDS, V^T in registers
 //   P' = exp2(c S - L2[q] + log2(scale)) ; dS = P' (dP - delta[q])        (P' = P~ / sqrt(48))
 //   dV^T[d,key] += dO^T[d,q] . P'  (rescaled by sqrt(48) once at the end) ; dK^T[d,key] += Q^T[d,q] . dS
-// LDS holds -L2 + log2(scale) and -delta per query so the elementwise block is 2 packed fma/add, 2 exp, 1 packed mul
-// and 2 packed converts per element pair.
+// LDS holds (-L2 + log2 scale) / c and -delta per query; they are read straight into the S / dP accumulators before the
+// MFMA chains, so the elementwise block is 2 packed mul, 2 exp and 2 packed converts per element pair.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     }
     if (tid < 64) {      // padded / out-of-range queries contribute nothing: -L2 = -big -> P' = 0
       const bool ok = FULL || ok2;
-      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) : -1.0e30f;
+      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) * (1.0f / c) : -1.0e30f;
       Dls[tid] = ok ? -rdl : 0.f;
     }
   };
@@ -626,9 +626,16 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     if (t + 1 < ntile) gload(t + 1, next_tag);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      // row constants ride in as the INITIAL accumulators (rows of the accumulators are queries:
+      // row(i) = (i&3) + 8 (i>>2) + 4 hh): S' = Q.K^T + (-L2 + log2 scale) / c, dP' = dO.V^T - delta
       f32x16 s, dp;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&L2s[sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Dls[sub * 32 + 8 * g4 + 4 * hh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a[e]; dp[4 * g4 + e] = b[e]; }
+      }
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qs[(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
@@ -636,20 +643,13 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
         const h16x8 da = *reinterpret_cast<const h16x8*>(&Ds[(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp, 0, 0, 0);
       }
-      // rows of the accumulators are queries: row(i) = (i&3) + 8 (i>>2) + 4 hh
       h16x8 pf[2], dsf[2];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 nl2 = *reinterpret_cast<const f32x4*>(&L2s[sub * 32 + 8 * g4 + 4 * hh]);
-        const f32x4 ndl = *reinterpret_cast<const f32x4*>(&Dls[sub * 32 + 8 * g4 + 4 * hh]);
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          const int i = 4 * g4 + e;
-          const f32x2 pt = pk_exp2(pk_fma((f32x2){s[i], s[i + 1]}, c2, (f32x2){nl2[e], nl2[e + 1]}));
-          const f32x2 d = pt * ((f32x2){dp[i], dp[i + 1]} + (f32x2){ndl[e], ndl[e + 1]});
-          pf[i >> 3][i & 7] = (h16)pt[0]; pf[i >> 3][(i & 7) + 1] = (h16)pt[1];
-          dsf[i >> 3][i & 7] = (h16)d[0]; dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
-        }
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]} * c2);
+        const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
+        pf[i >> 3][i & 7] = (h16)pt[0]; pf[i >> 3][(i & 7) + 1] = (h16)pt[1];
+        dsf[i >> 3][i & 7] = (h16)d[0]; dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
