@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--patches", type=int, default=10000)
-    ap.add_argument("--pathways", type=int, default=6)
+    ap.add_argument("--pathways", default="6", help="number of toy pathways (sizes 5, 6, ...) or 'real': the reference's 331-pathway "
+                                                    "grouping sizes (tests/golden/pathway_sizes_331.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-times", action="store_true", help="print the per-kernel time table (stderr)")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
@@ -89,7 +90,11 @@ def main():
 
     L = args.patches
     cfg = ModelConfig()                       # Prov-GigaPath ModalAdapter config (modaltune_gigapath_config.json)
-    sizes = synth.toy_group_sizes(args.pathways)
+    if args.pathways == "real":
+        sizes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "pathway_sizes_331.json")))
+    else:
+        sizes = synth.toy_group_sizes(int(args.pathways))
+    args.pathways = len(sizes)
     eng = Engine(cfg, sizes, dev)
     eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed=0))      # identical weights on every rank
     ts = TrainStep(eng)

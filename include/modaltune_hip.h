@@ -166,6 +166,19 @@ int mt_extract_attn_fwd(const float* q, const mt_half* kv, int B, int T, int L, 
 int mt_extract_attn_bwd(const float* q, const mt_half* kv, const float* out, const float* lse, const float* dout,
                         int B, int T, int L, float* dq, mt_half* dkv, mt_stream_t stream);
 
+/* Pathway networks of the gene encoder, all G pathways in one launch (gene_encoder.py:97-131,194-207: per pathway
+ * SNN_Block(n_i -> latent), SNN_Block(latent -> latent), ELU, AlphaDropout off):
+ *   z[i] = ELU(W2_i ELU(W1_i g_i + b1_i) + b2_i).
+ * params / grads: the flat fp32 parameter / gradient buffers; offs [G][4] = element offsets of (W1_i [latent, n_i],
+ * b1_i, W2_i [latent, latent], b2_i) (W2 offsets multiples of 4); sizes [G] = n_i; goff [G] = offset of g_i in the
+ * concatenated `genes` vector; a1, a2 [G, latent] pre-activations saved for the backward; latent must be 256. */
+int mt_gene_snn_fwd(const float* params, const long* offs, const int* sizes, const long* goff, const float* genes, int G,
+                    int latent, float* a1, float* a2, float* z, mt_stream_t stream);
+/* backward: grads (+)= dW1, db1, dW2, db2 for every pathway given dz [G, latent] (no input gradient: genes are data) */
+int mt_gene_snn_bwd(const float* params, float* grads, const long* offs, const int* sizes, const long* goff,
+                    const float* genes, int G, int latent, const float* a1, const float* a2, const float* dz,
+                    mt_stream_t stream);
+
 /* Small dense multi-head attention over tokens (prompt self-attention AM:87): q,k,v fp32 [B,T,E], heads h. */
 int mt_token_mha_fwd(const float* q, const float* k, const float* v, int B, int T, int E, int heads, float* out,
                      float* probs, mt_stream_t stream);

@@ -1,0 +1,147 @@
+// Grouped pathway networks of the gene encoder (gene_encoder.py:97-131,194-207): for each of G pathways
+//   z_i = ELU(W2_i ELU(W1_i g_i + b1_i) + b2_i),  W1_i [latent, n_i], W2_i [latent, latent], g_i [n_i]
+// With the real grouping (G = 331, n_i = 1..199, 24 M parameters) the reference runs 662 tiny nn.Linear modules; here
+// ONE launch per direction walks all pathways: workgroup = pathway, thread = output unit, weights streamed through LDS
+// in 32-column chunks with coalesced loads.  HBM-bound on the weights (forward reads them once; backward reads W2 once
+// and read-modify-writes the gradient slots).  Parameters are addressed by element offsets into the flat fp32
+// parameter / gradient buffers (the per-pathway tensors keep their reference state_dict names and order).
+#include "common.h"
+
+namespace {
+
+constexpr int GL = 256;      // latent width = workgroup size
+constexpr int GC = 32;       // chunk width
+
+MT_DEVINL float elu(float v) { return v > 0.f ? v : expm1f(v); }
+MT_DEVINL float elu_grad(float pre) { return pre > 0.f ? 1.f : __expf(pre); }
+
+struct GeneArgs {
+  const float* params; float* grads;
+  const long* offs;      // [G][4]: w1, b1, w2, b2 (element offsets)
+  const int* sizes;      // [G]
+  const long* goff;      // [G] offset of g_i in `genes`
+  const float* genes;
+  float* a1; float* a2;  // [G][latent] pre-activations (saved)
+  float* z;              // [G][latent] forward output
+  const float* dz;       // [G][latent]
+};
+
+// y[j] = bias[j] + sum_k W[j][k] x[k]  (thread j), W row-major [GL][n] streamed through LDS, x in LDS
+MT_DEVINL float gemv_rows(const float* __restrict__ W, int n, const float* xs, float (*Ws)[GC + 1], float acc) {
+  const int j = threadIdx.x;
+  for (int k0 = 0; k0 < n; k0 += GC) {
+    const int kc = min(GC, n - k0);
+    __syncthreads();
+    for (int i = j; i < GL * GC; i += GL) {       // 8 rows of 32 columns per pass: 128-B coalesced row segments
+      const int r = i / GC, c = i - r * GC;
+      Ws[r][c] = c < kc ? W[(long)r * n + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int c = 0; c < GC; ++c) acc = fmaf(Ws[j][c], (k0 + c < n) ? xs[k0 + c] : 0.f, acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(GL) void gene_snn_fwd_kernel(GeneArgs a) {
+  __shared__ float Ws[GL][GC + 1];
+  __shared__ float xs[GL];
+  const int i = blockIdx.x, j = threadIdx.x;
+  const int n = a.sizes[i];
+  const long* o = a.offs + 4L * i;
+  const float* g = a.genes + a.goff[i];
+  float acc = a.params[o[1] + j];
+  // first layer: n can exceed the LDS vector; walk it in pieces of GL
+  for (int p0 = 0; p0 < n; p0 += GL) {
+    const int pn = min(GL, n - p0);
+    __syncthreads();
+    if (j < pn) xs[j] = g[p0 + j];
+    __syncthreads();
+    // rows of W1 restricted to columns [p0, p0 + pn): row stride n
+    for (int k0 = 0; k0 < pn; k0 += GC) {
+      const int kc = min(GC, pn - k0);
+      __syncthreads();
+      for (int t = j; t < GL * GC; t += GL) {
+        const int r = t / GC, c = t - r * GC;
+        Ws[r][c] = c < kc ? a.params[o[0] + (long)r * n + p0 + k0 + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int c = 0; c < GC; ++c) acc = fmaf(Ws[j][c], (k0 + c < pn) ? xs[k0 + c] : 0.f, acc);
+    }
+  }
+  a.a1[(long)i * GL + j] = acc;
+  __syncthreads();
+  xs[j] = elu(acc);
+  float acc2 = gemv_rows(a.params + o[2], GL, xs, Ws, a.params[o[3] + j]);
+  a.a2[(long)i * GL + j] = acc2;
+  a.z[(long)i * GL + j] = elu(acc2);
+}
+
+__global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
+  __shared__ float Ws[GC][GL + 1];   // 32 rows x 256 columns of W2
+  __shared__ float da2s[GL], h1s[GL], da1s[GL];
+  const int i = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const int n = a.sizes[i];
+  const long* o = a.offs + 4L * i;
+  const float pre1 = a.a1[(long)i * GL + j], pre2 = a.a2[(long)i * GL + j];
+  const float da2 = a.dz[(long)i * GL + j] * elu_grad(pre2);
+  da2s[j] = da2;
+  h1s[j] = elu(pre1);
+  a.grads[o[3] + j] += da2;
+  __syncthreads();
+  // dW2[r][c] += da2[r] h1[c]: one wave per row, 16-byte accesses
+  for (int r = wave; r < GL; r += 4) {
+    float* dst = a.grads + o[2] + (long)r * GL + lane * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(dst);
+    const float d = da2s[r];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaf(d, h1s[lane * 4 + e], v[e]);
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+  // dh1[k] = sum_r W2[r][k] da2[r] (thread k): W2 streamed 32 rows at a time, coalesced
+  float dh1 = 0.f;
+  for (int r0 = 0; r0 < GL; r0 += GC) {
+    __syncthreads();
+    for (int t = j; t < GC * GL; t += GL) {
+      const int r = t / GL, c = t - r * GL;
+      Ws[r][c] = a.params[o[2] + (long)(r0 + r) * GL + c];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < GC; ++r) dh1 = fmaf(Ws[r][j], da2s[r0 + r], dh1);
+  }
+  const float da1 = dh1 * elu_grad(pre1);
+  a.grads[o[1] + j] += da1;
+  da1s[j] = da1;
+  __syncthreads();
+  // dW1[r][k] += da1[r] g[k]: rows of n floats (4-byte accesses: the slots are only 4-byte aligned inside a row)
+  const float* g = a.genes + a.goff[i];
+  for (long t = j; t < (long)GL * n; t += GL) {
+    const int r = (int)(t / n), k = (int)(t - (long)r * n);
+    a.grads[o[0] + t] += da1s[r] * g[k];
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_gene_snn_fwd(const float* params, const long* offs, const int* sizes, const long* goff, const float* genes,
+                               int G, int latent, float* a1, float* a2, float* z, mt_stream_t stream) {
+  if (!params || !offs || !sizes || !goff || !genes || !a1 || !a2 || !z || G < 1) return MT_ERR_BAD_ARG;
+  if (latent != GL) return MT_ERR_UNSUPPORTED;
+  GeneArgs a{params, nullptr, offs, sizes, goff, genes, a1, a2, z, nullptr};
+  hipLaunchKernelGGL(gene_snn_fwd_kernel, dim3(G), dim3(GL), 0, (hipStream_t)stream, a);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_gene_snn_bwd(const float* params, float* grads, const long* offs, const int* sizes, const long* goff,
+                               const float* genes, int G, int latent, const float* a1, const float* a2, const float* dz,
+                               mt_stream_t stream) {
+  if (!params || !grads || !offs || !sizes || !goff || !genes || !a1 || !a2 || !dz || G < 1) return MT_ERR_BAD_ARG;
+  if (latent != GL) return MT_ERR_UNSUPPORTED;
+  GeneArgs a{params, grads, offs, sizes, goff, genes, const_cast<float*>(a1), const_cast<float*>(a2), nullptr, dz};
+  hipLaunchKernelGGL(gene_snn_bwd_kernel, dim3(G), dim3(GL), 0, (hipStream_t)stream, a);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}

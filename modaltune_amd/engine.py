@@ -122,6 +122,15 @@ class Engine:
         self.taps: Dict[str, torch.Tensor] = {}
         self.T = cfg.num_tokens
         self._mean_w = torch.full((max(self.T, 2),), 1.0 / max(1, cfg.gene.final_groups), device=self.device)
+        # pathway networks (gene_networks.{i}.{0,1}.0.*): offset tables into the flat parameter / gradient buffers
+        sl, G = self.store.slots, len(self.group_sizes)
+        offs = [[sl[f"gene_encoder.gene_networks.{i}.{a}.0.{w}"][0] for a, w in ((0, "weight"), (0, "bias"), (1, "weight"), (1, "bias"))]
+                for i in range(G)]
+        goff = np.concatenate([[0], np.cumsum(self.group_sizes)[:-1]]).astype(np.int64)
+        self._gene_offs = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        self._gene_sizes = torch.tensor(self.group_sizes, dtype=torch.int32, device=self.device)
+        self._gene_goff = torch.from_numpy(goff).to(self.device)
+        self._gene_total = int(sum(self.group_sizes))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
@@ -315,26 +324,27 @@ class Engine:
         """GeneEncoder_Group.gene_encode (gene_encoder.py:194-215), batch 1."""
         tape, P, g = self.tape, self.store.param, self.cfg.gene
         G = len(self.group_sizes)
-        if len(genes) != G:
+        if not torch.is_tensor(genes) and len(genes) != G:
             raise ValueError(f"expected {G} gene groups, got {len(genes)}")
+        # all pathway networks in one launch per direction (the reference loops over 2 G nn.Linear modules)
+        if torch.is_tensor(genes):
+            gflat = genes.to(self.device, F32).reshape(-1)
+        else:
+            gflat = torch.cat([gi.reshape(-1) for gi in genes]).to(self.device, F32)
+        if gflat.numel() != self._gene_total:
+            raise ValueError(f"expected {self._gene_total} gene values in {G} groups, got {gflat.numel()}")
         z = Var(tape.new(1, G, g.latent_dim))
-        rows = []
-        for i, gi in enumerate(genes):
-            gi = gi.to(self.device, F32).reshape(1, -1).contiguous()
-            p = f"gene_encoder.gene_networks.{i}."
-            h1 = tape.linear(Var(gi, needs_grad=False), P(p + "0.0.weight"), P(p + "0.0.bias"), act=ops.ACT_ELU)
-            rows.append(tape.linear(h1, P(p + "1.0.weight"), P(p + "1.0.bias"), act=ops.ACT_ELU))
-        for i, r in enumerate(rows):      # torch.cat(x_in).unsqueeze(0)
-            ops.copy_rows(r.data, z.data[0, i:i + 1], 1, g.latent_dim)
-
+        a1, a2 = tape.new(G, g.latent_dim), tape.new(G, g.latent_dim)
+        st = self.store
+        ops.gene_snn_fwd(st.flat, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim, a1, a2, z.data)
         z0 = z          # (closures bind late: `z` is rebound by the mixer loop below)
 
-        def bwd_stack():
+        def bwd_networks():
             if z0.grad is None:
                 return
-            for i, r in enumerate(rows):
-                ops.copy_rows(z0.grad[0, i:i + 1], r.g(), 1, g.latent_dim, accumulate=True)
-        tape.record(bwd_stack)
+            ops.gene_snn_bwd(st.flat, st.flat_grad, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim,
+                             a1, a2, z0.grad)
+        tape.record(bwd_networks)
         for k in range(g.depth):
             p = f"gene_encoder.mlp_mixer.{k}."
             n1 = tape.layernorm(z, P(p + "0.norm.weight"), P(p + "0.norm.bias"))

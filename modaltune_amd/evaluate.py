@@ -45,14 +45,14 @@ class EmbeddingExtractor:
             genes = [genes[k] for k in sorted(genes.keys())]
         if not self.graphed:
             return eng.forward(x, coords, list(genes), self.onehots, need_grad=False, clinical=clinical)
-        key = (L, tuple(int(g.numel()) for g in genes))
+        gflat = genes.reshape(-1) if torch.is_tensor(genes) else torch.cat([g.reshape(-1) for g in genes])
+        key = (L, int(gflat.numel()))
         if key != self._key:
             self._key, self._graph, self._warm = key, None, 0
-            self._sgenes = [torch.empty(1, int(g.numel()), dtype=F32, device=self.dev) for g in genes]
+            self._sgenes = torch.empty(int(gflat.numel()), dtype=F32, device=self.dev)     # one flat static buffer
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
         eng.stage_inputs(x, coords, B=B)
-        for dst, g in zip(self._sgenes, genes):
-            dst.copy_(g.reshape(1, -1))
+        self._sgenes.copy_(gflat)
         if self._sclin is not None:
             self._sclin.copy_(clinical.reshape(1, -1))
         run = lambda: eng.forward(None, None, self._sgenes, self.onehots, need_grad=False, staged=True, geometry=(B, L),

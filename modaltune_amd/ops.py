@@ -142,6 +142,16 @@ def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
         TIMER.setdefault(name, []).append((e0, e1))
 
 
+def gene_snn_fwd(params, offs, sizes, goff, genes, G, latent, a1, a2, z):
+    check(_lib.load().mt_gene_snn_fwd(_p(params), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, _p(a1), _p(a2), _p(z),
+                                      _s()), "gene_snn_fwd")
+
+
+def gene_snn_bwd(params, grads, offs, sizes, goff, genes, G, latent, a1, a2, dz):
+    check(_lib.load().mt_gene_snn_bwd(_p(params), _p(grads), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, _p(a1),
+                                      _p(a2), _p(dz), _s()), "gene_snn_bwd")
+
+
 def inject_attn_fwd(q, k, v, a, M, rows_per_pass, T, lse=None):
     check(_lib.load().mt_inject_attn_fwd(_p(q), M, rows_per_pass, _p(k), _p(v), T, _p(a), _p(lse), _s()), "inject_attn_fwd")
 

@@ -90,15 +90,15 @@ class TrainStep:
         x = x.reshape(-1, x.shape[-1])
         L = x.shape[0]
         B = self.onehots.shape[0]
-        key = (L, tuple(int(g.numel()) for g in genes))
+        gflat = genes.reshape(-1) if torch.is_tensor(genes) else torch.cat([g.reshape(-1) for g in genes])
+        key = (L, int(gflat.numel()))
         if getattr(self, "_gkey", None) != key:
             self._gkey, self._graphs, self._gwarm = key, None, 0
-            self._sgenes = [torch.empty(1, int(g.numel()), dtype=F32, device=self.dev) for g in genes]
+            self._sgenes = torch.empty(int(gflat.numel()), dtype=F32, device=self.dev)     # one flat static buffer
             self._stext = torch.empty(tuple(text.shape), dtype=F32, device=self.dev)
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
         eng.stage_inputs(x, coords, B=B)
-        for dst, g in zip(self._sgenes, genes):
-            dst.copy_(g.reshape(1, -1))
+        self._sgenes.copy_(gflat)
         self._stext.copy_(text)
         if self._sclin is not None:
             self._sclin.copy_(clinical.reshape(1, -1))

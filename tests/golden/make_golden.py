@@ -122,6 +122,28 @@ def unit_gene(seed=3):
     np.savez_compressed(os.path.join(HERE, "unit_gene.npz"), seed=seed, **out)
 
 
+def unit_gene331(seed=5):
+    """The reference-default pathway grouping: sizes = genes per pathway in the reference's own grouping table
+    (dataset/gene_pathway_processed_v2.csv, 331 pathways, 1..199 genes) -> reference GeneEncoder_Group output."""
+    import pandas as pd
+    table = pd.read_csv("/root/reference/dataset/gene_pathway_processed_v2.csv")
+    sizes = [int(v) for v in table.drop(columns=["gene"]).sum(0).values]
+    json.dump(sizes, open(os.path.join(HERE, "pathway_sizes_331.json"), "w"))
+    cfg = ModelConfig.from_json(REF_CFG, depth=3, interaction_indexes=[[0, 0], [1, 1], [2, 2]])
+    dt = torch.float64
+    sd = synth.synth_state_dict(cfg, sizes, seed)
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    ge = GeneBaseClass.create("gene_mixer_group", latent_dim=256, depth=3, expansion_groups=0.5, expansion_dim=0.5,
+                              dropout=0.25, cls_token=False, n_classes=2, final_groups=64, output_dim=768,
+                              mode="feature", group_sizes=groups, n_groups=len(groups)).double()
+    ge.load_state_dict(sub_state(sd, "gene_encoder.", dt), strict=True)
+    ref_shims.zero_dropout(ge)
+    ge.eval()
+    genes = synth.synth_inputs(8, sizes, seed)["genes"]
+    y = ge({i: tt(g, dt) for i, g in enumerate(genes)})
+    np.savez_compressed(os.path.join(HERE, "unit_gene331.npz"), seed=seed, y=y.detach().numpy().astype(np.float32))
+
+
 GRAD_KEYS_FULL = ["interactions.0.injector.gamma", "interactions.1.injector.gamma", "final_project.bias",
                   "interactions.0.injector.attn.q_proj.bias", "task_weight.0.weight",
                   "gene_encoder.pathway_compression.weight", "interactions.2.extractor.ffn.linear1.bias"]
@@ -213,6 +235,8 @@ if __name__ == "__main__":
         unit_layer()
     if "gene" in which:
         unit_gene()
+    if "gene331" in which:
+        unit_gene331()
     if "m37" in which:
         model_case("L37_d3", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=11)
     if "m1500" in which:

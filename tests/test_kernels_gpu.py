@@ -513,3 +513,77 @@ def test_elementwise(ops):
     ops.cast_f16_to_f32(h, back)
     torch.cuda.synchronize()
     assert torch.equal(h.cpu(), x.half()) and torch.equal(back.cpu(), x.half().float())
+
+
+# ------------------------------------------------------------------------------------------ grouped pathway networks
+@pytest.mark.parametrize("sizes", [[1, 5, 199, 33, 64, 300, 7], [9] * 40])
+def test_gene_snn_grouped(ops, sizes):
+    """All pathway networks in one launch vs per-pathway torch (gene_encoder.py:97-131): forward and weight grads."""
+    g = rng(len(sizes))
+    G, Lt = len(sizes), 256
+    offs, pieces, cur = [], [], 0
+
+    def slot(t):
+        nonlocal cur
+        o = cur
+        pieces.append(t.reshape(-1))
+        pad = (-t.numel()) % 4
+        if pad:
+            pieces.append(torch.zeros(pad))
+        cur += t.numel() + pad
+        return o
+    W1 = [torch.randn(Lt, n, generator=g) * 0.3 for n in sizes]
+    b1 = [torch.randn(Lt, generator=g) * 0.1 for _ in sizes]
+    W2 = [torch.randn(Lt, Lt, generator=g) * 0.06 for _ in sizes]
+    b2 = [torch.randn(Lt, generator=g) * 0.1 for _ in sizes]
+    for i in range(G):
+        offs.append([slot(W1[i]), slot(b1[i]), slot(W2[i]), slot(b2[i])])
+    flat = torch.cat(pieces)
+    genes = [torch.randn(n, generator=g) for n in sizes]
+    dz = torch.randn(G, Lt, generator=g)
+    goff = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    # reference
+    ref_z, params = [], []
+    for i in range(G):
+        ps = [t.double().requires_grad_(True) for t in (W1[i], b1[i], W2[i], b2[i])]
+        params.append(ps)
+        h = torch.nn.functional.elu(ps[0] @ genes[i].double() + ps[1])
+        ref_z.append(torch.nn.functional.elu(ps[2] @ h + ps[3]))
+    ref_z = torch.stack(ref_z)
+    ref_z.backward(dz.double())
+    d = lambda t: t.to(DEV)
+    a1, a2, z = (torch.zeros(G, Lt, device=DEV) for _ in range(3))
+    grads = torch.zeros_like(flat).to(DEV)
+    t_offs = torch.tensor(offs, dtype=torch.int64, device=DEV)
+    t_sizes = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+    t_goff = torch.from_numpy(goff).to(DEV)
+    gflat = d(torch.cat(genes))
+    ops.gene_snn_fwd(d(flat), t_offs, t_sizes, t_goff, gflat, G, Lt, a1, a2, z)
+    ops.gene_snn_bwd(d(flat), grads, t_offs, t_sizes, t_goff, gflat, G, Lt, a1, a2, d(dz))
+    torch.cuda.synchronize()
+    assert rel(z, ref_z) < 1e-5
+    gc = grads.cpu()
+    for i in range(G):
+        for j, t in enumerate(params[i]):
+            got = gc[offs[i][j]:offs[i][j] + t.numel()].view(t.shape)
+            assert rel(got, t.grad) < 1e-5, (i, j)
+
+
+def test_gene_encoder_331_pathways_vs_reference_golden(ops, golden_dir):
+    """Engine gene encoder with the reference-default grouping against the reference's output."""
+    import json
+    from modaltune_amd import synth
+    from modaltune_amd.config import ModelConfig
+    from modaltune_amd.engine import Engine
+    sizes = json.load(open(os.path.join(golden_dir, "pathway_sizes_331.json")))
+    g = np.load(os.path.join(golden_dir, "unit_gene331.npz"))
+    seed = int(g["seed"])
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)))
+    eng = Engine(cfg, sizes, DEV)
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed))
+    genes = [torch.from_numpy(a).to(DEV) for a in synth.synth_inputs(8, sizes, seed)["genes"]]
+    eng.tape.reset()
+    eng.tape.grad_enabled = False
+    y = eng._gene_encoder(genes)
+    torch.cuda.synchronize()
+    assert rel(y.data, torch.from_numpy(g["y"])) < 1e-4

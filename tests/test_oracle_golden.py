@@ -82,6 +82,18 @@ def test_gene_encoder(golden_dir, name):
     assert _maxrel(O.gene_encoder(genes, sd), g[f"{name}_y"]) < 1e-12
 
 
+def test_gene_encoder_reference_default_331_pathways(golden_dir):
+    """The real grouping (331 pathways, 1..199 genes each; sizes recorded from the reference's grouping table)."""
+    import json
+    sizes = json.load(open(os.path.join(golden_dir, "pathway_sizes_331.json")))
+    assert len(sizes) == 331 and min(sizes) == 1 and max(sizes) == 199
+    g = np.load(os.path.join(golden_dir, "unit_gene331.npz"))
+    seed = int(g["seed"])
+    sd = _sd(_small_cfg(), sizes, seed)
+    genes = [torch.from_numpy(a).double() for a in synth.synth_inputs(8, sizes, seed)["genes"]]
+    assert _maxrel(O.gene_encoder(genes, sd), g["y"]) < 3e-7          # fixture stored as float32
+
+
 def _run_model_case(path, dtype):
     g = np.load(path)
     L, depth, seed, ngrids = int(g["L"]), int(g["depth"]), int(g["seed"]), int(g["ngrids"])
