@@ -8,6 +8,8 @@
 // gemm_nt structure: 128 x BN x 64 tiles, 4 waves, v_mfma_f32_16x16x32_f16, double-buffered LDS filled by LDS-DMA
 // (global_load_lds_dwordx4, issued for tile t+1 before the MFMAs of tile t; one barrier per K-tile), XOR-swizzled
 // 128-B rows so the ds_read_b128 fragment reads are bank-conflict free.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -30,13 +32,25 @@ struct GemmNtArgs {
 // bank-conflict fix is an XOR swizzle applied on the per-lane SOURCE address and again on the fragment reads
 // (guide rule 21): the 16-B chunk c of tile row r lives at chunk position c ^ (r & 7); with it the 16-lane groups
 // of ds_read_b128 hit 16 distinct 16-B slots.
+constexpr int erows_for(int bm, int cs, int lds_bytes) {
+  int e = bm;
+  while (e * cs * 4 > lds_bytes) e /= 2;
+  return e;
+}
+
+// Tile choice: 128 x {128, 64} with 4 waves (two workgroups per CU) everywhere, and 256 x 256 with 8 waves (128 KB of
+// LDS, one workgroup per CU) for the wide outputs.  A K-tile of the 128^2 form moves 32 KB for 1024 MFMA cycles per SIMD,
+// i.e. it wants ~134 GB/s per CU from L2 at full MFMA rate against ~70 GB/s deliverable (MI355X_MICROARCH.md, gather into
+// LDS from L2): that form is L2->LDS bound near 50 %.  256^2 halves the bytes per flop; it needs >= ~4 tiles per CU to
+// amortise its one-workgroup-per-CU tail, so it is used for N >= 2304 only.
 template <int BM, int BN, int WM, int WN, int EPI, typename OutT>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmNtArgs g) {
+  constexpr int NT = WM * WN * 64;              // threads
   constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
   constexpr int MI = TM / 16, NI = TN / 16;     // 16x16 MFMA tiles per wave
-  constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;  // 16-B chunks per thread per K-tile
+  constexpr int ACH = BM * 8 / NT, BCH = BN * 8 / NT;  // 16-B chunks per thread per K-tile
   constexpr int CS = BN + 4;                    // fp32 epilogue staging stride (floats)
-  constexpr int EROWS = (BM * CS * 4 <= 2 * (BM + BN) * BK * 2) ? BM : BM / 2;   // epilogue rows per pass
+  constexpr int EROWS = erows_for(BM, CS, 2 * (BM + BN) * BK * 2);   // epilogue rows per pass
   static_assert(EROWS * CS * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the operand LDS");
   __shared__ __attribute__((aligned(16))) h16 smem[2 * (BM + BN) * BK];
   h16* const As0 = smem;
@@ -62,23 +76,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
   const h16* bptr[BCH];
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
-    const int m = min(m0 + i * 32 + srow, g.M - 1);
+    const int m = min(m0 + i * (NT / 8) + srow, g.M - 1);
     aptr[i] = g.A + g.amap.map(m) * g.lda + lchunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < BCH; ++i) {
-    const int n = min(n0 + i * 32 + srow, g.N - 1);
+    const int n = min(n0 + i * (NT / 8) + srow, g.N - 1);
     bptr[i] = g.W + (long)n * g.K + lchunk * 8;
   }
   auto stage = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < ACH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(As0 + buf * BM * BK + (i * 256 + wave * 64) * 8), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(As0 + buf * BM * BK + (i * NT + wave * 64) * 8), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < BCH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bptr[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(Bs0 + buf * BN * BK + (i * 256 + wave * 64) * 8), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(Bs0 + buf * BN * BK + (i * NT + wave * 64) * 8), 16, 0, 0);
   };
 
   f32x4 acc[MI][NI];
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
   float* Cs = reinterpret_cast<float*>(smem);
   OutT* C = reinterpret_cast<OutT*>(g.C);
   constexpr int CPR = BN / 4;                                  // float4 chunks per tile row
-  constexpr int RPP = 256 / CPR;                               // rows per pass
+  constexpr int RPP = NT / CPR;                                // rows per pass
   const int cc = (tid % CPR) * 4, r0 = tid / CPR;
   const int n = n0 + cc;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gm4 = {0.f, 0.f, 0.f, 0.f};
@@ -174,20 +188,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs g) {
 
 template <int BN, int EPI, typename OutT>
 int launch_nt(const GemmNtArgs& a, hipStream_t s) {
-  constexpr int BM = 128;
-  const int nwg = cdiv(a.M, BM) * cdiv(a.N, BN);
-  if (BN == 128)
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, 128, 2, 2, EPI, OutT>), dim3(nwg), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, 64, 4, 1, EPI, OutT>), dim3(nwg), dim3(256), 0, s, a);
-  MT_CHECK_LAUNCH();
-  return MT_OK;
+  if constexpr (BN == 256) {
+    static const bool big_ok = getenv("MT_GEMM_NO256") == nullptr;
+    if (big_ok) {
+      hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), 0, s, a);
+      MT_CHECK_LAUNCH();
+      return MT_OK;
+    }
+    return launch_nt<128, EPI, OutT>(a, s);
+  } else {
+    constexpr int BM = 128;
+    const int nwg = cdiv(a.M, BM) * cdiv(a.N, BN);
+    if (BN == 128)
+      hipLaunchKernelGGL((gemm_nt_kernel<BM, 128, 2, 2, EPI, OutT>), dim3(nwg), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<BM, 64, 4, 1, EPI, OutT>), dim3(nwg), dim3(256), 0, s, a);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+  }
 }
 
 template <int EPI, typename OutT>
 int launch_nt_bn(const GemmNtArgs& a, hipStream_t s) {
   // N = 192 / 384 / 576 (adapter projections) tile exactly with BN = 64; everything else uses 128
   if (a.N % 128 != 0) return launch_nt<64, EPI, OutT>(a, s);
+  if (a.N % 256 == 0 && a.N >= 2304 && a.M >= 8192) return launch_nt<256, EPI, OutT>(a, s);
   return launch_nt<128, EPI, OutT>(a, s);
 }
 

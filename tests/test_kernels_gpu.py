@@ -103,7 +103,21 @@ def test_gemm_nt_rowmaps_resid_inject_posemb(ops):
     assert rel(out2, ref2) < 2e-5
 
 
-@pytest.mark.parametrize("M", [333, 2600])
+@pytest.mark.parametrize("N,K", [(3072, 768), (2304, 768)])
+def test_gemm_nt_256x256_tile(ops, N, K):
+    """M >= 8192 and N >= 2304 take the 8-wave 256 x 256 tile (ragged last row tile)."""
+    g = rng(N)
+    M = 8300
+    A = torch.randn(M, K, generator=g).half()
+    W = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g)
+    out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm_nt(A.to(DEV), W.to(DEV), out, M, N, K, bias=bias.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(out, A.double() @ W.double().t() + bias.double()) < 2e-3
+
+
+@pytest.mark.parametrize("M", [333, 2600, 8300])
 def test_gemm_nt_head_major_qkv_epilogue(ops, M):
     g = rng(19)
     N, K = 2304, 768
