@@ -79,11 +79,13 @@ int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, int M, int N
 /* Generic small strided fp32 GEMM for the token-side ops (T <= 66 rows; gene encoder GE:194-223, prompt
  * self-attention projections AM:81-94, extractor FFN AM:284-287, fusion head LVA:343-347), forward and
  * backward:  C(m,n) = act(sum_k A(m,k) B(n,k) + bias[n]) [+ C(m,n) if accumulate].
- * Element (i,j) of X is X[i*xs0 + j*xs1].  batch: pointer offsets a_bs/b_bs/c_bs per batch index. */
+ * Element (i,j) of X is X[i*xs0 + j*xs1].  batch: pointer offsets a_bs/b_bs/c_bs per batch index.
+ * rowsum (fp32 [M], or NULL; batch must be 1): rowsum[m] += sum_k A(m,k) -- the bias gradient riding on the
+ * dW = dy^T x product of an nn.Linear backward. */
 enum { MT_ACT_NONE = 0, MT_ACT_RELU = 1, MT_ACT_GELU = 2, MT_ACT_ELU = 3 };
 int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B, long bs0, long bs1, long b_bs,
                    const float* bias, int bias_on_m, float* C, long cs0, long cs1, long c_bs, int M, int N, int K,
-                   int batch, int act, int accumulate, mt_stream_t stream);
+                   int batch, int act, int accumulate, float* rowsum, mt_stream_t stream);
 
 /* ------------------------------------------------------------- LayerNorm --------------------------- */
 /* y = LN(f(x)) * w + b over the last dim D (eps 1e-5), one wave per row; stats (mean, rstd) saved per row.

@@ -44,7 +44,7 @@ SIGNATURES = {
     "mt_gemm_nt_f16": [P, L, RM, P, I, I, I, I, EP, P, L, RM, I, P],
     "mt_gemm_tn_f16": [P, L, RM, P, L, RM, I, I, I, P, L, P],
     "mt_colsum_f16": [P, L, RM, I, I, P, P],
-    "mt_sgemm_small": [P, L, L, L, P, L, L, L, P, I, P, L, L, L, I, I, I, I, I, I, P],
+    "mt_sgemm_small": [P, L, L, L, P, L, L, L, P, I, P, L, L, L, I, I, I, I, I, I, P, P],
     "mt_layernorm_fwd": [P, L, RM, I, I, P, P, P, I, P, L, RM, I, P, I, I, P],
     "mt_layernorm_bwd": [P, L, RM, I, P, L, RM, I, I, P, P, P, L, RM, I, I, P, P, P, I, I, P],
     "mt_dilated_attn_fwd": [P, PL, P, P, P],

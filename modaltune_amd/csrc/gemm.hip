@@ -344,6 +344,7 @@ struct SgemmArgs {
   const float* bias; int bias_on_m;
   float* C; long cs0, cs1, c_bs;
   int M, N, K, act, accumulate;
+  float* rowsum;      // optional: rowsum[m] += sum_k A(m,k) (the bias gradient riding on a dW = dy^T x product)
 };
 
 MT_DEVINL float apply_act(float v, int act) {
@@ -376,7 +377,8 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
       rb[j] = (bn < g.N && kk < g.K) ? B[bn * g.bs0 + kk * g.bs1] : 0.f;
     }
   };
-  float acc = 0.f;
+  float acc = 0.f, rs = 0.f;
+  const bool want_rs = g.rowsum != nullptr && blockIdx.x == 0 && tx == 0;    // one column of workgroups, one lane per row
   gload(0);
   for (int k0 = 0; k0 < g.K; k0 += KC) {
 #pragma unroll
@@ -385,8 +387,13 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
     if (k0 + KC < g.K) gload(k0 + KC);
 #pragma unroll
     for (int k = 0; k < KC; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
+    if (want_rs) {
+#pragma unroll
+      for (int k = 0; k < KC; ++k) rs += As[ty][k];
+    }
     __syncthreads();
   }
+  if (want_rs && m0 + ty < g.M) g.rowsum[m0 + ty] += rs;
   const int m = m0 + ty, n = n0 + tx;
   if (m < g.M && n < g.N) {
     if (g.bias) acc += g.bias[g.bias_on_m ? m : n];
@@ -465,9 +472,10 @@ extern "C" int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, i
 
 extern "C" int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B, long bs0, long bs1,
                               long b_bs, const float* bias, int bias_on_m, float* C, long cs0, long cs1, long c_bs,
-                              int M, int N, int K, int batch, int act, int accumulate, mt_stream_t stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return MT_ERR_BAD_ARG;
-  SgemmArgs g{A, as0, as1, a_bs, B, bs0, bs1, b_bs, bias, bias_on_m, C, cs0, cs1, c_bs, M, N, K, act, accumulate};
+                              int M, int N, int K, int batch, int act, int accumulate, float* rowsum,
+                              mt_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || (rowsum && batch != 1)) return MT_ERR_BAD_ARG;
+  SgemmArgs g{A, as0, as1, a_bs, B, bs0, bs1, b_bs, bias, bias_on_m, C, cs0, cs1, c_bs, M, N, K, act, accumulate, rowsum};
   hipLaunchKernelGGL(sgemm_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16), batch), dim3(256), 0, (hipStream_t)stream, g);
   MT_CHECK_LAUNCH();
   return MT_OK;

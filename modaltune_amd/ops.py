@@ -80,11 +80,11 @@ def colsum(A, out, M, N, *, lda=None, amap=None):
 
 
 def sgemm(A, a_str, B, b_str, Cm, c_str, M, N, K, *, bias=None, bias_on_m=False, act=ACT_NONE, accumulate=False,
-          batch=1, a_bs=0, b_bs=0, c_bs=0):
-    """C(m,n) = act(sum_k A(m,k) B(n,k) + bias) with explicit (row, col) element strides."""
+          batch=1, a_bs=0, b_bs=0, c_bs=0, rowsum=None):
+    """C(m,n) = act(sum_k A(m,k) B(n,k) + bias) with explicit (row, col) element strides; rowsum[m] += sum_k A(m,k)."""
     check(_lib.load().mt_sgemm_small(_p(A), a_str[0], a_str[1], a_bs, _p(B), b_str[0], b_str[1], b_bs, _p(bias),
                                      int(bias_on_m), _p(Cm), c_str[0], c_str[1], c_bs, M, N, K, batch, act,
-                                     int(accumulate), _s()), "sgemm_small")
+                                     int(accumulate), _p(rowsum), _s()), "sgemm_small")
 
 
 def layernorm_fwd(x, w, b, y, stats, M, D, *, ldx=None, xmap=None, ldy=None, ymap=None, gelu_in=False, add_rows=None,

@@ -89,9 +89,11 @@ class Tape:
                 dy = dpre
             if x.needs_grad:   # dx += dy @ W
                 ops.sgemm(dy, (N, 1), W.data, (1, K), x.g(), (K, 1), R, K, N, accumulate=True)
-            if W.grad is not None:   # dW += dy^T @ x
-                ops.sgemm(dy, (1, N), x.data, (1, K), W.grad, (K, 1), N, K, R, accumulate=True)
-            if b is not None and b.grad is not None:
+            want_db = b is not None and b.grad is not None
+            if W.grad is not None:   # dW += dy^T @ x ; the bias gradient (row sums of dy^T) rides on the same launch
+                ops.sgemm(dy, (1, N), x.data, (1, K), W.grad, (K, 1), N, K, R, accumulate=True,
+                          rowsum=b.grad if want_db else None)
+            elif want_db:
                 self._colsum(dy, R, N, b.grad)
         self.record(bwd)
         return y

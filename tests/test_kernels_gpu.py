@@ -166,6 +166,17 @@ def test_sgemm_small(ops):
     torch.cuda.synchronize()
     ref = C0.double() + (A2.double().transpose(1, 2) @ Bm.double().t() + bm.double()[:, None]).transpose(1, 2)
     assert rel(Cd, ref) < 1e-5
+    # rowsum rider: dW = dy^T x with db = column sums of dy on the same launch (nn.Linear backward)
+    R, Nout, Kin = 195, 50, 77
+    dy = torch.randn(R, Nout, generator=g)
+    x = torch.randn(R, Kin, generator=g)
+    dW = torch.zeros(Nout, Kin, device=DEV)
+    db0 = torch.randn(Nout, generator=g)
+    db = db0.to(DEV).clone()
+    ops.sgemm(dy.to(DEV), (1, Nout), x.to(DEV), (1, Kin), dW, (Kin, 1), Nout, Kin, R, accumulate=True, rowsum=db)
+    torch.cuda.synchronize()
+    assert rel(dW, dy.double().t() @ x.double()) < 1e-5
+    assert rel(db, db0.double() + dy.double().sum(0)) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
