@@ -119,11 +119,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmNtArgs g) {
       for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const h16x8*>(&As[(wm * TM + i * 16 + fr) * BK + pc]);
 #pragma unroll
       for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const h16x8*>(&Bs[(wn * TN + j * 16 + fr) * BK + pc]);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: see epilogue
+      __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
   }
