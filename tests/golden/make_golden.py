@@ -144,6 +144,42 @@ def unit_gene331(seed=5):
     np.savez_compressed(os.path.join(HERE, "unit_gene331.npz"), seed=seed, y=y.detach().numpy().astype(np.float32))
 
 
+def unit_dataset(seed=7):
+    """Case assembly + subsampling of the reference dataset class (data_utils/datasets.py:213-285) on three tiny
+    synthetic slides; the object is built without its __init__ (which wants the TCGA csv files)."""
+    import tempfile
+    import pandas as pd
+    from data_utils.datasets import FeaturesGeneTextDataset
+    r = np.random.default_rng(seed)
+    tmp = tempfile.mkdtemp()
+    lens, C = [23, 40, 11], 16
+    paths, slides = [], {}
+    for i, n in enumerate(lens):
+        f = torch.from_numpy(r.standard_normal((n, C)).astype(np.float32))
+        c = torch.from_numpy((r.integers(0, 40, size=(n, 2)) * 256).astype(np.int64))
+        pth = os.path.join(tmp, f"s{i}.pt")
+        torch.save({"features": f, "coords": c}, pth)
+        paths.append(pth)
+        slides[f"s{i}_features"], slides[f"s{i}_coords"] = f.numpy(), c.numpy()
+    ds = object.__new__(FeaturesGeneTextDataset)
+    ds.case_wise, ds.return_images, ds.return_case = True, True, True
+    ds.df = pd.DataFrame({"case_id": ["c0"] * 3, "case_submitter_id": ["c0"] * 3, "features_path": paths, "lab": [1, 1, 1]})
+    ds.case_ids = ds.df["case_id"].unique()
+    ds.labelset = "lab"
+    ds.textembeddings = {"c0": torch.zeros(4, 8)}
+    ds.clinicaldata = None
+    ds.gene_df = pd.DataFrame({"case_id": ["c0"], "g0": [0.5], "g1": [-1.0], "g2": [2.0]})
+    ds.gene_group_defination = {0: ["g0", "g2"], 1: ["g1"]}
+    out = {}
+    for thr in (1000, 50):
+        ds.threshold = thr
+        torch.manual_seed(seed)
+        image, coords, text, clinical, gene_data, label, case_id = ds[0]
+        out[f"thr{thr}_image"], out[f"thr{thr}_coords"] = image.numpy(), coords.numpy()
+        out[f"thr{thr}_genes"] = np.concatenate([np.atleast_1d(gene_data[k].numpy()) for k in sorted(gene_data)])
+    np.savez_compressed(os.path.join(HERE, "unit_dataset.npz"), seed=seed, nslides=len(lens), **slides, **out)
+
+
 GRAD_KEYS_FULL = ["interactions.0.injector.gamma", "interactions.1.injector.gamma", "final_project.bias",
                   "interactions.0.injector.attn.q_proj.bias", "task_weight.0.weight",
                   "gene_encoder.pathway_compression.weight", "interactions.2.extractor.ffn.linear1.bias"]
@@ -237,6 +273,8 @@ if __name__ == "__main__":
         unit_gene()
     if "gene331" in which:
         unit_gene331()
+    if "dataset" in which:
+        unit_dataset()
     if "m37" in which:
         model_case("L37_d3", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=11)
     if "m1500" in which:
