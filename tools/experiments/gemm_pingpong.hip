@@ -1,0 +1,648 @@
+// EXPERIMENT (not built): gemm.hip plus gemm_nt_pp_kernel, a 256 x 256 ping-pong schedule (two wave groups alternating MFMA
+// clusters and LDS-read / LDS-DMA intervals between raw s_barriers, counted vmcnt(4) once per K-tile, DMA 1-2 K-tiles ahead
+// in two buffers).  Correct (tests/test_kernels_gpu.py gemm cases).  Measured on MI355X, random operands:
+//   8192 x 4096 x 4096: 1214 TFLOP/s (2-buffer 256^2 kernel 1017, hipBLASLt 1361); 30003 x 3072 x 3072: 1007 (932 / 1299);
+//   30003 x 3072 x 768: 889 (824 / 1062).
+// Not enabled: every N >= 2304 GEMM of this workload has K = 768 (12 K-tiles), and in the full train step the same-box
+// A/B is 52.1 vs 52.0 ms.  It is the starting point for the deep-K shapes (N = 768, K = 3072 / 2304) once a stream-K style
+// split removes the 354-tiles-on-256-CUs tail of 256^2 tiles there.
+// GEMM kernels of the Modal-Adapter hot path (gfx950, fp16 operands, fp32 MFMA accumulation).
+//
+//   gemm_nt : C[M,N] = epi(A[M,K] . W[N,K]^T)      every big-M nn.Linear forward and every dX GEMM
+//   gemm_tn : C[N1,N2] += A[M,N1]^T . B[M,N2]      weight gradients of the trainable big-M linears
+//   colsum  : out[N]  += sum_m A[m,N]              bias gradients
+//   sgemm_small : strided fp32 GEMM for the token-side (T <= 66 rows) ops
+//
+// gemm_nt structure: 128 x BN x 64 tiles, 4 waves, v_mfma_f32_16x16x32_f16, double-buffered LDS filled by LDS-DMA
+// (global_load_lds_dwordx4, issued for tile t+1 before the MFMAs of tile t; one barrier per K-tile), XOR-swizzled
+// 128-B rows so the ds_read_b128 fragment reads are bank-conflict free.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+struct GemmNtArgs {
+  const h16* A; long lda; RowMap amap;
+  const h16* W;
+  int M, N, K;
+  const float* bias;
+  const float* resid; long ldr; RowMap rmap;
+  const float* colscale;
+  const float* pos_table; const int* pos_row; const int* pos_col;
+  void* C; long ldc; RowMap cmap;
+};
+
+// LDS-DMA staging (global_load_lds_dwordx4): each wave-instruction drops 64 x 16 B = 1 KiB = 8 tile rows of 128 B
+// straight into LDS, no staging VGPRs and no ds_write pass.  The DMA destination is lane-linear, so the
+// bank-conflict fix is an XOR swizzle applied on the per-lane SOURCE address and again on the fragment reads
+// (guide rule 21): the 16-B chunk c of tile row r lives at chunk position c ^ (r & 7); with it the 16-lane groups
+// of ds_read_b128 hit 16 distinct 16-B slots.
+constexpr int erows_for(int bm, int cs, int lds_bytes) {
+  int e = bm;
+  while (e * cs * 4 > lds_bytes) e /= 2;
+  return e;
+}
+
+// ---- epilogue (shared by the tile kernels).  The MFMAs were issued with the operands swapped (W fragment as A,
+// activation fragment as B), so each accumulator is a TRANSPOSED 16x16 tile: lane = (m = lane & 15, n = 4 * (lane >> 4)
+// .. + 3), i.e. four consecutive output columns of one row per lane -> one 16-byte LDS write per tile instead of four
+// scalar ones.  The tile is staged through LDS (the operand buffers are free now) so that every global access of the
+// epilogue -- the residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B per row).
+template <int BM, int BN, int WM, int WN, int EPI, typename OutT, int LDS_BYTES>
+MT_DEVINL void gemm_epilogue(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], h16* smem, int m0, int n0) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int CS = BN + 4;
+  constexpr int EROWS = erows_for(BM, CS, LDS_BYTES);
+  static_assert(EROWS * CS * 4 <= LDS_BYTES, "epilogue staging must fit the operand LDS");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  float* Cs = reinterpret_cast<float*>(smem);
+  OutT* C = reinterpret_cast<OutT*>(g.C);
+  constexpr int CPR = BN / 4;                                  // float4 chunks per tile row
+  constexpr int RPP = NT / CPR;                                // rows per pass
+  const int cc = (tid % CPR) * 4, r0 = tid / CPR;
+  const int n = n0 + cc;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gm4 = {0.f, 0.f, 0.f, 0.f};
+  if (n < g.N) {
+    if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+    if (EPI == MT_EPI_INJECT) gm4 = *reinterpret_cast<const f32x4*>(g.colscale + n);
+  }
+#pragma unroll
+  for (int pass = 0; pass < BM / EROWS; ++pass) {
+    const int rbase = pass * EROWS;
+    if (pass > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * TM + i * 16 + fr - rbase;
+      if (row >= 0 && row < EROWS) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) *reinterpret_cast<f32x4*>(&Cs[row * CS + wn * TN + j * 16 + fq * 4]) = acc[i][j];
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = r0; rr < EROWS; rr += RPP) {
+      const int m = m0 + rbase + rr;
+      if (m >= g.M || n >= g.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * CS + cc]);
+      v += bias4;
+      if (EPI == MT_EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+      if (EPI == MT_EPI_INJECT) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (1.0f + gm4[e]) * x[e] + gm4[e] * v[e];
+      }
+      if (EPI == MT_EPI_POSEMB) {
+        const int half = g.N >> 1;   // first half encodes the grid column, second half the row (A.8)
+        const float* tab = (n < half) ? g.pos_table + (long)g.pos_col[m] * half + n : g.pos_table + (long)g.pos_row[m] * half + (n - half);
+        v += *reinterpret_cast<const f32x4*>(tab);
+      }
+      OutT* dst = C + g.cmap.map(m) * g.ldc + n;
+      if (EPI == MT_EPI_QKV_HM)     // [q|k|v][head][M][48]: column n -> slab n / 48, offset n % 48 (4 | 48: chunks never straddle)
+        dst = C + ((long)(n / 48) * g.M + m) * 48 + (n % 48);
+      if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        *reinterpret_cast<h16x4*>(dst) = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+      }
+    }
+  }
+}
+
+// Tile choice: 128 x {128, 64} with 4 waves (two workgroups per CU) everywhere, and 256 x 256 with 8 waves (128 KB of
+// LDS, one workgroup per CU) for the wide outputs.  A K-tile of the 128^2 form moves 32 KB for 1024 MFMA cycles per SIMD,
+// i.e. it wants ~134 GB/s per CU from L2 at full MFMA rate against ~70 GB/s deliverable (MI355X_MICROARCH.md, gather into
+// LDS from L2): that form is L2->LDS bound near 50 %.  256^2 halves the bytes per flop; it needs >= ~4 tiles per CU to
+// amortise its one-workgroup-per-CU tail, so it is used for N >= 2304 only.
+template <int BM, int BN, int WM, int WN, int EPI, typename OutT>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmNtArgs g) {
+  constexpr int NT = WM * WN * 64;              // threads
+  constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
+  constexpr int MI = TM / 16, NI = TN / 16;     // 16x16 MFMA tiles per wave
+  constexpr int ACH = BM * 8 / NT, BCH = BN * 8 / NT;  // 16-B chunks per thread per K-tile
+  constexpr int CS = BN + 4;                    // fp32 epilogue staging stride (floats)
+  constexpr int EROWS = erows_for(BM, CS, 2 * (BM + BN) * BK * 2);   // epilogue rows per pass
+  static_assert(EROWS * CS * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the operand LDS");
+  __shared__ __attribute__((aligned(16))) h16 smem[2 * (BM + BN) * BK];
+  h16* const As0 = smem;
+  h16* const Bs0 = smem + 2 * BM * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  // XCD-aware tile order: consecutive logical tiles share an A row-panel; keep them on one XCD (T1).
+  const int nbn = (g.N + BN - 1) / BN;
+  const int nbm = (g.M + BM - 1) / BM;
+  const int nwg = nbn * nbm;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+
+  // per-thread DMA sources: chunk id c = i * 256 + tid -> tile row c >> 3, physical chunk c & 7, logical chunk
+  // (c & 7) ^ (row & 7); rows past the edge are clamped (their products are never stored)
+  const int srow = tid >> 3, lchunk = (tid & 7) ^ (srow & 7);
+  const h16* aptr[ACH];
+  const h16* bptr[BCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    const int m = min(m0 + i * (NT / 8) + srow, g.M - 1);
+    aptr[i] = g.A + g.amap.map(m) * g.lda + lchunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int n = min(n0 + i * (NT / 8) + srow, g.N - 1);
+    bptr[i] = g.W + (long)n * g.K + lchunk * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < ACH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(As0 + buf * BM * BK + (i * NT + wave * 64) * 8), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BCH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bptr[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(Bs0 + buf * BN * BK + (i * NT + wave * 64) * 8), 16, 0, 0);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = fr & 7;                         // row & 7 of every fragment row this lane reads
+  stage(0, 0);
+  __syncthreads();                               // (hipcc drains the LDS-DMA with vmcnt(0) before the barrier)
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) stage(buf ^ 1, (t + 1) * BK);
+    const h16* As = As0 + buf * BM * BK;
+    const h16* Bs = Bs0 + buf * BN * BK;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      const int pc = ((kk * 4 + fq) ^ sw) * 8;
+      h16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const h16x8*>(&As[(wm * TM + i * 16 + fr) * BK + pc]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const h16x8*>(&Bs[(wn * TN + j * 16 + fr) * BK + pc]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: see epilogue
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue<BM, BN, WM, WN, EPI, OutT, 2 * (BM + BN) * BK * 2>(g, acc, smem, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt, 256 x 256 ping-pong form (8 waves, wave tile 128 x 64, one workgroup per CU, 128 KB LDS).
+//
+// The two waves of a SIMD (wave i of row-group 0, wave i + 4 of row-group 1) alternate roles in lock step: while one
+// runs a CLUSTER of 16 MFMAs (one 64 x 32 quadrant of its output tile x a 64-deep K-tile), the other pulls the next
+// fragments out of LDS and issues LDS-DMA for a later K-tile; a raw s_barrier ends every interval and group 1 runs one
+// interval behind group 0.  Four intervals of each kind per K-tile:
+//   p0: read A(rows 0-63) + B(cols 0-31)   issue DMA A-half 0 of tile kt+1     MFMA quadrant (0,0)
+//   p1: read B(cols 32-63)                 issue DMA A-half 1 of tile kt+1     MFMA quadrant (0,1)
+//   p2: read A(rows 64-127)                issue DMA B-half 0 of tile kt+2     MFMA quadrant (1,1)
+//   p3: -                                  issue DMA B-half 1 of tile kt+2     MFMA quadrant (1,0)
+// LDS holds two K-tiles of four 16-KB half-tiles (A rows 0-127 / 128-255, B cols 0-127 / 128-255).  Fragments are in
+// registers after p0-p2, so a half-tile slot is refilled long before the tile that reuses the buffer is read: the DMA
+// runs 1-2 K-tiles ahead with only two buffers and is awaited ONCE per K-tile with a counted s_waitcnt vmcnt(4) in p3
+// (the two B half-tiles just issued stay in flight).
+//   RAW: a wave's vmcnt in p3 of tile kt retires its pieces of tile kt+1 (A) and earlier; group 1 does the same one
+//        interval later, and group 0 first reads tile kt+1 two barriers after its own wait = one barrier after group 1's.
+//   WAR: every ds_read is retired (lgkmcnt(0)) before the barrier that closes its interval; B slots of buffer d are
+//        last read in p1 of tile kt (group 1: during group 0's MFMA p1) and refilled from p2; A slots last read in p2
+//        and refilled in p0/p1 of the next tile.
+// ------------------------------------------------------------------------------------------------
+template <int N> MT_DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+MT_DEVINL void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs g) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
+  constexpr int HALF = 128 * BK;                 // halves per half-tile (16 KB)
+  constexpr int TILE = 4 * HALF;                 // A0 | A1 | B0 | B1
+  __shared__ __attribute__((aligned(16))) h16 smem[2 * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM, nwg = nbn * nbm;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+
+  // DMA pieces: a half-tile is 128 rows x 8 chunks of 16 B = 1024 chunks, 2 per thread: chunk c = i * 512 + tid ->
+  // row c >> 3, physical chunk c & 7, logical chunk (c & 7) ^ (row & 7)
+  const int srow = tid >> 3, lchunk = (tid & 7) ^ (srow & 7);
+  const h16* asrc[2][2];                         // [half][piece]
+  const h16* bsrc[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = min(m0 + h * 128 + i * 64 + srow, g.M - 1);
+      asrc[h][i] = g.A + g.amap.map(m) * g.lda + lchunk * 8;
+      const int n = min(n0 + h * 128 + i * 64 + srow, g.N - 1);
+      bsrc[h][i] = g.W + (long)n * g.K + lchunk * 8;
+    }
+  auto dma = [&](const h16* const (&src)[2], int slot_halves, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(smem + slot_halves + (i * 512 + wave * 64) * 8), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+  const int a_off = wr * HALF;                                   // this wave's A half-tile inside a K-tile buffer
+  const int b_off = 2 * HALF + (wc >> 1) * HALF + (wc & 1) * 64 * BK;   // its 64 B columns inside the B half-tile
+
+  h16x8 af[4][2], bf[2][2][2];                   // af[row tile][k step]; bf[qn][col tile][k step]
+  auto read_a = [&](const h16* buf, int qm) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        af[i][kk] = *reinterpret_cast<const h16x8*>(&buf[a_off + (qm * 64 + i * 16 + fr) * BK + (((kk * 4 + fq) ^ sw) * 8)]);
+  };
+  auto read_b = [&](const h16* buf, int qn) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        bf[qn][j][kk] = *reinterpret_cast<const h16x8*>(&buf[b_off + (qn * 32 + j * 16 + fr) * BK + (((kk * 4 + fq) ^ sw) * 8)]);
+  };
+  auto cluster = [&](int qm, int qn) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[qm * 4 + i][qn * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[qn][j][kk], af[i][kk], acc[qm * 4 + i][qn * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
+
+  // prologue: tile 0 complete, B halves of tile 1 in flight
+  dma(asrc[0], 0 * HALF, 0); dma(asrc[1], 1 * HALF, 0); dma(bsrc[0], 2 * HALF, 0); dma(bsrc[1], 3 * HALF, 0);
+  if (nk > 1) { dma(bsrc[0], TILE + 2 * HALF, BK); dma(bsrc[1], TILE + 3 * HALF, BK); wait_vmcnt<4>(); }
+  else wait_vmcnt<0>();
+  bar();
+  if (wr == 1) bar();                            // group 1 runs one interval behind
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const h16* buf = smem + (kt & 1) * TILE;
+    const int nb = ((kt + 1) & 1) * TILE;        // buffer of tile kt+1; tile kt+2 reuses this tile's buffer
+    const int cb = (kt & 1) * TILE;
+    const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+    // p0
+    read_b(buf, 0); read_a(buf, 0);
+    if (has1) dma(asrc[0], nb + 0 * HALF, (kt + 1) * BK);
+    wait_lds(); bar();
+    cluster(0, 0); bar();
+    // p1
+    read_b(buf, 1);
+    if (has1) dma(asrc[1], nb + 1 * HALF, (kt + 1) * BK);
+    wait_lds(); bar();
+    cluster(0, 1); bar();
+    // p2
+    read_a(buf, 1);
+    if (has2) dma(bsrc[0], cb + 2 * HALF, (kt + 2) * BK);
+    wait_lds(); bar();
+    cluster(1, 1); bar();
+    // p3: await tile kt+1 (its A halves; its B halves are older), leave tile kt+2's B halves in flight
+    if (has2) { dma(bsrc[1], cb + 3 * HALF, (kt + 2) * BK); wait_vmcnt<4>(); }
+    else wait_vmcnt<0>();
+    bar();
+    cluster(1, 0); bar();
+  }
+  if (wr == 0) bar();                            // group 0 matches group 1's extra barrier
+  __syncthreads();
+  gemm_epilogue<BM, BN, WM, WN, EPI, OutT, 2 * TILE * 2>(g, acc, smem, m0, n0);
+}
+
+template <int BN, int EPI, typename OutT>
+int launch_nt(const GemmNtArgs& a, hipStream_t s) {
+  if constexpr (BN == 256) {
+    static const bool big_ok = getenv("MT_GEMM_NO256") == nullptr;
+    static const bool pp_ok = getenv("MT_GEMM_NOPP") == nullptr;
+    if (big_ok) {
+      if (pp_ok)
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), 0, s, a);
+      else
+        hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), 0, s, a);
+      MT_CHECK_LAUNCH();
+      return MT_OK;
+    }
+    return launch_nt<128, EPI, OutT>(a, s);
+  } else {
+    constexpr int BM = 128;
+    const int nwg = cdiv(a.M, BM) * cdiv(a.N, BN);
+    if (BN == 128)
+      hipLaunchKernelGGL((gemm_nt_kernel<BM, 128, 2, 2, EPI, OutT>), dim3(nwg), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<BM, 64, 4, 1, EPI, OutT>), dim3(nwg), dim3(256), 0, s, a);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+  }
+}
+
+template <int EPI, typename OutT>
+int launch_nt_bn(const GemmNtArgs& a, hipStream_t s) {
+  // N = 192 / 384 / 576 (adapter projections) tile exactly with BN = 64; everything else uses 128
+  if (a.N % 128 != 0) return launch_nt<64, EPI, OutT>(a, s);
+  if (a.N % 256 == 0 && a.N >= 2304 && a.M >= 8192) return launch_nt<256, EPI, OutT>(a, s);
+  return launch_nt<128, EPI, OutT>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn: C[N1,N2] += sum_m A[m,n1] B[m,n2].  64x64 output tile per workgroup, 32 rows of m per step,
+// split over M (grid.z) with fp32 atomics.  Both operands are "k-strided" in memory, so the tiles are staged
+// as they lie ([m][n]) and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transposed read).
+// ------------------------------------------------------------------------------------------------
+constexpr int TN_STRIDE = 72;   // halves per LDS row: 64 + 8 (144 B; 8-byte aligned tr reads, 16-B aligned writes)
+
+MT_DEVINL h16x4 lds_tr4(const h16* p) {
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)p);
+  return __builtin_bit_cast(h16x4, r);
+}
+
+struct GemmTnArgs {
+  const h16* A; long lda; RowMap amap;
+  const h16* B; long ldb; RowMap bmap;
+  int M, N1, N2, rows_per_split;
+  float* C; long ldc;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
+  __shared__ __attribute__((aligned(16))) h16 As[2][32 * TN_STRIDE];
+  __shared__ __attribute__((aligned(16))) h16 Bs[2][32 * TN_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;      // wave tile 32(n1) x 32(n2)
+  const int n1_0 = blockIdx.x * 64, n2_0 = blockIdx.y * 64;
+  const int mbeg = blockIdx.z * g.rows_per_split;
+  const int mend = min(g.M, mbeg + g.rows_per_split);
+  if (mbeg >= mend) return;
+  // staging: tile 32 rows x 64 cols = 256 chunks of 16 B: one chunk per thread per operand
+  const int srow = tid >> 3, skc = tid & 7;
+  h16x8 ra, rb;
+  const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto gload = [&](int mt) {      // branch-free: clamp the row, select zero past the end of the split
+    const int m = mt + srow, mc = min(m, mend - 1);
+    const h16x8 a = ldg8(g.A + g.amap.map(mc) * g.lda + n1_0 + skc * 8);
+    const h16x8 b = ldg8(g.B + g.bmap.map(mc) * g.ldb + n2_0 + skc * 8);
+    ra = m < mend ? a : zero; rb = m < mend ? b : zero;
+  };
+  auto lstore = [&](int buf) {
+    *reinterpret_cast<h16x8*>(&As[buf][srow * TN_STRIDE + skc * 8]) = ra;
+    *reinterpret_cast<h16x8*>(&Bs[buf][srow * TN_STRIDE + skc * 8]) = rb;
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (mend - mbeg + 31) / 32;
+  gload(mbeg);
+  lstore(0);
+  __syncthreads();
+  // transposed-read addressing (T10): 16-lane group grp covers k rows 8*grp + {0..3} (+4 for the second read);
+  // lane 4q+p of the group supplies the address of row q, columns 4p..4p+3 of the 16-column block.
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) gload(mbeg + (t + 1) * 32);
+    h16x8 af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const h16* pa = &As[buf][(8 * grp + tq) * TN_STRIDE + wm * 32 + i * 16 + 4 * tp];
+      h16x4 lo = lds_tr4(pa), hi = lds_tr4(pa + 4 * TN_STRIDE);
+      af[i] = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const h16* pb = &Bs[buf][(8 * grp + tq) * TN_STRIDE + wn * 32 + i * 16 + 4 * tp];
+      lo = lds_tr4(pb); hi = lds_tr4(pb + 4 * TN_STRIDE);
+      bf[i] = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    if (t + 1 < nt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n1 = n1_0 + wm * 32 + i * 16 + fq * 4 + r;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n2 = n2_0 + wn * 32 + j * 16 + fr;
+        atomicAdd(&g.C[(long)n1 * g.ldc + n2], acc[i][j][r]);
+      }
+    }
+}
+
+// block = 32 column groups of 8 (16-byte loads) x 8 row lanes over a slab of rows; one atomic per column per block
+__global__ __launch_bounds__(256) void colsum_kernel(const h16* A, long lda, RowMap amap, int M, int N,
+                                                     int rows_per_block, float* out) {
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + cg * 8;
+  const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (col < N)
+    for (int m = mbeg + rl; m < mend; m += 8) {
+      const h16x8 v = ldg8(A + amap.map(m) * lda + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+  __shared__ float red[8][256 + 8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = s[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
+    atomicAdd(&out[blockIdx.x * 256 + c], t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small strided fp32 GEMM (token side).  16x16 outputs per workgroup, K walked in 16-wide LDS tiles.
+// ------------------------------------------------------------------------------------------------
+struct SgemmArgs {
+  const float* A; long as0, as1, a_bs;
+  const float* B; long bs0, bs1, b_bs;
+  const float* bias; int bias_on_m;
+  float* C; long cs0, cs1, c_bs;
+  int M, N, K, act, accumulate;
+  float* rowsum;      // optional: rowsum[m] += sum_k A(m,k) (the bias gradient riding on a dW = dy^T x product)
+};
+
+MT_DEVINL float apply_act(float v, int act) {
+  switch (act) {
+    case MT_ACT_RELU: return fmaxf(v, 0.f);
+    case MT_ACT_GELU: return gelu_erf(v);
+    case MT_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+
+__global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
+  constexpr int KC = 64;                       // K chunk per barrier pair
+  __shared__ float As[16][KC + 1], Bs[16][KC + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, bz = blockIdx.z;
+  const float* A = g.A + (long)bz * g.a_bs;
+  const float* B = g.B + (long)bz * g.b_bs;
+  float* C = g.C + (long)bz * g.c_bs;
+  // staging: thread -> (row = tid / 16, k = tid % 16 + 16 j), j = 0..3; the next chunk is prefetched into registers
+  // while the current one is consumed (these GEMMs are latency-bound: one global round trip per chunk otherwise)
+  const int sr = threadIdx.x >> 4, sk = threadIdx.x & 15;
+  const int am = m0 + sr, bn = n0 + sr;
+  float ra[KC / 16], rb[KC / 16];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < KC / 16; ++j) {
+      const int kk = k0 + sk + 16 * j;
+      ra[j] = (am < g.M && kk < g.K) ? A[am * g.as0 + kk * g.as1] : 0.f;
+      rb[j] = (bn < g.N && kk < g.K) ? B[bn * g.bs0 + kk * g.bs1] : 0.f;
+    }
+  };
+  float acc = 0.f, rs = 0.f;
+  const bool want_rs = g.rowsum != nullptr && blockIdx.x == 0 && tx == 0;    // one column of workgroups, one lane per row
+  gload(0);
+  for (int k0 = 0; k0 < g.K; k0 += KC) {
+#pragma unroll
+    for (int j = 0; j < KC / 16; ++j) { As[sr][sk + 16 * j] = ra[j]; Bs[sr][sk + 16 * j] = rb[j]; }
+    __syncthreads();
+    if (k0 + KC < g.K) gload(k0 + KC);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
+    if (want_rs) {
+#pragma unroll
+      for (int k = 0; k < KC; ++k) rs += As[ty][k];
+    }
+    __syncthreads();
+  }
+  if (want_rs && m0 + ty < g.M) g.rowsum[m0 + ty] += rs;
+  const int m = m0 + ty, n = n0 + tx;
+  if (m < g.M && n < g.N) {
+    if (g.bias) acc += g.bias[g.bias_on_m ? m : n];
+    acc = apply_act(acc, g.act);
+    float* c = &C[m * g.cs0 + n * g.cs1];
+    *c = g.accumulate ? *c + acc : acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* W, int M, int N, int K,
+                              int epilogue, const MtGemmEpilogue* epi, void* C, long ldc, const MtRowMap* cmap,
+                              int out_dtype, mt_stream_t stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return MT_ERR_BAD_ARG;
+  if (K % BK != 0 || lda % 8 != 0 || (N % 64) != 0 || (ldc % 4) != 0) return MT_ERR_BAD_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7)) return MT_ERR_BAD_ARG;
+  if (epi && epi->resid && (((uintptr_t)epi->resid & 15) || (epi->ldr % 4))) return MT_ERR_BAD_ARG;
+  GemmNtArgs a;
+  a.A = (const h16*)A; a.lda = lda; a.amap = make_rowmap(amap);
+  a.W = (const h16*)W; a.M = M; a.N = N; a.K = K;
+  a.bias = epi ? epi->bias : nullptr;
+  a.resid = epi ? epi->resid : nullptr; a.ldr = epi ? epi->ldr : 0;
+  a.rmap = make_rowmap(epi ? &epi->rmap : nullptr);
+  a.colscale = epi ? epi->colscale : nullptr;
+  a.pos_table = epi ? epi->pos_table : nullptr;
+  a.pos_row = epi ? epi->pos_row : nullptr; a.pos_col = epi ? epi->pos_col : nullptr;
+  a.C = C; a.ldc = ldc; a.cmap = make_rowmap(cmap);
+  hipStream_t s = (hipStream_t)stream;
+  const bool f32 = out_dtype == MT_OUT_F32;
+  switch (epilogue) {
+    case MT_EPI_BIAS:
+      return f32 ? launch_nt_bn<MT_EPI_BIAS, float>(a, s) : launch_nt_bn<MT_EPI_BIAS, h16>(a, s);
+    case MT_EPI_BIAS_RESID:
+      if (!a.resid) return MT_ERR_BAD_ARG;
+      return f32 ? launch_nt_bn<MT_EPI_BIAS_RESID, float>(a, s) : launch_nt_bn<MT_EPI_BIAS_RESID, h16>(a, s);
+    case MT_EPI_INJECT:
+      if (!a.resid || !a.colscale || !f32) return MT_ERR_BAD_ARG;
+      return launch_nt_bn<MT_EPI_INJECT, float>(a, s);
+    case MT_EPI_POSEMB:
+      if (!a.pos_table || !a.pos_row || !a.pos_col || !f32) return MT_ERR_BAD_ARG;
+      return launch_nt_bn<MT_EPI_POSEMB, float>(a, s);
+    case MT_EPI_QKV_HM:
+      if (f32 || (N % 48) != 0 || cmap) return MT_ERR_BAD_ARG;
+      return launch_nt_bn<MT_EPI_QKV_HM, h16>(a, s);
+    default:
+      return MT_ERR_BAD_ARG;
+  }
+}
+
+extern "C" int mt_gemm_tn_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* B, long ldb,
+                              const MtRowMap* bmap, int M, int N1, int N2, float* C, long ldc, mt_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N1 % 64 || N2 % 64 || lda % 8 || ldb % 8) return MT_ERR_BAD_ARG;
+  GemmTnArgs g;
+  g.A = (const h16*)A; g.lda = lda; g.amap = make_rowmap(amap);
+  g.B = (const h16*)B; g.ldb = ldb; g.bmap = make_rowmap(bmap);
+  g.M = M; g.N1 = N1; g.N2 = N2; g.C = C; g.ldc = ldc;
+  const int tiles = (N1 / 64) * (N2 / 64);
+  int split = max(1, min(cdiv(M, 256), cdiv(2048, tiles)));   // ~2k workgroups, >= 256 rows each
+  g.rows_per_split = cdiv(cdiv(M, split), 32) * 32;
+  split = cdiv(M, g.rows_per_split);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(N1 / 64, N2 / 64, split), dim3(256), 0, (hipStream_t)stream, g);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, int M, int N, float* out,
+                             mt_stream_t stream) {
+  if (!A || !out || M <= 0 || N <= 0 || (N & 7) || (lda & 7)) return MT_ERR_BAD_ARG;
+  const int rows_per_block = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream,
+                     (const h16*)A, lda, make_rowmap(amap), M, N, rows_per_block, out);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B, long bs0, long bs1,
+                              long b_bs, const float* bias, int bias_on_m, float* C, long cs0, long cs1, long c_bs,
+                              int M, int N, int K, int batch, int act, int accumulate, float* rowsum,
+                              mt_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || (rowsum && batch != 1)) return MT_ERR_BAD_ARG;
+  SgemmArgs g{A, as0, as1, a_bs, B, bs0, bs1, b_bs, bias, bias_on_m, C, cs0, cs1, c_bs, M, N, K, act, accumulate, rowsum};
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16), batch), dim3(256), 0, (hipStream_t)stream, g);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
