@@ -20,6 +20,7 @@ struct GemmNtArgs {
   const h16* A; long lda; RowMap amap;
   const h16* W;
   int M, N, K;
+  int m_begin, m_end;     // row range of this launch (tile rows start at m_begin; rows >= m_end are not stored)
   const float* bias;
   const float* resid; long ldr; RowMap rmap;
   const float* colscale;
@@ -38,11 +39,78 @@ constexpr int erows_for(int bm, int cs, int lds_bytes) {
   return e;
 }
 
-// Tile choice: 128 x {128, 64} with 4 waves (two workgroups per CU) everywhere, and 256 x 256 with 8 waves (128 KB of
-// LDS, one workgroup per CU) for the wide outputs.  A K-tile of the 128^2 form moves 32 KB for 1024 MFMA cycles per SIMD,
-// i.e. it wants ~134 GB/s per CU from L2 at full MFMA rate against ~70 GB/s deliverable (MI355X_MICROARCH.md, gather into
-// LDS from L2): that form is L2->LDS bound near 50 %.  256^2 halves the bytes per flop; it needs >= ~4 tiles per CU to
-// amortise its one-workgroup-per-CU tail, so it is used for N >= 2304 only.
+// ---- epilogue (shared by the tile kernels).  The MFMAs were issued with the operands swapped (W fragment as A,
+// activation fragment as B), so each accumulator is a TRANSPOSED 16x16 tile: lane = (m = lane & 15, n = 4 * (lane >> 4)
+// .. + 3), i.e. four consecutive output columns of one row per lane -> one 16-byte LDS write per tile instead of four
+// scalar ones.  The tile is staged through LDS (the operand buffers are free now) so that every global access of the
+// epilogue -- the residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B per row).
+template <int BM, int BN, int WM, int WN, int EPI, typename OutT, int LDS_BYTES>
+MT_DEVINL void gemm_epilogue(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], h16* smem, int m0, int n0) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int CS = BN + 4;
+  constexpr int EROWS = erows_for(BM, CS, LDS_BYTES);
+  static_assert(EROWS * CS * 4 <= LDS_BYTES, "epilogue staging must fit the operand LDS");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  float* Cs = reinterpret_cast<float*>(smem);
+  OutT* C = reinterpret_cast<OutT*>(g.C);
+  constexpr int CPR = BN / 4;                                  // float4 chunks per tile row
+  constexpr int RPP = NT / CPR;                                // rows per pass
+  const int cc = (tid % CPR) * 4, r0 = tid / CPR;
+  const int n = n0 + cc;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gm4 = {0.f, 0.f, 0.f, 0.f};
+  if (n < g.N) {
+    if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+    if (EPI == MT_EPI_INJECT) gm4 = *reinterpret_cast<const f32x4*>(g.colscale + n);
+  }
+#pragma unroll
+  for (int pass = 0; pass < BM / EROWS; ++pass) {
+    const int rbase = pass * EROWS;
+    if (pass > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * TM + i * 16 + fr - rbase;
+      if (row >= 0 && row < EROWS) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) *reinterpret_cast<f32x4*>(&Cs[row * CS + wn * TN + j * 16 + fq * 4]) = acc[i][j];
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = r0; rr < EROWS; rr += RPP) {
+      const int m = m0 + rbase + rr;
+      if (m >= g.m_end || n >= g.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * CS + cc]);
+      v += bias4;
+      if (EPI == MT_EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+      if (EPI == MT_EPI_INJECT) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (1.0f + gm4[e]) * x[e] + gm4[e] * v[e];
+      }
+      if (EPI == MT_EPI_POSEMB) {
+        const int half = g.N >> 1;   // first half encodes the grid column, second half the row (A.8)
+        const float* tab = (n < half) ? g.pos_table + (long)g.pos_col[m] * half + n : g.pos_table + (long)g.pos_row[m] * half + (n - half);
+        v += *reinterpret_cast<const f32x4*>(tab);
+      }
+      OutT* dst = C + g.cmap.map(m) * g.ldc + n;
+      if (EPI == MT_EPI_QKV_HM)     // [q|k|v][head][M][48]: column n -> slab n / 48, offset n % 48 (4 | 48: chunks never straddle)
+        dst = C + ((long)(n / 48) * g.M + m) * 48 + (n % 48);
+      if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        *reinterpret_cast<h16x4*>(dst) = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+      }
+    }
+  }
+}
+
+// Tile choice: 128 x {128, 64} with 4 waves (two workgroups per CU) for the narrow / shallow shapes, and the 256 x 256
+// ping-pong kernel below (8 waves, 128 KB of LDS, one workgroup per CU) for N >= 2304 or K >= 2304.  A K-tile of the 128^2
+// form moves 32 KB for 1024 MFMA cycles per SIMD, i.e. it wants ~134 GB/s per CU from L2 at full MFMA rate against
+// ~70 GB/s deliverable (MI355X_MICROARCH.md, gather into LDS from L2), and it ends every K-tile on a vmcnt(0) + barrier.
 template <int BM, int BN, int WM, int WN, int EPI, typename OutT>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmNtArgs g) {
   constexpr int NT = WM * WN * 64;              // threads
@@ -60,14 +128,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmNtArgs g) {
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: consecutive logical tiles share an A row-panel; keep them on one XCD (T1).
   const int nbn = (g.N + BN - 1) / BN;
-  const int nbm = (g.M + BM - 1) / BM;
+  const int nbm = (g.m_end - g.m_begin + BM - 1) / BM;
   const int nwg = nbn * nbm;
   int bid = blockIdx.x;
   {
     const int q = nwg / 8, r = nwg % 8, x = bid % 8;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
   }
-  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+  const int m0 = g.m_begin + (bid / nbn) * BM, n0 = (bid % nbn) * BN;
 
   // per-thread DMA sources: chunk id c = i * 256 + tid -> tile row c >> 3, physical chunk c & 7, logical chunk
   // (c & 7) ^ (row & 7); rows past the edge are clamped (their products are never stored)
@@ -130,74 +198,192 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmNtArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue.  The MFMAs were issued with the operands swapped (W fragment as A, activation fragment as B), so
-  // each accumulator is a TRANSPOSED 16x16 tile: lane = (m = lane & 15, n = 4 * (lane >> 4) .. + 3), i.e. four
-  // consecutive output columns of one row per lane -> one 16-byte LDS write per tile instead of four scalar ones.
-  // The tile is staged through LDS (the operand buffers are free now) so that every global access of the epilogue --
-  // the residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B contiguous per row).
-  float* Cs = reinterpret_cast<float*>(smem);
-  OutT* C = reinterpret_cast<OutT*>(g.C);
-  constexpr int CPR = BN / 4;                                  // float4 chunks per tile row
-  constexpr int RPP = NT / CPR;                                // rows per pass
-  const int cc = (tid % CPR) * 4, r0 = tid / CPR;
-  const int n = n0 + cc;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gm4 = {0.f, 0.f, 0.f, 0.f};
-  if (n < g.N) {
-    if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
-    if (EPI == MT_EPI_INJECT) gm4 = *reinterpret_cast<const f32x4*>(g.colscale + n);
+  gemm_epilogue<BM, BN, WM, WN, EPI, OutT, 2 * (BM + BN) * BK * 2>(g, acc, smem, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt, 256 x 256 ping-pong form (8 waves, wave tile 128 x 64, one workgroup per CU, 128 KB LDS).
+//
+// The two waves of a SIMD (wave i of row-group 0, wave i + 4 of row-group 1) alternate roles in lock step: while one
+// runs a CLUSTER of 16 MFMAs (one 64 x 32 quadrant of its output tile x a 64-deep K-tile), the other pulls the next
+// fragments out of LDS and issues LDS-DMA for a later K-tile; a raw s_barrier ends every interval and group 1 runs one
+// interval behind group 0.  Four intervals of each kind per K-tile:
+//   p0: read A(rows 0-63) + B(cols 0-31)   issue DMA A-half 0 of tile kt+1     MFMA quadrant (0,0)
+//   p1: read B(cols 32-63)                 issue DMA A-half 1 of tile kt+1     MFMA quadrant (0,1)
+//   p2: read A(rows 64-127)                issue DMA B-half 0 of tile kt+2     MFMA quadrant (1,1)
+//   p3: -                                  issue DMA B-half 1 of tile kt+2     MFMA quadrant (1,0)
+// LDS holds two K-tiles of four 16-KB half-tiles (A rows 0-127 / 128-255, B cols 0-127 / 128-255).  Fragments are in
+// registers after p0-p2, so a half-tile slot is refilled long before the tile that reuses the buffer is read: the DMA
+// runs 1-2 K-tiles ahead with only two buffers and is awaited ONCE per K-tile with a counted s_waitcnt vmcnt(4) in p3
+// (the two B half-tiles just issued stay in flight).
+//   RAW: a wave's vmcnt in p3 of tile kt retires its pieces of tile kt+1 (A) and earlier; group 1 does the same one
+//        interval later, and group 0 first reads tile kt+1 two barriers after its own wait = one barrier after group 1's.
+//   WAR: every ds_read is retired (lgkmcnt(0)) before the barrier that closes its interval; B slots of buffer d are
+//        last read in p1 of tile kt (group 1: during group 0's MFMA p1) and refilled from p2; A slots last read in p2
+//        and refilled in p0/p1 of the next tile.
+// ------------------------------------------------------------------------------------------------
+template <int N> MT_DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+MT_DEVINL void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// RH = rows per A half-tile = rows per wave group: 128 (256 x 256 tile) or 64 (128 x 256 tile for the last partial round)
+template <int RH, int EPI, typename OutT>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs g) {
+  constexpr int BM = 2 * RH, BN = 256, WM = 2, WN = 4;
+  constexpr int AH = RH * BK, HALF = 128 * BK;   // halves per A / B half-tile
+  constexpr int TILE = 2 * AH + 2 * HALF;        // A0 | A1 | B0 | B1
+  constexpr int AP = RH / 64;                    // DMA pieces per thread per A half-tile (B: 2)
+  constexpr int RT = RH / 32;                    // 16-row fragment tiles per A quadrant
+  __shared__ __attribute__((aligned(16))) h16 smem[2 * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nbn = (g.N + BN - 1) / BN, nbm = (g.m_end - g.m_begin + BM - 1) / BM, nwg = nbn * nbm;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
   }
+  const int m0 = g.m_begin + (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+
+  // DMA pieces: 64 rows x 8 chunks of 16 B per piece (one per thread): row = tid >> 3, physical chunk tid & 7, logical
+  // chunk (tid & 7) ^ (row & 7); an A half-tile is AP pieces, a B half-tile 2
+  const int srow = tid >> 3, lchunk = (tid & 7) ^ (srow & 7);
+  const h16* asrc[2][AP];                        // [half][piece]
+  const h16* bsrc[2][2];
 #pragma unroll
-  for (int pass = 0; pass < BM / EROWS; ++pass) {
-    const int rbase = pass * EROWS;
-    if (pass > 0) __syncthreads();
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int row = wm * TM + i * 16 + fr - rbase;
-      if (row >= 0 && row < EROWS) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) *reinterpret_cast<f32x4*>(&Cs[row * CS + wn * TN + j * 16 + fq * 4]) = acc[i][j];
-      }
+    for (int i = 0; i < AP; ++i) {
+      const int m = min(m0 + h * RH + i * 64 + srow, g.M - 1);
+      asrc[h][i] = g.A + g.amap.map(m) * g.lda + lchunk * 8;
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int rr = r0; rr < EROWS; rr += RPP) {
-      const int m = m0 + rbase + rr;
-      if (m >= g.M || n >= g.N) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * CS + cc]);
-      v += bias4;
-      if (EPI == MT_EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
-      if (EPI == MT_EPI_INJECT) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (1.0f + gm4[e]) * x[e] + gm4[e] * v[e];
-      }
-      if (EPI == MT_EPI_POSEMB) {
-        const int half = g.N >> 1;   // first half encodes the grid column, second half the row (A.8)
-        const float* tab = (n < half) ? g.pos_table + (long)g.pos_col[m] * half + n : g.pos_table + (long)g.pos_row[m] * half + (n - half);
-        v += *reinterpret_cast<const f32x4*>(tab);
-      }
-      OutT* dst = C + g.cmap.map(m) * g.ldc + n;
-      if (EPI == MT_EPI_QKV_HM)     // [q|k|v][head][M][48]: column n -> slab n / 48, offset n % 48 (4 | 48: chunks never straddle)
-        dst = C + ((long)(n / 48) * g.M + m) * 48 + (n % 48);
-      if constexpr (sizeof(OutT) == 4) {
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-        *reinterpret_cast<h16x4*>(dst) = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int n = min(n0 + h * 128 + i * 64 + srow, g.N - 1);
+      bsrc[h][i] = g.W + (long)n * g.K + lchunk * 8;
     }
   }
+  auto dma_a = [&](int h, int slot_halves, int k0) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[h][i] + k0),
+                                       (__attribute__((address_space(3))) void*)(smem + slot_halves + (i * 512 + wave * 64) * 8), 16, 0, 0);
+  };
+  auto dma_b = [&](int h, int slot_halves, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[h][i] + k0),
+                                       (__attribute__((address_space(3))) void*)(smem + slot_halves + (i * 512 + wave * 64) * 8), 16, 0, 0);
+  };
+
+  f32x4 acc[2 * RT][4];
+#pragma unroll
+  for (int i = 0; i < 2 * RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+  const int a_off = wr * AH;                                     // this wave's A half-tile inside a K-tile buffer
+  const int b_off = 2 * AH + (wc >> 1) * HALF + (wc & 1) * 64 * BK;     // its 64 B columns inside the B half-tile
+
+  h16x8 af[RT][2], bf[2][2][2];                  // af[row tile][k step]; bf[qn][col tile][k step]
+  auto read_a = [&](const h16* buf, int qm) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        af[i][kk] = *reinterpret_cast<const h16x8*>(&buf[a_off + (qm * (RH / 2) + i * 16 + fr) * BK + (((kk * 4 + fq) ^ sw) * 8)]);
+  };
+  auto read_b = [&](const h16* buf, int qn) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        bf[qn][j][kk] = *reinterpret_cast<const h16x8*>(&buf[b_off + (qn * 32 + j * 16 + fr) * BK + (((kk * 4 + fq) ^ sw) * 8)]);
+  };
+  auto cluster = [&](int qm, int qn) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[qm * RT + i][qn * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[qn][j][kk], af[i][kk], acc[qm * RT + i][qn * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
+
+  // prologue: tile 0 complete, B halves of tile 1 in flight
+  constexpr int B0 = 2 * AH, B1 = 2 * AH + HALF;                 // slots inside a K-tile buffer
+  dma_a(0, 0, 0); dma_a(1, AH, 0); dma_b(0, B0, 0); dma_b(1, B1, 0);
+  if (nk > 1) { dma_b(0, TILE + B0, BK); dma_b(1, TILE + B1, BK); wait_vmcnt<4>(); }
+  else wait_vmcnt<0>();
+  bar();
+  if (wr == 1) bar();                            // group 1 runs one interval behind
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const h16* buf = smem + (kt & 1) * TILE;
+    const int nb = ((kt + 1) & 1) * TILE;        // buffer of tile kt+1; tile kt+2 reuses this tile's buffer
+    const int cb = (kt & 1) * TILE;
+    const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+    // p0
+    read_b(buf, 0); read_a(buf, 0);
+    if (has1) dma_a(0, nb, (kt + 1) * BK);
+    wait_lds(); bar();
+    cluster(0, 0); bar();
+    // p1
+    read_b(buf, 1);
+    if (has1) dma_a(1, nb + AH, (kt + 1) * BK);
+    wait_lds(); bar();
+    cluster(0, 1); bar();
+    // p2
+    read_a(buf, 1);
+    if (has2) dma_b(0, cb + B0, (kt + 2) * BK);
+    wait_lds(); bar();
+    cluster(1, 1); bar();
+    // p3: await tile kt+1 (its A halves; its B halves are older), leave tile kt+2's B halves in flight
+    if (has2) { dma_b(1, cb + B1, (kt + 2) * BK); wait_vmcnt<4>(); }
+    else wait_vmcnt<0>();
+    bar();
+    cluster(1, 0); bar();
+  }
+  if (wr == 0) bar();                            // group 0 matches group 1's extra barrier
+  __syncthreads();
+  gemm_epilogue<BM, BN, WM, WN, EPI, OutT, 2 * TILE * 2>(g, acc, smem, m0, n0);
 }
 
 template <int BN, int EPI, typename OutT>
 int launch_nt(const GemmNtArgs& a, hipStream_t s) {
   if constexpr (BN == 256) {
-    static const bool big_ok = getenv("MT_GEMM_NO256") == nullptr;
-    if (big_ok) {
-      hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, EPI, OutT>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), 0, s, a);
-      MT_CHECK_LAUNCH();
-      return MT_OK;
+    // Ping-pong 256 x 256 tiles, one workgroup per CU.  When the tile count leaves a short last round, the rows of that
+    // round are covered by 128 x 256 tiles instead (half the time per tile): e.g. N = 768, M = 30003 is 354 tiles on
+    // 256 CUs = 2 rounds; 255 big + 195 small tiles finish in 1.5.
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        ncu = 256;
     }
-    return launch_nt<128, EPI, OutT>(a, s);
+    const int nbn = cdiv(a.N, 256), nrt = cdiv(a.M, 256);
+    int big_rt = nrt;                                     // row tiles covered by 256-row tiles
+    if (nrt * nbn > ncu) {
+      const int full = (nrt * nbn) / ncu;                 // whole rounds of big tiles
+      const int rt = (full * ncu) / nbn;
+      const int rest_rows = a.M - rt * 256;
+      if (rest_rows > 0 && cdiv(rest_rows, 128) * nbn <= ncu) big_rt = rt;
+    }
+    GemmNtArgs g1 = a;
+    g1.m_begin = 0; g1.m_end = min(a.M, big_rt * 256);
+    if (big_rt > 0) hipLaunchKernelGGL((gemm_nt_pp_kernel<128, EPI, OutT>), dim3(big_rt * nbn), dim3(512), 0, s, g1);
+    if (g1.m_end < a.M) {
+      GemmNtArgs g2 = a;
+      g2.m_begin = g1.m_end; g2.m_end = a.M;
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<64, EPI, OutT>), dim3(cdiv(a.M - g1.m_end, 128) * nbn), dim3(512), 0, s, g2);
+    }
+    MT_CHECK_LAUNCH();
+    return MT_OK;
   } else {
     constexpr int BM = 128;
     const int nwg = cdiv(a.M, BM) * cdiv(a.N, BN);
@@ -214,7 +400,8 @@ template <int EPI, typename OutT>
 int launch_nt_bn(const GemmNtArgs& a, hipStream_t s) {
   // N = 192 / 384 / 576 (adapter projections) tile exactly with BN = 64; everything else uses 128
   if (a.N % 128 != 0) return launch_nt<64, EPI, OutT>(a, s);
-  if (a.N % 256 == 0 && a.N >= 2304 && a.M >= 8192) return launch_nt<256, EPI, OutT>(a, s);
+  static const bool pp_ok = getenv("MT_GEMM_NOPP") == nullptr;
+  if (pp_ok && a.N % 256 == 0 && a.M >= 8192 && (a.N >= 2304 || a.K >= 2304)) return launch_nt<256, EPI, OutT>(a, s);
   return launch_nt<128, EPI, OutT>(a, s);
 }
 
@@ -417,6 +604,7 @@ extern "C" int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, 
   GemmNtArgs a;
   a.A = (const h16*)A; a.lda = lda; a.amap = make_rowmap(amap);
   a.W = (const h16*)W; a.M = M; a.N = N; a.K = K;
+  a.m_begin = 0; a.m_end = M;
   a.bias = epi ? epi->bias : nullptr;
   a.resid = epi ? epi->resid : nullptr; a.ldr = epi ? epi->ldr : 0;
   a.rmap = make_rowmap(epi ? &epi->rmap : nullptr);
