@@ -1,0 +1,1031 @@
+// EXPERIMENT (not built): attn.hip plus dilated_attn_bwd_kv8_kernel, the dK/dV pass as a barrier-synchronised ping-pong (8 waves,
+// the two waves of a SIMD alternating a 14-MFMA matrix phase with an exp / convert / LDS-read phase).  Correct.  Measured on
+// MI355X at L = 10000: 1.14 ms per launch against 0.92 ms for the free-running 4-wave kernel (a 4-interval variant: 1.00 ms).
+// The vector phase (LDS latency -> exp -> convert chains, 256 VGPRs with a small spill) is far longer than the matrix phase,
+// so the lock step costs more than the collisions it removes.
+// Dilated attention (LongNet) for the frozen Prov-GigaPath backbone: 16 heads x 48, five branches.
+//
+// Reference semantics (torchscale/component/dilated_attention.py:22-59,82-144,212-255):
+//   branch (s, r): the sequence is cut in segments of s tokens; head h (group g = h / (16/r)) attends, inside
+//   each segment, over the positions g, g+r, g+2r, ... (n = ceil(s/r) entries).  Entries past the segment end
+//   or past N are ALL-ZERO rows that still act as keys (logit 0, value 0).  Branch outputs are mixed with
+//   softmax-over-branches of the per-(position, head) LSE, treated as constants in backward.
+//
+// Forward kernel: one workgroup = 128 queries (4 waves x 32) of one (pass, branch, segment, head); K/V tiles of
+// 64 keys are gathered in place from the fused qkv activation (no diag_embed / pad copies) into LDS.
+// Per wave, "swapped" products keep the softmax lane-local (query = lane, keys = registers):
+//   S^T[key, q] = K . Q^T           v_mfma_f32_32x32x16_f16, K rows from LDS (ds_read_b128), Q^T in registers
+//   O^T[d, q]  += V^T[d, key] . P^T  P^T taken straight from the S accumulators (no LDS round trip),
+//                                    V^T via ds_read_b64_tr_b16; V carries a ones column so O^T row 48 = sum(P)
+#include "attn_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// forward.  K and V tiles are double-buffered in LDS, one barrier per tile; the global loads of tile t+1 are issued
+// at the top of tile t and first touched at its end.  (A variant software-pipelined across tiles inside each wave --
+// S^T of tile t+1 in flight during the softmax of tile t -- measured 5 % slower: it needs 185 VGPRs = 2 waves/SIMD
+// against 142 = 3 waves/SIMD here, and these kernels are latency-bound, not pipe-bound.)
+// ------------------------------------------------------------------------------------------------
+#ifdef MT_DIAG
+#define DIAG_V(v) (VARIANT == (v))
+template <int VARIANT>
+#else
+#define DIAG_V(v) false
+#endif
+__global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __restrict__ qkv, Plan p, h16* __restrict__ o_br,
+                                                               float* __restrict__ lse_br) {
+  __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];
+  __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * VSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const WorkItem w = decode(p, blockIdx.x);
+  const Seq sq = make_seq(p, w);
+  const long M = (long)p.B * p.N;
+  const float c = 0.14433756729740643f * LOG2E;   // 48^-1/2 * log2(e)
+
+  // ones columns (d = 48 and 52) so that O^T row 48 (both lane halves) accumulates sum(P); written once
+  if (tid < 128) {
+    const int buf = tid >> 6, row = tid & 63;
+    h16x8 one = {(h16)1.f, 0, 0, 0, (h16)1.f, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<h16x8*>(&Vs[buf][row * VSTR + 48]) = one;
+    *reinterpret_cast<h16x8*>(&Vs[buf][row * VSTR + 56]) = zero;
+  }
+
+  // Q^T fragments (B operand): lane = query, element j of k-step ks = Q[q][16 ks + 8 hh + j]
+  const int iq = w.qt * 128 + wave * 32 + l31;
+  const bool qvalid = sq.valid(iq);
+  const long qrow = sq.row_clamped(iq);
+  h16x8 qf[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+    qf[ks] = sel8(qvalid, ldg8(hm_ptr(qkv, M, w.h, qrow) + ks * 16 + hh * 8));
+
+  const StageIdx st(tid);
+  const int ntile = (sq.n + 63) / 64;
+  // tiles [0, nfull) hold only real rows: loaded with a uniform base + constant 32-bit lane offset, no clamp, no select
+  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);
+  const h16* kbase = hm_ptr(qkv, M, H + w.h, sq.row(0));
+  const h16* vbase = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
+  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
+  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
+  h16x8 rk0, rk1, rv0, rv1;
+  bool kok0 = false, kok1 = false, vok0 = false, vok1 = false;
+  // ragged tiles: unconditional loads of clamped rows; padded rows are zeroed by a select when the tile goes to LDS
+  auto gload_k = [&](int t, auto full_tag) {
+    const int kb = t * 64;
+    if (decltype(full_tag)::value) {
+      const h16* b = kbase + (long)kb * sq.dr * HD;
+      rk0 = ldg8_off(b, c0); rk1 = ldg8_off(b, c1);
+    } else {
+      const int i0 = kb + st.row0, i1 = kb + st.row1;
+      rk0 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
+      rk1 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
+      kok0 = sq.valid(i0); kok1 = sq.valid(i1);
+    }
+  };
+  auto gload_v = [&](int t, auto full_tag) {
+    const int kb = t * 64;
+    if (decltype(full_tag)::value) {
+      const h16* b = vbase + (long)kb * sq.dr * HD;
+      rv0 = ldg8_off(b, c0); rv1 = ldg8_off(b, c1);
+    } else {
+      const int i0 = kb + st.row0, i1 = kb + st.row1;
+      rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
+      rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
+      vok0 = sq.valid(i0); vok1 = sq.valid(i1);
+    }
+  };
+  auto lstore_k = [&](int buf, auto full_tag) {
+    h16x8 a = rk0, b = rk1;
+    if (!decltype(full_tag)::value) { a = sel8(kok0, a); b = sel8(kok1, b); }
+    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = a;
+    if (st.has1) *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = b;
+  };
+  auto lstore_v = [&](int buf, auto full_tag) {
+    h16x8 a = rv0, b = rv1;
+    if (!decltype(full_tag)::value) { a = sel8(vok0, a); b = sel8(vok1, b); }
+    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = a;
+    if (st.has1) *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = b;
+  };
+  auto qk = [&](int buf, f32x16 (&s)[2]) {      // raw scores of one 64-key tile: s[sub][reg] (key = row, query = lane)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Ks[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+  float m_run = NEG_BIG;      // running row maximum of the RAW logits q.k (scale c folded into the exp2 argument)
+
+  // prologue: tile 0 -> LDS
+  gload_k(0, std::false_type{}); gload_v(0, std::false_type{});
+  lstore_k(0, std::false_type{}); lstore_v(0, std::false_type{});
+  __syncthreads();
+
+  // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  // next_tag: tile t + 1 is a full tile (fast loads, no selects)
+  auto tile = [&](int t, auto last_tag, auto tail_tag, auto next_tag) {
+    constexpr bool LAST = decltype(last_tag)::value, TAIL = decltype(tail_tag)::value;
+    const int kb = t * 64, buf = t & 1;
+    if (!LAST) { gload_k(t + 1, next_tag); gload_v(t + 1, next_tag); }
+    f32x16 s_cur[2];
+    qk(buf, s_cur);
+    // keys >= n are tile padding (excluded, last tile only); zero-padded keys keep logit 0 (DA:98-101)
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (TAIL) {
+          const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kidx >= sq.n) s_cur[sub][i] = NEG_BIG;
+        }
+        mx = fmaxf(mx, s_cur[sub][i]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    // Deferred rescale (exact): the reference point m_run only moves when some row's maximum grew by more than
+    // 2^RESCALE_LOG2; until then P = exp2((s - m_run) c) <= 2^RESCALE_LOG2, which fp16 P / fp32 O hold without loss.
+    if (__any((m_new - m_run) * c > RESCALE_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      m_run = m_new;
+    }
+    const f32x2 c2 = {c, c}, nmc2 = {-m_run * c, -m_run * c};
+    // O^T += V^T . P^T ; A fragment element e of lane half hh = V[key 16 s2 + 8 (e>>2) + 4 hh + (e&3)][d = lane & 31]
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        h16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 a = pk_exp2(pk_fma((f32x2){s_cur[sub][8 * s2 + e], s_cur[sub][8 * s2 + e + 1]}, c2, nmc2));
+          pf[e] = (h16)a[0]; pf[e + 1] = (h16)a[1];
+        }
+        const h16* vrow = &Vs[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
+        const h16x8 v0 = cat8(lds_tr4(vrow), lds_tr4(vrow + 8 * VSTR));
+        const h16x8 v1 = cat8(lds_tr4(vrow + 32), lds_tr4(vrow + 8 * VSTR + 32));
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf, o1, 0, 0, 0);
+      }
+    if (!LAST) {
+      lstore_k(buf ^ 1, next_tag); lstore_v(buf ^ 1, next_tag);
+      __syncthreads();
+    }
+  };
+  int t = 0;
+  for (; t + 1 < nfull; ++t) tile(t, std::false_type{}, std::false_type{}, std::true_type{});
+  for (; t < ntile - 1; ++t) tile(t, std::false_type{}, std::false_type{}, std::false_type{});
+  if (sq.n & 63) tile(ntile - 1, std::true_type{}, std::true_type{}, std::false_type{});
+  else tile(ntile - 1, std::true_type{}, std::false_type{}, std::false_type{});
+
+  if (qvalid) {
+    const float l = o1[8];           // O^T row 48 (lane half 0) / row 52 (lane half 1): both carry sum(P)
+    const float inv = 1.0f / l;
+    h16* orow = o_br + ((long)w.br * M + qrow) * DM + w.h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      h16x4 v = {(h16)(o0[4 * gq] * inv), (h16)(o0[4 * gq + 1] * inv), (h16)(o0[4 * gq + 2] * inv), (h16)(o0[4 * gq + 3] * inv)};
+      *reinterpret_cast<h16x4*>(orow + 8 * gq + 4 * hh) = v;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      h16x4 v = {(h16)(o1[4 * gq] * inv), (h16)(o1[4 * gq + 1] * inv), (h16)(o1[4 * gq + 2] * inv), (h16)(o1[4 * gq + 3] * inv)};
+      *reinterpret_cast<h16x4*>(orow + 32 + 8 * gq + 4 * hh) = v;
+    }
+    if (hh == 0) lse_br[((long)w.br * M + qrow) * H + w.h] = (m_run * c + __log2f(l)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// branch mix + inner_attn_ln (forward / backward): one wave per token row (16 heads x 48); a lane owns 12 consecutive
+// columns = a quarter of one head.  HBM-bound passes over the covered branch outputs, so the row loop is kept
+// branch-free: a lane's group id per branch is computed once, the row's residue per branch is wave-uniform, and a
+// branch that does not cover (position, head) reads the (always covered) ratio-1 branch's line instead -- an L1 hit --
+// and is discarded with a select.  (A branch around each load made hipcc wait for every load separately.)
+// ------------------------------------------------------------------------------------------------
+struct MixGeom {
+  int grp[MT_MAX_BRANCHES];     // this lane's head group per branch: h / (16 / ratio)
+  MT_DEVINL MixGeom(const Plan& p, int h) {
+#pragma unroll
+    for (int b = 0; b < MT_MAX_BRANCHES; ++b) grp[b] = b < p.nbranch ? h / (H / p.ratio[b]) : -1;
+  }
+};
+// residue of position pos inside its segment, modulo the dilation (wave-uniform)
+MT_DEVINL int residue(const Plan& p, int b, int pos) {
+  const int sg = p.seg[b], dr = p.ratio[b];
+  const int loc = sg >= p.N ? pos : pos % sg;
+  return (dr & (dr - 1)) == 0 ? (loc & (dr - 1)) : loc % dr;
+}
+MT_DEVINL int dense_branch(const Plan& p) {      // a branch with ratio 1 covers every (position, head)
+  int d = 0;
+#pragma unroll
+  for (int b = 0; b < MT_MAX_BRANCHES; ++b) if (b < p.nbranch && p.ratio[b] == 1) d = b;
+  return d;
+}
+struct H12 { h16x4 a, b, c; };
+MT_DEVINL H12 ld12(const h16* p) {
+  return H12{*reinterpret_cast<const h16x4*>(p), *reinterpret_cast<const h16x4*>(p + 4), *reinterpret_cast<const h16x4*>(p + 8)};
+}
+MT_DEVINL float h12(const H12& v, int e) { return (float)(e < 4 ? v.a[e & 3] : e < 8 ? v.b[e & 3] : v.c[e & 3]); }
+
+template <int NB>
+__global__ __launch_bounds__(256) void mix_ln_fwd_kernel(const h16* __restrict__ o_br, const float* __restrict__ lse_br, Plan p,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                         h16* __restrict__ y, float* __restrict__ stats, float* __restrict__ lse_tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long M = (long)p.B * p.N;
+  const int h = lane >> 2, c0 = lane * 12;
+  const MixGeom geo(p, h);
+  const int db = dense_branch(p);
+  float w[12], bb[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) { w[e] = ln_w[c0 + e]; bb[e] = ln_b[c0 + e]; }
+  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+    const int pos = (int)(m % p.N);
+    bool cov[NB];
+    float lse[NB];
+    H12 ob[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      cov[b] = b < p.nbranch && geo.grp[b] == residue(p, b, pos);
+      const int sb = cov[b] ? b : db;
+      lse[b] = lse_br[((long)sb * M + m) * H + h];
+      ob[b] = ld12(o_br + ((long)sb * M + m) * DM + c0);
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { lse[b] = cov[b] ? lse[b] : NEG_BIG; mx = fmaxf(mx, lse[b]); }
+    float den = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) den += cov[b] ? __expf(lse[b] - mx) : 0.f;
+    const float tot = mx + __logf(den);
+    float v[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float wgt = cov[b] ? __expf(lse[b] - tot) : 0.f;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) v[e] = fmaf(wgt, cov[b] ? h12(ob[b], e) : 0.f, v[e]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) s += v[e];
+    const float mean = wave_sum(s) * (1.0f / DM);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) { const float d = v[e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / DM) + 1e-5f);
+    h16* dst = y + m * DM + c0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      h16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (h16)((v[4 * k + e] - mean) * rstd * w[4 * k + e] + bb[4 * k + e]);
+      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
+    }
+    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+    if ((lane & 3) == 0) lse_tot[m * H + h] = tot;
+  }
+}
+
+// backward of mix + LN: recompute mixed from the branch outputs, LayerNorm backward (frozen affine: no dw/db),
+// dmixed (fp16, head-major) and delta_b = sum_d dmixed * O_b per (row, head, branch).
+template <int NB>
+__global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__ dy, const h16* __restrict__ o_br,
+                                                         const float* __restrict__ lse_br, const float* __restrict__ lse_tot, Plan p,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ stats,
+                                                         h16* __restrict__ dmixed, float* __restrict__ delta_br) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long M = (long)p.B * p.N;
+  const int h = lane >> 2, c0 = lane * 12;
+  const MixGeom geo(p, h);
+  const int db = dense_branch(p);
+  float w[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) w[e] = ln_w[c0 + e];
+  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+    const int pos = (int)(m % p.N);
+    const float tot = lse_tot[m * H + h];
+    const float mean = stats[2 * m], rstd = stats[2 * m + 1];
+    const H12 dyv = ld12(dy + m * DM + c0);
+    bool cov[NB];
+    float lse[NB];
+    H12 ob[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      cov[b] = b < p.nbranch && geo.grp[b] == residue(p, b, pos);
+      const int sb = cov[b] ? b : db;
+      lse[b] = lse_br[((long)sb * M + m) * H + h];
+      ob[b] = ld12(o_br + ((long)sb * M + m) * DM + c0);
+    }
+    float v[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float wgt = cov[b] ? __expf(lse[b] - tot) : 0.f;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) v[e] = fmaf(wgt, cov[b] ? h12(ob[b], e) : 0.f, v[e]);
+    }
+    float g[12], xh[12];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      xh[i] = (v[i] - mean) * rstd;
+      g[i] = h12(dyv, i) * w[i];
+      s1 += g[i]; s2 = fmaf(g[i], xh[i], s2);
+    }
+    const float c1 = wave_sum(s1) * (1.0f / DM), c2 = wave_sum(s2) * (1.0f / DM);
+    float dm[12];
+    h16* dst = dmixed + ((long)h * M + m) * HD + (c0 - h * HD);      // head-major [head][B*N][48]
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      h16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * k + e;
+        o[e] = (h16)(rstd * (g[i] - c1 - xh[i] * c2));
+        dm[i] = (float)o[e];          // delta must match the fp16 dmixed the attention backward consumes
+      }
+      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) d = fmaf(dm[e], h12(ob[b], e), d);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      if ((lane & 3) == 0 && cov[b]) delta_br[((long)b * M + m) * H + h] = d;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, kernel Q: dQ.  Same decomposition as the forward (query = lane).
+//   P'^T = exp2(c S^T - L2[q] + log2(scale))   (L2 = lse_tot * log2e; P' = w_b * P_b / sqrt(48))
+//   dP^T[key,q] = V . dO^T                      V rows from LDS, dO^T in registers
+//   dS^T = P'^T (dP^T - delta_b[q])             (the 1/sqrt(48) of dS rides inside P')
+//   dQ^T[d,q] += K^T[d,key] . dS^T              K^T via transposed LDS reads
+// The elementwise block is written with packed fp32 ops (v_pk_fma/add/mul_f32): these kernels issue about as many
+// VALU cycles as MFMA cycles, and the two did not overlap (PMC: VALU 49 %, MFMA 37 % busy before this form).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
+                                                                 const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
+                                                                 Plan p, h16* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];   // row-read layout
+  __shared__ __attribute__((aligned(16))) h16 Kt[2][64 * VSTR];   // transposed-read layout
+  __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * KSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const WorkItem w = decode(p, blockIdx.x);
+  const Seq sq = make_seq(p, w);
+  const long M = (long)p.B * p.N;
+  const float c = 0.14433756729740643f * LOG2E;
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  if (tid < 128) {   // zero the never-written columns 48..63 of the transposed-layout tile (read as d rows 48..63)
+    const int buf = tid >> 6, row = tid & 63;
+    *reinterpret_cast<h16x8*>(&Kt[buf][row * VSTR + 48]) = zero8;
+    *reinterpret_cast<h16x8*>(&Kt[buf][row * VSTR + 56]) = zero8;
+  }
+
+  const int iq = w.qt * 128 + wave * 32 + l31;
+  const bool qvalid = sq.valid(iq);
+  const long qrow = sq.row_clamped(iq);
+  h16x8 qf[3], dof[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    qf[ks] = sel8(qvalid, ldg8(hm_ptr(qkv, M, w.h, qrow) + ks * 16 + hh * 8));
+    dof[ks] = sel8(qvalid, ldg8(hm_ptr(dmixed, M, w.h, qrow) + ks * 16 + hh * 8));
+  }
+  // invalid queries: -L2 = -big -> P' = 0
+  const float L2raw = lse_tot[qrow * H + w.h], dlraw = delta_br[((long)w.br * M + qrow) * H + w.h];
+  const float nl2 = qvalid ? fmaf(-L2raw, LOG2E, LOG2_SCALE) : -1.0e30f;
+  const float ndl = qvalid ? -dlraw : 0.f;
+  const f32x2 c2 = {c, c}, nl22 = {nl2, nl2}, ndl2 = {ndl, ndl};
+
+  const StageIdx st(tid);
+  const int ntile = (sq.n + 63) / 64;
+  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);   // tiles [0, nfull) hold only real rows
+  const h16* kbase = hm_ptr(qkv, M, H + w.h, sq.row(0));
+  const h16* vbase = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
+  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
+  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
+  h16x8 rk0, rk1, rv0, rv1;
+  bool ok0 = false, ok1 = false;
+  auto gload = [&](int t, auto full_tag) {      // first touched in lstore() (latency hides under the MFMAs)
+    const int kb = t * 64;
+    if (decltype(full_tag)::value) {
+      const long adv = (long)kb * sq.dr * HD;
+      rk0 = ldg8_off(kbase + adv, c0); rv0 = ldg8_off(vbase + adv, c0);
+      rk1 = ldg8_off(kbase + adv, c1); rv1 = ldg8_off(vbase + adv, c1);
+    } else {      // ragged tile: clamped rows, zeroed by a select in lstore()
+      const int i0 = kb + st.row0, i1 = kb + st.row1;
+      const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1);
+      rk0 = ldg8(hm_ptr(qkv, M, H + w.h, r0) + st.part0 * 8); rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r0) + st.part0 * 8);
+      rk1 = ldg8(hm_ptr(qkv, M, H + w.h, r1) + st.part1 * 8); rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r1) + st.part1 * 8);
+      ok0 = sq.valid(i0); ok1 = sq.valid(i1);
+    }
+  };
+  auto lstore = [&](int buf, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const h16x8 k0 = FULL ? rk0 : sel8(ok0, rk0), v0 = FULL ? rv0 : sel8(ok0, rv0);
+    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = k0;
+    *reinterpret_cast<h16x8*>(&Kt[buf][st.row0 * VSTR + st.part0 * 8]) = k0;
+    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * KSTR + st.part0 * 8]) = v0;
+    if (st.has1) {
+      const h16x8 k1 = FULL ? rk1 : sel8(ok1, rk1), v1 = FULL ? rv1 : sel8(ok1, rv1);
+      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = k1;
+      *reinterpret_cast<h16x8*>(&Kt[buf][st.row1 * VSTR + st.part1 * 8]) = k1;
+      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * KSTR + st.part1 * 8]) = v1;
+    }
+  };
+
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dq0[i] = 0.f; dq1[i] = 0.f; }
+  gload(0, std::false_type{});
+  lstore(0, std::false_type{});
+  __syncthreads();
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  // tail_tag: the tile holds keys >= n (tile padding, excluded); next_tag: tile t + 1 is a full tile
+  auto tile = [&](int t, auto tail_tag, auto next_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int buf = t & 1, kb = t * 64;
+    if (t + 1 < ntile) gload(t + 1, next_tag);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Ks[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        const h16x8 vf = *reinterpret_cast<const h16x8*>(&Vs[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
+      }
+      h16x8 dsf[2];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 pt = pk_exp2(pk_fma((f32x2){s[i], s[i + 1]}, c2, nl22));
+        if (TAIL) {
+          const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kidx >= sq.n) pt[0] = 0.f;
+          if (kidx + 1 >= sq.n) pt[1] = 0.f;
+        }
+        const f32x2 d = pt * ((f32x2){dp[i], dp[i + 1]} + ndl2);
+        dsf[i >> 3][i & 7] = (h16)d[0];
+        dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const h16* krow = &Kt[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
+        const h16x8 k0 = cat8(lds_tr4(krow), lds_tr4(krow + 8 * VSTR));
+        const h16x8 k1 = cat8(lds_tr4(krow + 32), lds_tr4(krow + 8 * VSTR + 32));
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, dsf[s2], dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, dsf[s2], dq1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntile) lstore(buf ^ 1, next_tag);
+    __syncthreads();
+  };
+  int t = 0;
+  for (; t + 1 < nfull; ++t) tile(t, std::false_type{}, std::true_type{});
+  const int nmask = (sq.n & 63) ? ntile - 1 : ntile;          // tiles >= nmask contain keys >= n
+  for (; t < nmask; ++t) tile(t, std::false_type{}, std::false_type{});
+  for (; t < ntile; ++t) tile(t, std::true_type{}, std::false_type{});
+  if (qvalid) {
+    h16* out = ws + ws_slot(p, w, iq);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const h16x4 v = {(h16)dq0[4 * gq], (h16)dq0[4 * gq + 1], (h16)dq0[4 * gq + 2], (h16)dq0[4 * gq + 3]};
+      *reinterpret_cast<h16x4*>(out + 8 * gq + 4 * hh) = v;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const h16x4 v = {(h16)dq1[4 * gq], (h16)dq1[4 * gq + 1], (h16)dq1[4 * gq + 2], (h16)dq1[4 * gq + 3]};
+      *reinterpret_cast<h16x4*>(out + 32 + 8 * gq + 4 * hh) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, kernel KV: dK, dV.  One workgroup = 128 keys (key = lane) of one (pass, branch, segment, head),
+// sweeping the queries of the same sparse sequence in tiles of 64.
+//   S[q,key]  = Q . K^T            Q rows from LDS, K^T in registers
+//   dP[q,key] = dO . V^T           dO rows from LDS, V^T in registers
+//   P' = exp2(c S - L2[q] + log2(scale)) ; dS = P' (dP - delta[q])        (P' = P~ / sqrt(48))
+//   dV^T[d,key] += dO^T[d,q] . P'  (rescaled by sqrt(48) once at the end) ; dK^T[d,key] += Q^T[d,q] . dS
+// LDS holds (-L2 + log2 scale) / c and -delta per query; they are read straight into the S / dP accumulators before the
+// MFMA chains, so the elementwise block is 2 packed mul, 2 exp and 2 packed converts per element pair.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
+                                                                  const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
+                                                                  Plan p, h16* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) h16 Qs[64 * KSTR];
+  __shared__ __attribute__((aligned(16))) h16 Qt[64 * VSTR];
+  __shared__ __attribute__((aligned(16))) h16 Ds[64 * KSTR];
+  __shared__ __attribute__((aligned(16))) h16 Dt[64 * VSTR];
+  __shared__ __attribute__((aligned(16))) float L2s[64];
+  __shared__ __attribute__((aligned(16))) float Dls[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const WorkItem w = decode(p, blockIdx.x);
+  const Seq sq = make_seq(p, w);
+  const long M = (long)p.B * p.N;
+  const float c = 0.14433756729740643f * LOG2E;
+  const f32x2 c2 = {c, c};
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  if (tid < 64) {
+    *reinterpret_cast<h16x8*>(&Qt[tid * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Qt[tid * VSTR + 56]) = zero8;
+    *reinterpret_cast<h16x8*>(&Dt[tid * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Dt[tid * VSTR + 56]) = zero8;
+  }
+
+  // this lane's key: K^T / V^T fragments (B operands), element j of k-step ks = K[key][16 ks + 8 hh + j]
+  const int ik = w.qt * 128 + wave * 32 + l31;
+  const bool kvalid = sq.valid(ik);
+  const long krow = sq.row_clamped(ik);
+  h16x8 kf[3], vf[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    kf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, H + w.h, krow) + ks * 16 + hh * 8));
+    vf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, 2 * H + w.h, krow) + ks * 16 + hh * 8));
+  }
+
+  const StageIdx st(tid);
+  const int ntile = (sq.n + 63) / 64;
+  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);   // tiles [0, nfull) hold only real rows
+  const h16* qbase = hm_ptr(qkv, M, w.h, sq.row(0));
+  const h16* dbase = hm_ptr(dmixed, M, w.h, sq.row(0));
+  const float* lbase = lse_tot + sq.row(0) * H + w.h;
+  const float* dlbase = delta_br + ((long)w.br * M + sq.row(0)) * H + w.h;
+  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
+  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
+  const uint32_t cl = (uint32_t)(lane * sq.dr * H) * 4u;
+  h16x8 rq0, rq1, rd0, rd1;
+  float rl2 = 0.f, rdl = 0.f;
+  bool ok0 = false, ok1 = false, ok2 = false;
+  auto gload = [&](int t, auto full_tag) {      // first touched in lstore()
+    const int qb = t * 64;
+    if (decltype(full_tag)::value) {
+      const long adv = (long)qb * sq.dr * HD, advl = (long)qb * sq.dr * H;
+      rq0 = ldg8_off(qbase + adv, c0); rd0 = ldg8_off(dbase + adv, c0);
+      rq1 = ldg8_off(qbase + adv, c1); rd1 = ldg8_off(dbase + adv, c1);
+      rl2 = ldf_off(lbase + advl, cl); rdl = ldf_off(dlbase + advl, cl);
+    } else {      // ragged tile: clamped rows, neutralised in lstore()
+      const int i0 = qb + st.row0, i1 = qb + st.row1, i2 = qb + lane;
+      const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1), r2 = sq.row_clamped(i2);
+      rq0 = ldg8(hm_ptr(qkv, M, w.h, r0) + st.part0 * 8); rd0 = ldg8(hm_ptr(dmixed, M, w.h, r0) + st.part0 * 8);
+      rq1 = ldg8(hm_ptr(qkv, M, w.h, r1) + st.part1 * 8); rd1 = ldg8(hm_ptr(dmixed, M, w.h, r1) + st.part1 * 8);
+      rl2 = lse_tot[r2 * H + w.h]; rdl = delta_br[((long)w.br * M + r2) * H + w.h];
+      ok0 = sq.valid(i0); ok1 = sq.valid(i1); ok2 = sq.valid(i2);
+    }
+  };
+  auto lstore = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const h16x8 q0 = FULL ? rq0 : sel8(ok0, rq0), d0 = FULL ? rd0 : sel8(ok0, rd0);
+    *reinterpret_cast<h16x8*>(&Qs[st.row0 * KSTR + st.part0 * 8]) = q0;
+    *reinterpret_cast<h16x8*>(&Qt[st.row0 * VSTR + st.part0 * 8]) = q0;
+    *reinterpret_cast<h16x8*>(&Ds[st.row0 * KSTR + st.part0 * 8]) = d0;
+    *reinterpret_cast<h16x8*>(&Dt[st.row0 * VSTR + st.part0 * 8]) = d0;
+    if (st.has1) {
+      const h16x8 q1 = FULL ? rq1 : sel8(ok1, rq1), d1 = FULL ? rd1 : sel8(ok1, rd1);
+      *reinterpret_cast<h16x8*>(&Qs[st.row1 * KSTR + st.part1 * 8]) = q1;
+      *reinterpret_cast<h16x8*>(&Qt[st.row1 * VSTR + st.part1 * 8]) = q1;
+      *reinterpret_cast<h16x8*>(&Ds[st.row1 * KSTR + st.part1 * 8]) = d1;
+      *reinterpret_cast<h16x8*>(&Dt[st.row1 * VSTR + st.part1 * 8]) = d1;
+    }
+    if (tid < 64) {      // padded / out-of-range queries contribute nothing: -L2 = -big -> P' = 0
+      const bool ok = FULL || ok2;
+      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) * (1.0f / c) : -1.0e30f;
+      Dls[tid] = ok ? -rdl : 0.f;
+    }
+  };
+
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  // cur_tag: tile t (in registers) is a full tile; next_tag: tile t + 1 is
+  auto tile = [&](int t, auto cur_tag, auto next_tag) {
+    __syncthreads();            // previous tile fully consumed
+    lstore(cur_tag);
+    __syncthreads();
+    if (t + 1 < ntile) gload(t + 1, next_tag);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      // row constants ride in as the INITIAL accumulators (rows of the accumulators are queries:
+      // row(i) = (i&3) + 8 (i>>2) + 4 hh): S' = Q.K^T + (-L2 + log2 scale) / c, dP' = dO.V^T - delta
+      f32x16 s, dp;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&L2s[sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Dls[sub * 32 + 8 * g4 + 4 * hh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a[e]; dp[4 * g4 + e] = b[e]; }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qs[(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s, 0, 0, 0);
+        const h16x8 da = *reinterpret_cast<const h16x8*>(&Ds[(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp, 0, 0, 0);
+      }
+      h16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]} * c2);
+        const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
+        pf[i >> 3][i & 7] = (h16)pt[0]; pf[i >> 3][(i & 7) + 1] = (h16)pt[1];
+        dsf[i >> 3][i & 7] = (h16)d[0]; dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int roff = (sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp;
+        const h16x8 d0 = cat8(lds_tr4(&Dt[roff]), lds_tr4(&Dt[roff + 8 * VSTR]));
+        const h16x8 d1 = cat8(lds_tr4(&Dt[roff + 32]), lds_tr4(&Dt[roff + 8 * VSTR + 32]));
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, pf[s2], dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, pf[s2], dv1, 0, 0, 0);
+        const h16x8 q0 = cat8(lds_tr4(&Qt[roff]), lds_tr4(&Qt[roff + 8 * VSTR]));
+        const h16x8 q1 = cat8(lds_tr4(&Qt[roff + 32]), lds_tr4(&Qt[roff + 8 * VSTR + 32]));
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, dsf[s2], dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, dsf[s2], dk1, 0, 0, 0);
+      }
+    }
+  };
+  if (nfull > 0) gload(0, std::true_type{});
+  else gload(0, std::false_type{});
+  int t = 0;
+  for (; t + 1 < nfull; ++t) tile(t, std::true_type{}, std::true_type{});
+  if (t < nfull) { tile(t, std::true_type{}, std::false_type{}); ++t; }     // last full tile, ragged successor
+  for (; t < ntile; ++t) tile(t, std::false_type{}, std::false_type{});
+  if (kvalid) {
+    h16* outk = ws + ws_slot(p, w, ik) + HD;
+    h16* outv = outk + HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const h16x4 a = {(h16)dk0[4 * gq], (h16)dk0[4 * gq + 1], (h16)dk0[4 * gq + 2], (h16)dk0[4 * gq + 3]};
+      const h16x4 b = {(h16)(dv0[4 * gq] * INV_SCALE), (h16)(dv0[4 * gq + 1] * INV_SCALE), (h16)(dv0[4 * gq + 2] * INV_SCALE),
+                       (h16)(dv0[4 * gq + 3] * INV_SCALE)};
+      *reinterpret_cast<h16x4*>(outk + 8 * gq + 4 * hh) = a;
+      *reinterpret_cast<h16x4*>(outv + 8 * gq + 4 * hh) = b;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const h16x4 a = {(h16)dk1[4 * gq], (h16)dk1[4 * gq + 1], (h16)dk1[4 * gq + 2], (h16)dk1[4 * gq + 3]};
+      const h16x4 b = {(h16)(dv1[4 * gq] * INV_SCALE), (h16)(dv1[4 * gq + 1] * INV_SCALE), (h16)(dv1[4 * gq + 2] * INV_SCALE),
+                       (h16)(dv1[4 * gq + 3] * INV_SCALE)};
+      *reinterpret_cast<h16x4*>(outk + 32 + 8 * gq + 4 * hh) = a;
+      *reinterpret_cast<h16x4*>(outv + 32 + 8 * gq + 4 * hh) = b;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, kernel KV, ping-pong form: one workgroup = 8 waves = 256 keys (key = lane, 32 per wave) of one (pass,
+// branch, segment, head).  Same arithmetic as dilated_attn_bwd_kv_kernel; what changes is WHEN the two waves of a SIMD
+// (wave i of group 0, wave i + 4 of group 1) do it.  A 32-query step of a wave has four intervals, each closed by a raw
+// s_barrier, and group 1 runs one interval behind group 0:
+//     I1  S, dP chains (6 MFMA)            while the partner is in I4 (row reads)
+//     I2  exp / convert + transposed reads while the partner is in I1 (MFMA)
+//     I3  dV, dK products (8 MFMA)         while the partner is in I2 (VALU, LDS)
+//     I4  row reads + row constants of the next step   while the partner is in I3 (MFMA)
+// so in every interval exactly one wave per SIMD owns the matrix pipe and the other one the VALU / LDS pipes, instead of
+// the two drifting through MFMA || MFMA and VALU || VALU collisions.  The 64-query Q / dO tiles are double-buffered;
+// tile t + 1 is fetched from global memory at the start of tile t and written to LDS in the I2 of its second step.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void dilated_attn_bwd_kv8_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
+                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
+                                                                   Plan p, h16* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) h16 Qs[2][64 * KSTR];
+  __shared__ __attribute__((aligned(16))) h16 Qt[2][64 * VSTR];
+  __shared__ __attribute__((aligned(16))) h16 Ds[2][64 * KSTR];
+  __shared__ __attribute__((aligned(16))) h16 Dt[2][64 * VSTR];
+  __shared__ __attribute__((aligned(16))) float L2s[2][64];
+  __shared__ __attribute__((aligned(16))) float Dls[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp1 = wave >> 2;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const WorkItem w = decode(p, blockIdx.x);
+  const Seq sq = make_seq(p, w);
+  const long M = (long)p.B * p.N;
+  const float c = 0.14433756729740643f * LOG2E;
+  const f32x2 c2 = {c, c};
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  if (tid < 128) {
+    const int buf = tid >> 6, row = tid & 63;
+    *reinterpret_cast<h16x8*>(&Qt[buf][row * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Qt[buf][row * VSTR + 56]) = zero8;
+    *reinterpret_cast<h16x8*>(&Dt[buf][row * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Dt[buf][row * VSTR + 56]) = zero8;
+  }
+
+  const int ik = w.qt * 256 + wave * 32 + l31;
+  const bool kvalid = sq.valid(ik);
+  const long krow = sq.row_clamped(ik);
+  h16x8 kf[3], vf[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    kf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, H + w.h, krow) + ks * 16 + hh * 8));
+    vf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, 2 * H + w.h, krow) + ks * 16 + hh * 8));
+  }
+
+  // staging roles: threads 0..383 carry Q chunk tid, threads 128..511 carry dO chunk tid - 128 (384 chunks of 16 B per
+  // 64 x 48 tile); threads 0..63 carry L2 of row tid, threads 64..127 delta of row tid - 64
+  const bool hasq = tid < 384, hasd = tid >= 128;
+  const int cq = hasq ? tid : 0, cd = hasd ? tid - 128 : 0;
+  const int qrow_ = cq / 6, qpart = cq - qrow_ * 6, drow_ = cd / 6, dpart = cd - drow_ * 6;
+  const int ntile = (sq.n + 63) / 64;
+  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);
+  const h16* qbase = hm_ptr(qkv, M, w.h, sq.row(0));
+  const h16* dbase = hm_ptr(dmixed, M, w.h, sq.row(0));
+  const float* lbase = lse_tot + sq.row(0) * H + w.h;
+  const float* dlbase = delta_br + ((long)w.br * M + sq.row(0)) * H + w.h;
+  const uint32_t oq = (uint32_t)(qrow_ * sq.dr * HD + qpart * 8) * 2u;
+  const uint32_t od = (uint32_t)(drow_ * sq.dr * HD + dpart * 8) * 2u;
+  const uint32_t ol = (uint32_t)((tid & 63) * sq.dr * H) * 4u;
+  h16x8 rq, rd;
+  float rc = 0.f;
+  bool okq = false, okd = false, okc = false;
+  auto gload = [&](int t) {
+    const int qb = t * 64;
+    if (t < nfull) {
+      const long adv = (long)qb * sq.dr * HD, advl = (long)qb * sq.dr * H;
+      rq = ldg8_off(qbase + adv, oq); rd = ldg8_off(dbase + adv, od);
+      rc = ldf_off((tid < 64 ? lbase : dlbase) + advl, ol);
+      okq = okd = okc = true;
+    } else {
+      const int i0 = qb + qrow_, i1 = qb + drow_, i2 = qb + (tid & 63);
+      rq = ldg8(hm_ptr(qkv, M, w.h, sq.row_clamped(i0)) + qpart * 8);
+      rd = ldg8(hm_ptr(dmixed, M, w.h, sq.row_clamped(i1)) + dpart * 8);
+      const long r2 = sq.row_clamped(i2);
+      rc = tid < 64 ? lse_tot[r2 * H + w.h] : delta_br[((long)w.br * M + r2) * H + w.h];
+      okq = sq.valid(i0); okd = sq.valid(i1); okc = sq.valid(i2);
+    }
+  };
+  auto lstore = [&](int buf) {
+    if (hasq) {
+      const h16x8 v = sel8(okq, rq);
+      *reinterpret_cast<h16x8*>(&Qs[buf][qrow_ * KSTR + qpart * 8]) = v;
+      *reinterpret_cast<h16x8*>(&Qt[buf][qrow_ * VSTR + qpart * 8]) = v;
+    }
+    if (hasd) {
+      const h16x8 v = sel8(okd, rd);
+      *reinterpret_cast<h16x8*>(&Ds[buf][drow_ * KSTR + dpart * 8]) = v;
+      *reinterpret_cast<h16x8*>(&Dt[buf][drow_ * VSTR + dpart * 8]) = v;
+    }
+    if (tid < 64) L2s[buf][tid] = okc ? fmaf(-rc, LOG2E, LOG2_SCALE) * (1.0f / c) : -1.0e30f;
+    else if (tid < 128) Dls[buf][tid - 64] = okc ? -rc : 0.f;
+  };
+
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
+
+  f32x16 s, dp;                 // S / dP accumulators, pre-loaded with the row constants by rows()
+  h16x8 qa[3], da[3];
+  auto rows = [&](int buf, int sub) {      // row reads + row constants of a step
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&L2s[buf][sub * 32 + 8 * g4 + 4 * hh]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&Dls[buf][sub * 32 + 8 * g4 + 4 * hh]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a[e]; dp[4 * g4 + e] = b[e]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      qa[ks] = *reinterpret_cast<const h16x8*>(&Qs[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+      da[ks] = *reinterpret_cast<const h16x8*>(&Ds[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+    }
+  };
+  h16x8 d0[2], d1[2], q0[2], q1[2], pf[2], dsf[2];
+  auto products = [&]() {       // dV, dK of the previous step
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0[s2], pf[s2], dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1[s2], pf[s2], dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0[s2], dsf[s2], dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1[s2], dsf[s2], dk1, 0, 0, 0);
+    }
+  };
+
+  // prologue: tile 0 in LDS, tile 1 in the staging registers, first row reads done
+  gload(0);
+  lstore(0);
+  if (ntile > 1) gload(1);
+  __syncthreads();
+  rows(0, 0);
+  bar();
+  if (grp1) bar();              // group 1 runs one phase behind
+
+  bool have_prev = false;
+  for (int t = 0; t < ntile; ++t) {
+    const int buf = t & 1;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      // ---- matrix phase: dV, dK of the previous step + S, dP of this one (14 MFMAs)
+      __builtin_amdgcn_s_setprio(1);
+      if (have_prev) products();
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da[ks], vf[ks], dp, 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      have_prev = true;
+      bar();
+      // ---- vector phase: transposed reads, exp / convert, the next step's row reads (+ the next tile's LDS image)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int roff = (sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp;
+        d0[s2] = cat8(lds_tr4(&Dt[buf][roff]), lds_tr4(&Dt[buf][roff + 8 * VSTR]));
+        d1[s2] = cat8(lds_tr4(&Dt[buf][roff + 32]), lds_tr4(&Dt[buf][roff + 8 * VSTR + 32]));
+        q0[s2] = cat8(lds_tr4(&Qt[buf][roff]), lds_tr4(&Qt[buf][roff + 8 * VSTR]));
+        q1[s2] = cat8(lds_tr4(&Qt[buf][roff + 32]), lds_tr4(&Qt[buf][roff + 8 * VSTR + 32]));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]} * c2);
+        const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
+        pf[i >> 3][i & 7] = (h16)pt[0]; pf[i >> 3][(i & 7) + 1] = (h16)pt[1];
+        dsf[i >> 3][i & 7] = (h16)d[0]; dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
+      }
+      if (sub == 0) {
+        // tile t + 1 (in the staging registers since the previous tile) -> the other buffer; its first reads come two
+        // phases later, one barrier after the lagging group's stores.  Then start fetching tile t + 2.
+        if (t + 1 < ntile) {
+          lstore(buf ^ 1);
+          if (t + 2 < ntile) gload(t + 2);
+        }
+        rows(buf, 1);
+      } else if (t + 1 < ntile) {
+        rows(buf ^ 1, 0);
+      }
+      bar();
+    }
+  }
+  __builtin_amdgcn_s_setprio(1);
+  if (have_prev) products();
+  __builtin_amdgcn_s_setprio(0);
+  if (!grp1) bar();             // group 0 matches group 1's extra barrier
+
+  if (kvalid) {
+    h16* outk = ws + ws_slot(p, w, ik) + HD;
+    h16* outv = outk + HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const h16x4 a = {(h16)dk0[4 * gq], (h16)dk0[4 * gq + 1], (h16)dk0[4 * gq + 2], (h16)dk0[4 * gq + 3]};
+      const h16x4 b = {(h16)(dv0[4 * gq] * INV_SCALE), (h16)(dv0[4 * gq + 1] * INV_SCALE), (h16)(dv0[4 * gq + 2] * INV_SCALE),
+                       (h16)(dv0[4 * gq + 3] * INV_SCALE)};
+      *reinterpret_cast<h16x4*>(outk + 8 * gq + 4 * hh) = a;
+      *reinterpret_cast<h16x4*>(outv + 8 * gq + 4 * hh) = b;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const h16x4 a = {(h16)dk1[4 * gq], (h16)dk1[4 * gq + 1], (h16)dk1[4 * gq + 2], (h16)dk1[4 * gq + 3]};
+      const h16x4 b = {(h16)(dv1[4 * gq] * INV_SCALE), (h16)(dv1[4 * gq + 1] * INV_SCALE), (h16)(dv1[4 * gq + 2] * INV_SCALE),
+                       (h16)(dv1[4 * gq + 3] * INV_SCALE)};
+      *reinterpret_cast<h16x4*>(outk + 32 + 8 * gq + 4 * hh) = a;
+      *reinterpret_cast<h16x4*>(outv + 32 + 8 * gq + 4 * hh) = b;
+    }
+  }
+}
+
+// Sum the per-branch compact gradients into the dense fp16 dqkv [B*N, 2304] that feeds the dX GEMM.
+// 192 threads per token row: thread -> 12 consecutive columns of one (q|k|v, head).
+__global__ __launch_bounds__(192) void dilated_attn_bwd_combine_kernel(const h16* __restrict__ ws, Plan p, h16* __restrict__ dqkv) {
+  const long M = (long)p.B * p.N;
+  const int t = threadIdx.x;
+  const int col = t * 12, which = col / DM, h = (col % DM) / HD, d0 = col % HD;
+  for (long m = blockIdx.x; m < M; m += gridDim.x) {
+    const int b = (int)(m / p.N), pos = (int)(m % p.N);
+    float acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int br = 0; br < MT_MAX_BRANCHES; ++br) {
+      if (br < p.nbranch) {
+        const int dr = p.ratio[br], sg = p.seg[br];
+        const int j = pos / sg, loc = pos - j * sg;
+        const int r = h / (H / dr);
+        if (loc % dr == r) {
+          const int i = loc / dr;
+          const h16* src = ws + p.ws_off[br] + ((((long)b * p.nseg[br] + j) * H + h) * p.n[br] + i) * (3 * HD) + which * HD + d0;
+          const h16x4 a0 = *reinterpret_cast<const h16x4*>(src), a1 = *reinterpret_cast<const h16x4*>(src + 4),
+                      a2 = *reinterpret_cast<const h16x4*>(src + 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[e] += (float)a0[e]; acc[4 + e] += (float)a1[e]; acc[8 + e] += (float)a2[e]; }
+        }
+      }
+    }
+    h16* dst = dqkv + m * QKV_LD + col;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const h16x4 o = {(h16)acc[4 * k], (h16)acc[4 * k + 1], (h16)acc[4 * k + 2], (h16)acc[4 * k + 3]};
+      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_dilated_attn_fwd(const mt_half* qkv, const MtDilatedPlan* plan, mt_half* o_br, float* lse_br,
+                                   mt_stream_t stream) {
+  if (!qkv || !o_br || !lse_br || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  const int nblk = p.blk_off[p.nbranch];
+#ifdef MT_DIAG
+  const char* ev = getenv("MT_DIAG_VARIANT");
+  const int variant = ev ? atoi(ev) : 0;
+#define MT_LAUNCH_V(v) case v: hipLaunchKernelGGL(dilated_attn_fwd_kernel<v>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv, p, (h16*)o_br, lse_br); break;
+  switch (variant) { MT_LAUNCH_V(0) MT_LAUNCH_V(1) MT_LAUNCH_V(2) MT_LAUNCH_V(3) MT_LAUNCH_V(4) MT_LAUNCH_V(5) default: return MT_ERR_BAD_ARG; }
+#else
+  hipLaunchKernelGGL(dilated_attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv, p,
+                     (h16*)o_br, lse_br);
+#endif
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_dilated_mix_ln_fwd(const mt_half* o_br, const float* lse_br, const MtDilatedPlan* plan,
+                                     const float* ln_w, const float* ln_b, mt_half* y, float* stats, float* lse_tot,
+                                     mt_stream_t stream) {
+  if (!o_br || !lse_br || !ln_w || !ln_b || !y || !stats || !lse_tot || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  const long M = (long)p.B * p.N;
+  const dim3 grid((int)min((M + 3) / 4, 8192L));
+  if (p.nbranch <= 5)
+    hipLaunchKernelGGL(mix_ln_fwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)o_br, lse_br, p, ln_w, ln_b,
+                       (h16*)y, stats, lse_tot);
+  else
+    hipLaunchKernelGGL(mix_ln_fwd_kernel<MT_MAX_BRANCHES>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)o_br, lse_br, p,
+                       ln_w, ln_b, (h16*)y, stats, lse_tot);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, const float* lse_br, const float* lse_tot,
+                                     const MtDilatedPlan* plan, const float* ln_w, const float* stats, mt_half* dmixed,
+                                     float* delta_br, mt_stream_t stream) {
+  if (!dy || !o_br || !lse_br || !lse_tot || !ln_w || !stats || !dmixed || !delta_br || !plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  const long M = (long)p.B * p.N;
+  const dim3 grid((int)min((M + 3) / 4, 8192L));
+  if (p.nbranch <= 5)
+    hipLaunchKernelGGL(mix_ln_bwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)dy, (const h16*)o_br, lse_br,
+                       lse_tot, p, ln_w, stats, (h16*)dmixed, delta_br);
+  else
+    hipLaunchKernelGGL(mix_ln_bwd_kernel<MT_MAX_BRANCHES>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)dy,
+                       (const h16*)o_br, lse_br, lse_tot, p, ln_w, stats, (h16*)dmixed, delta_br);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" long mt_dilated_attn_bwd_workspace_bytes(const MtDilatedPlan* plan) {
+  if (!plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  return p.ws_off[p.nbranch] * (long)sizeof(h16);
+}
+
+extern "C" int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot,
+                                   const float* delta_br, const MtDilatedPlan* plan, void* workspace, mt_half* dqkv,
+                                   int phases, mt_stream_t stream) {
+  if (!qkv || !dmixed || !lse_tot || !delta_br || !workspace || !dqkv || !plan_ok(plan) || !(phases & 7)) return MT_ERR_BAD_ARG;
+  const Plan p = make_plan(plan, 128);
+  const int nblk = p.blk_off[p.nbranch];
+  hipStream_t s = (hipStream_t)stream;
+  // every (branch, position, head) slot of the workspace is written exactly once by each of the two kernels
+  static const bool kv8 = getenv("MT_KV8") != nullptr;
+  if ((phases & MT_ATTN_BWD_KV) && kv8) {
+    const Plan p8 = make_plan(plan, 256);
+    hipLaunchKernelGGL(dilated_attn_bwd_kv8_kernel, dim3(p8.blk_off[p8.nbranch]), dim3(512), 0, s, (const h16*)qkv,
+                       (const h16*)dmixed, lse_tot, delta_br, p8, (h16*)workspace);
+  } else if (phases & MT_ATTN_BWD_KV)
+    hipLaunchKernelGGL(dilated_attn_bwd_kv_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
+                       delta_br, p, (h16*)workspace);
+  if (phases & MT_ATTN_BWD_Q)
+    hipLaunchKernelGGL(dilated_attn_bwd_q_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
+                       delta_br, p, (h16*)workspace);
+  const long M = (long)p.B * p.N;
+  if (phases & MT_ATTN_BWD_COMBINE)
+    hipLaunchKernelGGL(dilated_attn_bwd_combine_kernel, dim3((int)min(M, 16384L)), dim3(192), 0, s, (const h16*)workspace, p, (h16*)dqkv);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
