@@ -24,141 +24,216 @@ MT_DEVINL void store16(h16* p, const float* v) {
 }
 
 // ---------------------------------------------------------------- injector -----------------------
-// grid (ceil(rows/256), 12 heads, B passes); thread = one patch row of the pass, K/V of (pass, head) in LDS.
+// forward on MFMA: grid (ceil(rows/128), 12 heads, B passes); wave = 32 patch rows (row = lane & 31).  With d = 16 one
+// v_mfma_f32_32x32x16_f16 is a whole 32-token x 32-row score block: S^T = K . Q^T (K rows from an fp16 LDS image, Q^T
+// straight from global memory), softmax lane-local (row = lane, tokens in registers + one cross-half shuffle),
+// O^T += V^T . P^T with P^T taken from the score accumulators (V^T from a transposed fp16 LDS image).
+constexpr int KP = 24;            // halves per row of the row-read K image (48 B: conflict-free 16-lane ds_read_b128 groups)
+constexpr int TPV = TMAX + 8;     // halves per row of the transposed [16][tokens] images (272 B)
+MT_DEVINL h16x8 cat8h(h16x4 lo, h16x4 hi) { return (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+
 __global__ __launch_bounds__(256) void inject_attn_fwd_kernel(const h16* __restrict__ q, int rows_per_pass, const float* __restrict__ k,
                                                               const float* __restrict__ v, int T, h16* __restrict__ a,
                                                               float* __restrict__ lse) {
-  __shared__ __attribute__((aligned(16))) float ks[TMAX * AD], vs[TMAX * AD];
-  const int h = blockIdx.y, b = blockIdx.z;
-  for (int i = threadIdx.x; i < T * AD; i += 256) {
+  __shared__ __attribute__((aligned(16))) h16 ksh[TMAX * KP];     // K[t][d]
+  __shared__ __attribute__((aligned(16))) h16 vT[AD * TPV];       // V^T[d][t]
+  const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+  for (int i = tid; i < TMAX * AD; i += 256) {
     const int t = i / AD, d = i % AD;
-    ks[i] = k[((long)b * T + t) * AE + h * AD + d];
-    vs[i] = v[((long)b * T + t) * AE + h * AD + d];
+    const bool ok = t < T;
+    ksh[t * KP + d] = (h16)(ok ? k[((long)b * T + t) * AE + h * AD + d] : 0.f);
+    vT[d * TPV + t] = (h16)(ok ? v[((long)b * T + t) * AE + h * AD + d] : 0.f);
   }
   __syncthreads();
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= rows_per_pass) return;
-  const long m = (long)b * rows_per_pass + r;
-  float qv[AD], acc[AD];
-  load16(q + m * AE + h * AD, qv);
+  const int ntb = (T + 31) / 32;
+  const int r = blockIdx.x * 128 + wave * 32 + l31;
+  const bool valid = r < rows_per_pass;
+  const long m = (long)b * rows_per_pass + (valid ? r : 0);
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const h16x8 qf = valid ? ldg8(q + m * AE + h * AD + 8 * hh) : zero8;     // B operand: Q^T[d = 8 hh + j][row]
+  f32x16 sc[TMAX / 32];
+  float mx = -1.0e30f;
 #pragma unroll
-  for (int d = 0; d < AD; ++d) { qv[d] *= ASCALE; acc[d] = 0.f; }
-  float mx = -1.0e30f, l = 0.f;
-  for (int t = 0; t < T; ++t) {
-    float s = 0.f;
+  for (int tb = 0; tb < TMAX / 32; ++tb) {
+    if (tb < ntb) {
 #pragma unroll
-    for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[t * AD + d], s);
-    const float mn = fmaxf(mx, s);
-    const float al = __expf(mx - mn), p = __expf(s - mn);
-    l = l * al + p;
+      for (int i = 0; i < 16; ++i) sc[tb][i] = 0.f;
+      const h16x8 kf = *reinterpret_cast<const h16x8*>(&ksh[(tb * 32 + l31) * KP + 8 * hh]);
+      sc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, sc[tb], 0, 0, 0);
 #pragma unroll
-    for (int d = 0; d < AD; ++d) acc[d] = fmaf(acc[d], al, p * vs[t * AD + d]);
-    mx = mn;
+      for (int i = 0; i < 16; ++i) {      // accumulator rows are tokens: (i&3) + 8 (i>>2) + 4 hh
+        if (tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= T) sc[tb][i] = -1.0e30f;
+        mx = fmaxf(mx, sc[tb][i]);
+      }
+    }
   }
-  const float inv = 1.0f / l;
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float c = ASCALE * 1.4426950408889634f;
+  f32x16 acc;
 #pragma unroll
-  for (int d = 0; d < AD; ++d) acc[d] *= inv;
-  store16(a + m * AE + h * AD, acc);
-  if (lse) lse[m * AH + h] = mx + __logf(l);      // of the scaled logits (q carries the 1/4)
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int tb = 0; tb < TMAX / 32; ++tb) {
+    if (tb < ntb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        h16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pv = __builtin_amdgcn_exp2f((sc[tb][8 * s2 + e] - mx) * c);
+          l += pv;
+          pf[e] = (h16)pv;
+        }
+        // A operand: V^T[d = lane & 15][token 16 s2 + 8 (e>>2) + 4 hh + (e&3)] (the accumulator-order k permutation)
+        const h16* vr = &vT[(l31 & 15) * TPV + tb * 32 + 16 * s2 + 4 * hh];
+        const h16x8 vf = cat8h(*reinterpret_cast<const h16x4*>(vr), *reinterpret_cast<const h16x4*>(vr + 8));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc, 0, 0, 0);
+      }
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (valid) {
+    const float inv = 1.0f / l;
+    // O^T rows d = (i&3) + 8 (i>>2) + 4 hh, valid for i < 8: this lane holds d = 4 hh + {0..3} and 8 + 4 hh + {0..3}
+    h16* dst = a + m * AE + h * AD;
+    *reinterpret_cast<h16x4*>(dst + 4 * hh) = (h16x4){(h16)(acc[0] * inv), (h16)(acc[1] * inv), (h16)(acc[2] * inv), (h16)(acc[3] * inv)};
+    *reinterpret_cast<h16x4*>(dst + 8 + 4 * hh) = (h16x4){(h16)(acc[4] * inv), (h16)(acc[5] * inv), (h16)(acc[6] * inv), (h16)(acc[7] * inv)};
+    if (lse && hh == 0) lse[m * AH + h] = mx * ASCALE + __logf(l);
+  }
 }
 
-// backward: workgroup = ITILES x 128 rows of one (pass, head).
-// Phase 1 (thread = row, one sweep over the tokens): p = exp(s/4 - lse), dp = da . v, delta = a . da (flash identity),
-// ds = p (dp - delta) / 4, dq += ds k; p / ds / q / da go to LDS TRANSPOSED ([token][row], [dim][row], fp16).
-// Phase 2 (MFMA): dk[t,d] += sum_rows ds[row,t] q[row,d] and dv[t,d] += sum_rows p[row,t] da[row,d] are 32x32x16
-// products with the row index as the reduction dimension -- both operands are plain 16-byte row reads of the
-// transposed images (wave 0 owns dk, wave 1 owns dv).  The accumulators live across the row tiles: one atomic per
-// (token, dim) per workgroup at the very end.
+// backward: workgroup = 4 waves = ITILES x 128 rows of one (pass, head); everything on MFMA.
+// Phase 1 (wave = 32 rows, row = lane): S^T = K . Q^T and dP^T = V . dA^T (one 32x32x16 MFMA per 32-token block each),
+// p = exp(s/4 - lse) (lse saved by the forward, same fp16 K), delta = a . da (flash identity), ds = p (dp - delta) / 4,
+// dQ^T += K^T . dS^T with dS^T taken from the accumulators; p / ds / q / da go to LDS TRANSPOSED ([token][row], [dim][row]).
+// Phase 2: dk[t,d] += sum_rows ds[row,t] q[row,d] and dv[t,d] += sum_rows p[row,t] da[row,d] are 32x32x16 products with
+// the row index as the reduction dimension -- both operands are plain 16-byte row reads of the transposed images
+// (wave w: product w & 1, token blocks w >> 1 and (w >> 1) + 2).  The accumulators live across the row tiles: one
+// atomic per (token, dim) per workgroup at the very end.
 constexpr int IBR = 128, ITILES = 4, RSTR = IBR + 8;   // RSTR: halves per transposed row (272 B: conflict-free b128)
-__global__ __launch_bounds__(IBR) void inject_attn_bwd_kernel(const h16* __restrict__ q, const h16* __restrict__ a,
+__global__ __launch_bounds__(256) void inject_attn_bwd_kernel(const h16* __restrict__ q, const h16* __restrict__ a,
                                                               const float* __restrict__ lse, const h16* __restrict__ da,
                                                               int rows_per_pass, const float* __restrict__ k,
                                                               const float* __restrict__ v, int T, h16* __restrict__ dq,
                                                               float* __restrict__ dk, float* __restrict__ dv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* ks = smem;                                   // [T][16]
-  float* vs = ks + T * AD;                            // [T][16]
-  h16* psT = reinterpret_cast<h16*>(vs + T * AD);     // [T][RSTR]
+  const int ntb = (T + 31) / 32, TB = ntb * 32;
+  h16* ksh = reinterpret_cast<h16*>(smem);            // [TB][KP]   K rows
+  h16* vsh = ksh + TB * KP;                           // [TB][KP]   V rows
+  h16* kT = vsh + TB * KP;                            // [16][TPV]  K^T
+  h16* psT = kT + AD * TPV;                           // [T][RSTR]
   h16* dssT = psT + T * RSTR;                         // [T][RSTR]
   h16* qT = dssT + T * RSTR;                          // [16][RSTR]
   h16* daT = qT + AD * RSTR;                          // [16][RSTR]
   const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
-  for (int i = tid; i < T * AD; i += IBR) {
+  for (int i = tid; i < TB * AD; i += 256) {
     const int t = i / AD, d = i % AD;
-    ks[i] = k[((long)b * T + t) * AE + h * AD + d];
-    vs[i] = v[((long)b * T + t) * AE + h * AD + d];
+    const bool ok = t < T;
+    const h16 kv_ = (h16)(ok ? k[((long)b * T + t) * AE + h * AD + d] : 0.f);
+    ksh[t * KP + d] = kv_;
+    kT[d * TPV + t] = kv_;
+    vsh[t * KP + d] = (h16)(ok ? v[((long)b * T + t) * AE + h * AD + d] : 0.f);
   }
-  const int ntb = (T + 31) / 32;
-  f32x16 acc[TMAX / 32];
+  f32x16 acc[TMAX / 64];            // phase 2: token blocks (wave >> 1) and (wave >> 1) + 2 of product (wave & 1)
 #pragma unroll
-  for (int tb = 0; tb < TMAX / 32; ++tb)
+  for (int j = 0; j < TMAX / 64; ++j)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[tb][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float c = ASCALE * 1.4426950408889634f;
   __syncthreads();
   for (int tile = 0; tile < ITILES; ++tile) {
     const int r0 = (blockIdx.x * ITILES + tile) * IBR;
     if (r0 >= rows_per_pass) break;                   // uniform
-    const int r = r0 + tid;
+    const int rl = wave * 32 + l31;                   // row inside the tile
+    const int r = r0 + rl;
     const bool valid = r < rows_per_pass;
     const long m = (long)b * rows_per_pass + (valid ? r : 0);
-    float qv[AD], dav[AD], av[AD];
-    load16(q + m * AE + h * AD, qv);
-    load16(da + m * AE + h * AD, dav);
-    load16(a + m * AE + h * AD, av);
-    const float ls = lse[m * AH + h];
+    const h16x8 qf = valid ? ldg8(q + m * AE + h * AD + 8 * hh) : zero8;
+    const h16x8 daf = valid ? ldg8(da + m * AE + h * AD + 8 * hh) : zero8;
+    const h16x8 af = ldg8(a + m * AE + h * AD + 8 * hh);
+    const float nl2 = valid ? -lse[m * AH + h] * 1.4426950408889634f : -1.0e30f;
     float delta = 0.f;
 #pragma unroll
-    for (int d = 0; d < AD; ++d) {
-      if (!valid) { qv[d] = 0.f; dav[d] = 0.f; }
-      delta = fmaf(av[d], dav[d], delta);
-      qT[d * RSTR + tid] = (h16)qv[d];                // exact: q and da are fp16 values
-      daT[d * RSTR + tid] = (h16)dav[d];
+    for (int e = 0; e < 8; ++e) {
+      delta = fmaf((float)af[e], (float)daf[e], delta);
+      qT[(8 * hh + e) * RSTR + rl] = qf[e];
+      daT[(8 * hh + e) * RSTR + rl] = daf[e];
     }
-    float dqv[AD];
+    delta += __shfl_xor(delta, 32, 64);
+    f32x16 dqa;
 #pragma unroll
-    for (int d = 0; d < AD; ++d) dqv[d] = 0.f;
-    for (int t = 0; t < T; ++t) {
-      float sc = 0.f, dp = 0.f;
-#pragma unroll
-      for (int d = 0; d < AD; ++d) { sc = fmaf(qv[d], ks[t * AD + d], sc); dp = fmaf(dav[d], vs[t * AD + d], dp); }
-      const float p = valid ? __expf(fmaf(sc, ASCALE, -ls)) : 0.f;
-      const float ds = p * (dp - delta) * ASCALE;
-      psT[t * RSTR + tid] = (h16)p;
-      dssT[t * RSTR + tid] = (h16)ds;
-#pragma unroll
-      for (int d = 0; d < AD; ++d) dqv[d] = fmaf(ds, ks[t * AD + d], dqv[d]);
-    }
-    if (valid) store16(dq + m * AE + h * AD, dqv);
-    __syncthreads();
-    const h16* Asrc = wave ? psT : dssT;
-    const h16* Bsrc = wave ? daT : qT;
+    for (int i = 0; i < 16; ++i) dqa[i] = 0.f;
 #pragma unroll
     for (int tb = 0; tb < TMAX / 32; ++tb) {
+      if (tb < ntb) {
+        f32x16 sc, dpv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dpv[i] = 0.f; }
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&ksh[(tb * 32 + l31) * KP + 8 * hh]);
+        const h16x8 vf = *reinterpret_cast<const h16x8*>(&vsh[(tb * 32 + l31) * KP + 8 * hh]);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, sc, 0, 0, 0);
+        dpv = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, daf, dpv, 0, 0, 0);
+        h16x8 dsf[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;      // accumulator rows are tokens
+          const float pv = t < T ? __builtin_amdgcn_exp2f(fmaf(sc[i], c, nl2)) : 0.f;
+          const float ds = pv * (dpv[i] - delta) * ASCALE;
+          dsf[i >> 3][i & 7] = (h16)ds;
+          if (t < T) {
+            psT[t * RSTR + rl] = (h16)pv;
+            dssT[t * RSTR + rl] = (h16)ds;
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const h16* kr = &kT[(l31 & 15) * TPV + tb * 32 + 16 * s2 + 4 * hh];
+          const h16x8 ktf = cat8h(*reinterpret_cast<const h16x4*>(kr), *reinterpret_cast<const h16x4*>(kr + 8));
+          dqa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktf, dsf[s2], dqa, 0, 0, 0);
+        }
+      }
+    }
+    if (valid) {
+      h16* dst = dq + m * AE + h * AD;
+      *reinterpret_cast<h16x4*>(dst + 4 * hh) = (h16x4){(h16)dqa[0], (h16)dqa[1], (h16)dqa[2], (h16)dqa[3]};
+      *reinterpret_cast<h16x4*>(dst + 8 + 4 * hh) = (h16x4){(h16)dqa[4], (h16)dqa[5], (h16)dqa[6], (h16)dqa[7]};
+    }
+    __syncthreads();
+    const h16* Asrc = (wave & 1) ? psT : dssT;
+    const h16* Bsrc = (wave & 1) ? daT : qT;
+#pragma unroll
+    for (int j = 0; j < TMAX / 64; ++j) {
+      const int tb = (wave >> 1) + 2 * j;
       if (tb < ntb) {
         const int trow = min(tb * 32 + l31, T - 1);   // rows >= T: valid memory, results never flushed
 #pragma unroll
         for (int kk = 0; kk < IBR / 16; ++kk) {
-          const h16x8 af = *reinterpret_cast<const h16x8*>(&Asrc[trow * RSTR + kk * 16 + hh * 8]);
-          const h16x8 bf = *reinterpret_cast<const h16x8*>(&Bsrc[(l31 & 15) * RSTR + kk * 16 + hh * 8]);
-          acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[tb], 0, 0, 0);
+          const h16x8 afr = *reinterpret_cast<const h16x8*>(&Asrc[trow * RSTR + kk * 16 + hh * 8]);
+          const h16x8 bfr = *reinterpret_cast<const h16x8*>(&Bsrc[(l31 & 15) * RSTR + kk * 16 + hh * 8]);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr, acc[j], 0, 0, 0);
         }
       }
     }
     __syncthreads();
   }
   // accumulator rows are tokens: row(i) = (i&3) + 8 (i>>2) + 4 hh; column = lane & 31 = dim (16 valid)
-  float* dst = wave ? dv : dk;
+  float* dst = (wave & 1) ? dv : dk;
   if (l31 < AD) {
 #pragma unroll
-    for (int tb = 0; tb < TMAX / 32; ++tb)
+    for (int j = 0; j < TMAX / 64; ++j) {
+      const int tb = (wave >> 1) + 2 * j;
       if (tb < ntb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int t = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (t < T) atomicAdd(&dst[((long)b * T + t) * AE + h * AD + l31], acc[tb][i]);
+          if (t < T) atomicAdd(&dst[((long)b * T + t) * AE + h * AD + l31], acc[j][i]);
         }
       }
+    }
   }
 }
 
@@ -456,7 +531,7 @@ extern "C" int mt_inject_attn_fwd(const mt_half* q, int M, int rows_per_pass, co
                                   mt_half* a, float* lse, mt_stream_t stream) {
   if (!q || !k || !v || !a || M <= 0 || rows_per_pass <= 0 || M % rows_per_pass || T < 1 || T > TMAX) return MT_ERR_BAD_ARG;
   const int B = M / rows_per_pass;
-  hipLaunchKernelGGL(inject_attn_fwd_kernel, dim3(cdiv(rows_per_pass, 256), AH, B), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(inject_attn_fwd_kernel, dim3(cdiv(rows_per_pass, 128), AH, B), dim3(256), 0, (hipStream_t)stream,
                      (const h16*)q, rows_per_pass, k, v, T, (h16*)a, lse);
   MT_CHECK_LAUNCH();
   return MT_OK;
@@ -469,13 +544,14 @@ extern "C" int mt_inject_attn_bwd(const mt_half* q, const mt_half* a, const floa
       T > TMAX)
     return MT_ERR_BAD_ARG;
   const int B = M / rows_per_pass;
-  const size_t shm = sizeof(float) * (2 * T * AD) + sizeof(h16) * (2 * T + 2 * AD) * RSTR;
+  const int TBk = cdiv(T, 32) * 32;
+  const size_t shm = sizeof(h16) * ((size_t)2 * TBk * KP + AD * TPV + (size_t)(2 * T + 2 * AD) * RSTR);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)inject_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(inject_attn_bwd_kernel, dim3(cdiv(rows_per_pass, IBR * ITILES), AH, B), dim3(IBR), shm, (hipStream_t)stream,
+  hipLaunchKernelGGL(inject_attn_bwd_kernel, dim3(cdiv(rows_per_pass, IBR * ITILES), AH, B), dim3(256), shm, (hipStream_t)stream,
                      (const h16*)q, (const h16*)a, lse, (const h16*)da, rows_per_pass, k, v, T, (h16*)dq, dk, dv);
   MT_CHECK_LAUNCH();
   return MT_OK;
