@@ -238,71 +238,114 @@ __global__ __launch_bounds__(256) void inject_attn_bwd_kernel(const h16* __restr
 }
 
 // ---------------------------------------------------------------- extractor ----------------------
-// forward: grid (nsplit, 12, B); 256 threads = nsub key-lanes x T tokens (nsub = min(256 / T, 8)): thread (t, sub)
-// sweeps keys sub, sub + nsub, ... of each 64-key LDS tile with an online softmax; the nsub partials of a token are
-// merged through LDS at the end, so the partial buffers keep one entry per (split, token).
-constexpr int EKT = 64, EFT = 256;
+// forward on MFMA: grid (nsplit, 12, B); 4 waves, wave w sweeps the 32-key blocks w, w + 4, ... of the split.
+// S^T[key, token] = K . Q^T: K rows straight from global memory (A operand, key = lane & 31), Q^T (pre-scaled, fp16) in
+// registers, one 32x32x16 MFMA per 32-token block; online softmax lane-local (token = lane, keys in registers + one
+// cross-half shuffle); O^T[d, token] += V^T . P^T with P^T from the accumulators and V^T read transposed
+// (ds_read_b64_tr_b16) from a wave-private LDS copy of the 32 x 16 V block.  The four waves' partials are merged
+// through LDS into one partial per (split, token) for the reduce kernel below.
+constexpr int EKT = 32, EFT = 256, VP = 24;       // VP: halves per LDS row of the V block (48 B, 8-byte aligned tr reads)
+MT_DEVINL h16x4 ad_tr4(const h16* p) {
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)p);
+  return __builtin_bit_cast(h16x4, r);
+}
 __global__ __launch_bounds__(EFT) void extract_attn_fwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv, int T, int L,
                                                                int keys_per_split, float* __restrict__ part_acc, float* __restrict__ part_ml) {
-  __shared__ __attribute__((aligned(16))) float ks[EKT * AD], vs[EKT * AD];
-  __shared__ float mrg[EFT][AD + 3];
+  __shared__ __attribute__((aligned(16))) h16 vsh[4][32 * VP];
+  __shared__ float mrg[4][TMAX][AD + 2];
   const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int nsplit = gridDim.x;
-  const int nsub = min(EFT / T, 8);
-  const int sub = tid / T, t = tid - sub * T;
-  const bool tv = sub < nsub;
-  float qv[AD], acc[AD];
+  const int lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+  const int li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int ntb = (T + 31) / 32;
+  h16x8 qf[TMAX / 32];              // B operands: Q^T[d = 8 hh + j][token]
+  f32x16 acc[TMAX / 32];
+  float mrun[TMAX / 32], lrun[TMAX / 32];
 #pragma unroll
-  for (int d = 0; d < AD; ++d) { qv[d] = tv ? q[((long)b * T + t) * AE + h * AD + d] * ASCALE : 0.f; acc[d] = 0.f; }
-  float mx = -1.0e30f, l = 0.f;
-  const int kbeg = sp * keys_per_split, kend = min(L, kbeg + keys_per_split);
-  for (int k0 = kbeg; k0 < kend; k0 += EKT) {
-    __syncthreads();
-    if (tid < 2 * EKT) {   // 64 keys x (16 k + 16 v) halves: thread -> (key, k|v)
-      const int key = tid >> 1, which = tid & 1;
-      float tmp[AD];
-      if (k0 + key < kend) load16(kv + ((long)b * L + k0 + key) * (2 * AE) + which * AE + h * AD, tmp);
-      else {
+  for (int tb = 0; tb < TMAX / 32; ++tb) {
+    const int t = tb * 32 + l31;
 #pragma unroll
-        for (int d = 0; d < AD; ++d) tmp[d] = 0.f;
-      }
-      float* dst = (which ? vs : ks) + key * AD;
+    for (int e = 0; e < 8; ++e) qf[tb][e] = (h16)(t < T ? q[((long)b * T + t) * AE + h * AD + 8 * hh + e] * ASCALE : 0.f);
 #pragma unroll
-      for (int d = 0; d < AD; ++d) dst[d] = tmp[d];
-    }
-    __syncthreads();
-    const int nk = min(EKT, kend - k0);
-    if (tv)
-      for (int j = sub; j < nk; j += nsub) {
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[j * AD + d], s);
-        const float mn = fmaxf(mx, s);
-        const float al = __expf(mx - mn), p = __expf(s - mn);
-        l = l * al + p;
-#pragma unroll
-        for (int d = 0; d < AD; ++d) acc[d] = fmaf(acc[d], al, p * vs[j * AD + d]);
-        mx = mn;
-      }
+    for (int i = 0; i < 16; ++i) acc[tb][i] = 0.f;
+    mrun[tb] = -1.0e30f; lrun[tb] = 0.f;
   }
-  // merge the nsub partials of each token
-  if (tv) {
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int kbeg = sp * keys_per_split, kend = min(L, kbeg + keys_per_split);
+  h16* vw = vsh[wave];
+  for (int k0 = kbeg + wave * EKT; k0 < kend; k0 += 4 * EKT) {
+    const int key = k0 + l31;
+    const bool valid = key < kend;
+    const h16* row = kv + ((long)b * L + (valid ? key : kbeg)) * (2 * AE) + h * AD + 8 * hh;
+    const h16x8 kf = valid ? ldg8(row) : zero8;
+    const h16x8 vf = valid ? ldg8(row + AE) : zero8;
+    *reinterpret_cast<h16x8*>(&vw[l31 * VP + 8 * hh]) = vf;      // wave-private: no workgroup barrier needed
+    // V^T fragments (A operand of O^T += V^T . P^T), shared by the token blocks; lanes >= 16 of a half produce the unused
+    // d rows 16..31 from the same columns
+    h16x8 vt[2];
 #pragma unroll
-    for (int d = 0; d < AD; ++d) mrg[tid][d] = acc[d];
-    mrg[tid][AD] = mx; mrg[tid][AD + 1] = l;
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const h16* vr = &vw[(s2 * 16 + 4 * hh + tq) * VP + 4 * tp];
+      const h16x4 lo = ad_tr4(vr), hi = ad_tr4(vr + 8 * VP);
+      vt[s2] = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int tb = 0; tb < TMAX / 32; ++tb) {
+      if (tb < ntb) {
+        f32x16 sc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[tb], sc, 0, 0, 0);
+        float mx = -1.0e30f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {      // accumulator rows are keys (i&3) + 8 (i>>2) + 4 hh
+          if (k0 + (i & 3) + 8 * (i >> 2) + 4 * hh >= kend) sc[i] = -1.0e30f;
+          mx = fmaxf(mx, sc[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(mrun[tb], mx);
+        const float al = __expf(mrun[tb] - mn);
+        float ls = 0.f;
+        h16x8 pf[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float pv = __expf(sc[i] - mn);
+          ls += pv;
+          pf[i >> 3][i & 7] = (h16)pv;
+        }
+        ls += __shfl_xor(ls, 32, 64);
+        lrun[tb] = lrun[tb] * al + ls;
+        mrun[tb] = mn;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[tb][i] *= al;
+        acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[0], pf[0], acc[tb], 0, 0, 0);
+        acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[1], pf[1], acc[tb], 0, 0, 0);
+      }
+    }
+  }
+  // per-wave partials -> LDS: O^T rows d = (i&3) + 8 (i>>2) + 4 hh (i < 8), column = token
+#pragma unroll
+  for (int tb = 0; tb < TMAX / 32; ++tb) {
+    const int t = tb * 32 + l31;
+    if (tb < ntb && t < T) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mrg[wave][t][(i & 3) + 8 * (i >> 2) + 4 * hh] = acc[tb][i];
+      if (hh == 0) { mrg[wave][t][AD] = mrun[tb]; mrg[wave][t][AD + 1] = lrun[tb]; }
+    }
   }
   __syncthreads();
   if (tid < T) {
     float m2 = -1.0e30f;
-    for (int s = 0; s < nsub; ++s) m2 = fmaxf(m2, mrg[s * T + tid][AD]);
+    for (int wv = 0; wv < 4; ++wv) m2 = fmaxf(m2, mrg[wv][tid][AD]);
     float l2 = 0.f, a2[AD];
 #pragma unroll
     for (int d = 0; d < AD; ++d) a2[d] = 0.f;
-    for (int s = 0; s < nsub; ++s) {
-      const float wgt = __expf(mrg[s * T + tid][AD] - m2);
-      l2 = fmaf(wgt, mrg[s * T + tid][AD + 1], l2);
+    for (int wv = 0; wv < 4; ++wv) {
+      const float wgt = __expf(mrg[wv][tid][AD] - m2);
+      l2 = fmaf(wgt, mrg[wv][tid][AD + 1], l2);
 #pragma unroll
-      for (int d = 0; d < AD; ++d) a2[d] = fmaf(wgt, mrg[s * T + tid][d], a2[d]);
+      for (int d = 0; d < AD; ++d) a2[d] = fmaf(wgt, mrg[wv][tid][d], a2[d]);
     }
     const long o = (((long)b * AH + h) * nsplit + sp) * T + tid;
 #pragma unroll
@@ -334,98 +377,124 @@ __global__ void extract_attn_reduce_kernel(const float* __restrict__ part_acc, c
   lse[((long)b * T + t) * AH + h] = mx + __logf(l);
 }
 
-// backward: workgroup = ETILES x 128 keys of one (pass, head); thread = key.  q, dout, lse, delta of the (pass, head)
-// live in LDS.  Phase 1: per key sweep the tokens -> dk, dv (fp16 rows); ds and k go to LDS transposed (fp16).
-// Phase 2 (MFMA, as in the injector backward): dq[t,d] += sum_keys ds[key,t] k[key,d]; the two waves split the
-// 32-token blocks; one atomic per (token, dim) per workgroup at the end.
+// backward on MFMA: workgroup = 4 waves = ETILES x 128 keys of one (pass, head); wave = 32 keys (key = lane & 31).
+// Phase 1: S[t,key] = Q . K^T and dP[t,key] = dO . V^T, one 32x32x16 MFMA per 32-token block each, with -lse[t] and
+// -delta[t] as the initial accumulators (rows of the accumulators are tokens); p = exp(S'), ds = p dP';
+// dK^T[d,key] += Q^T . dS and dV^T[d,key] += dO^T . P with dS / P taken from the accumulators (Q^T, dO^T from
+// transposed fp16 LDS images); ds and k go to LDS transposed.  Phase 2: dq[t,d] += sum_keys ds[key,t] k[key,d] (wave w:
+// token block w); one atomic per (token, dim) per workgroup at the end.  q (pre-scaled by 1/4) and dout are rounded to
+// fp16 for the MFMA, as in the forward.
 constexpr int EBK = 128, ETILES = 4;
-__global__ __launch_bounds__(EBK) void extract_attn_bwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv,
+__global__ __launch_bounds__(256) void extract_attn_bwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv,
                                                                const float* __restrict__ out, const float* __restrict__ lse,
                                                                const float* __restrict__ dout, int T, int L, float* __restrict__ dq,
                                                                h16* __restrict__ dkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* qs = smem;                 // [T][16] (pre-scaled)
-  float* dos = qs + T * AD;         // [T][16]
-  float* ls = dos + T * AD;         // [T]
-  float* dl = ls + TMAX;            // [T]
-  h16* dssT = reinterpret_cast<h16*>(dl + TMAX);    // [T][RSTR]
-  h16* kT = dssT + T * RSTR;                        // [16][RSTR]
+  const int ntb = (T + 31) / 32, TB = ntb * 32;
+  float* nls = smem;                                  // [TB]  -lse (natural log) ; big negative past T
+  float* ndl = nls + TMAX;                            // [TB]  -delta
+  h16* qsh = reinterpret_cast<h16*>(ndl + TMAX);      // [TB][KP]   Q rows (scaled)
+  h16* dosh = qsh + TB * KP;                          // [TB][KP]   dO rows
+  h16* qT = dosh + TB * KP;                           // [16][TPV]  Q^T
+  h16* doT = qT + AD * TPV;                           // [16][TPV]  dO^T
+  h16* dssT = doT + AD * TPV;                         // [T][RSTR]
+  h16* kT = dssT + T * RSTR;                          // [16][RSTR]
   const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
-  for (int i = tid; i < T * AD; i += EBK) {
+  for (int i = tid; i < TB * AD; i += 256) {
     const int t = i / AD, d = i % AD;
-    qs[i] = q[((long)b * T + t) * AE + h * AD + d] * ASCALE;
-    dos[i] = dout[((long)b * T + t) * AE + h * AD + d];
+    const bool ok = t < T;
+    const h16 qv_ = (h16)(ok ? q[((long)b * T + t) * AE + h * AD + d] * ASCALE : 0.f);
+    const h16 dv_ = (h16)(ok ? dout[((long)b * T + t) * AE + h * AD + d] : 0.f);
+    qsh[t * KP + d] = qv_; qT[d * TPV + t] = qv_;
+    dosh[t * KP + d] = dv_; doT[d * TPV + t] = dv_;
   }
-  for (int t = tid; t < T; t += EBK) {
-    ls[t] = lse[((long)b * T + t) * AH + h];
-    float d = 0.f;
-    for (int e = 0; e < AD; ++e) d = fmaf(dout[((long)b * T + t) * AE + h * AD + e], out[((long)b * T + t) * AE + h * AD + e], d);
-    dl[t] = d;
+  for (int t = tid; t < TB; t += 256) {
+    float d = 0.f, l = 1.0e30f;
+    if (t < T) {
+      l = lse[((long)b * T + t) * AH + h];
+      for (int e = 0; e < AD; ++e) d = fmaf(dout[((long)b * T + t) * AE + h * AD + e], out[((long)b * T + t) * AE + h * AD + e], d);
+    }
+    nls[t] = -l; ndl[t] = -d;
   }
-  const int ntb = (T + 31) / 32;
-  f32x16 acc[TMAX / 64];            // this wave's token blocks: wave, wave + 2
+  f32x16 accq;                      // phase 2: token block `wave`
 #pragma unroll
-  for (int j = 0; j < TMAX / 64; ++j)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  for (int i = 0; i < 16; ++i) accq[i] = 0.f;
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   __syncthreads();
   for (int tile = 0; tile < ETILES; ++tile) {
     const int k0 = (blockIdx.x * ETILES + tile) * EBK;
     if (k0 >= L) break;             // uniform
-    const int key = k0 + tid;
+    const int kl = wave * 32 + l31;
+    const int key = k0 + kl;
     const bool valid = key < L;
-    float kvv[AD], vv[AD], dkv_[AD], dvv[AD];
-    if (valid) {
-      load16(kv + ((long)b * L + key) * (2 * AE) + h * AD, kvv);
-      load16(kv + ((long)b * L + key) * (2 * AE) + AE + h * AD, vv);
-    } else {
+    const h16* kvrow = kv + ((long)b * L + (valid ? key : 0)) * (2 * AE) + h * AD + 8 * hh;
+    const h16x8 kf = valid ? ldg8(kvrow) : zero8;             // B operands: K^T[d = 8 hh + j][key], V^T likewise
+    const h16x8 vf = valid ? ldg8(kvrow + AE) : zero8;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) { kvv[d] = 0.f; vv[d] = 0.f; }
+    for (int e = 0; e < 8; ++e) kT[(8 * hh + e) * RSTR + kl] = kf[e];
+    f32x16 dka, dva;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dka[i] = 0.f; dva[i] = 0.f; }
+#pragma unroll
+    for (int tb = 0; tb < TMAX / 32; ++tb) {
+      if (tb < ntb) {
+        f32x16 sc, dpv;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {      // accumulator rows are tokens (i&3) + 8 (i>>2) + 4 hh
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(&nls[tb * 32 + 8 * g4 + 4 * hh]);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(&ndl[tb * 32 + 8 * g4 + 4 * hh]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sc[4 * g4 + e] = l4[e]; dpv[4 * g4 + e] = d4[e]; }
+        }
+        const h16x8 qa = *reinterpret_cast<const h16x8*>(&qsh[(tb * 32 + l31) * KP + 8 * hh]);
+        const h16x8 da = *reinterpret_cast<const h16x8*>(&dosh[(tb * 32 + l31) * KP + 8 * hh]);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf, sc, 0, 0, 0);
+        dpv = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf, dpv, 0, 0, 0);
+        h16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          const float pv = valid ? __expf(sc[i]) : 0.f;       // rows past T carry -1e30 -> 0
+          const float ds = pv * dpv[i];
+          pf[i >> 3][i & 7] = (h16)pv;
+          dsf[i >> 3][i & 7] = (h16)ds;
+          if (t < T) dssT[t * RSTR + kl] = (h16)(ds * ASCALE);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int toff = (l31 & 15) * TPV + tb * 32 + 16 * s2 + 4 * hh;
+          const h16x8 qtf = cat8h(*reinterpret_cast<const h16x4*>(&qT[toff]), *reinterpret_cast<const h16x4*>(&qT[toff + 8]));
+          const h16x8 dtf = cat8h(*reinterpret_cast<const h16x4*>(&doT[toff]), *reinterpret_cast<const h16x4*>(&doT[toff + 8]));
+          dka = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf[s2], dka, 0, 0, 0);
+          dva = __builtin_amdgcn_mfma_f32_32x32x16_f16(dtf, pf[s2], dva, 0, 0, 0);
+        }
+      }
     }
-#pragma unroll
-    for (int d = 0; d < AD; ++d) { kT[d * RSTR + tid] = (h16)kvv[d]; dkv_[d] = 0.f; dvv[d] = 0.f; }
-    for (int t = 0; t < T; ++t) {
-      float s = 0.f, dp = 0.f;
-#pragma unroll
-      for (int d = 0; d < AD; ++d) { s = fmaf(qs[t * AD + d], kvv[d], s); dp = fmaf(dos[t * AD + d], vv[d], dp); }
-      const float p = valid ? __expf(s - ls[t]) : 0.f;
-      const float ds = p * (dp - dl[t]);
-      dssT[t * RSTR + tid] = (h16)(ds * ASCALE);
-#pragma unroll
-      for (int d = 0; d < AD; ++d) { dkv_[d] = fmaf(ds, qs[t * AD + d], dkv_[d]); dvv[d] = fmaf(p, dos[t * AD + d], dvv[d]); }
-    }
-    if (valid) {
-      store16(dkv + ((long)b * L + key) * (2 * AE) + h * AD, dkv_);        // qs already carries the 1/4 scale
-      store16(dkv + ((long)b * L + key) * (2 * AE) + AE + h * AD, dvv);
+    if (valid) {      // rows d = (i&3) + 8 (i>>2) + 4 hh of the d x key accumulators, i < 8 (qsh already carries the 1/4)
+      h16* dst = dkv + ((long)b * L + key) * (2 * AE) + h * AD;
+      *reinterpret_cast<h16x4*>(dst + 4 * hh) = (h16x4){(h16)dka[0], (h16)dka[1], (h16)dka[2], (h16)dka[3]};
+      *reinterpret_cast<h16x4*>(dst + 8 + 4 * hh) = (h16x4){(h16)dka[4], (h16)dka[5], (h16)dka[6], (h16)dka[7]};
+      *reinterpret_cast<h16x4*>(dst + AE + 4 * hh) = (h16x4){(h16)dva[0], (h16)dva[1], (h16)dva[2], (h16)dva[3]};
+      *reinterpret_cast<h16x4*>(dst + AE + 8 + 4 * hh) = (h16x4){(h16)dva[4], (h16)dva[5], (h16)dva[6], (h16)dva[7]};
     }
     __syncthreads();
+    if (wave < ntb) {               // uniform per wave
+      const int trow = min(wave * 32 + l31, T - 1);
 #pragma unroll
-    for (int j = 0; j < TMAX / 64; ++j) {
-      const int tb = wave + 2 * j;
-      if (tb < ntb) {
-        const int trow = min(tb * 32 + l31, T - 1);
-#pragma unroll
-        for (int kk = 0; kk < EBK / 16; ++kk) {
-          const h16x8 af = *reinterpret_cast<const h16x8*>(&dssT[trow * RSTR + kk * 16 + hh * 8]);
-          const h16x8 bf = *reinterpret_cast<const h16x8*>(&kT[(l31 & 15) * RSTR + kk * 16 + hh * 8]);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[j], 0, 0, 0);
-        }
+      for (int kk = 0; kk < EBK / 16; ++kk) {
+        const h16x8 af = *reinterpret_cast<const h16x8*>(&dssT[trow * RSTR + kk * 16 + hh * 8]);
+        const h16x8 bf = *reinterpret_cast<const h16x8*>(&kT[(l31 & 15) * RSTR + kk * 16 + hh * 8]);
+        accq = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, accq, 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  if (l31 < AD) {
+  if (l31 < AD && wave < ntb) {
 #pragma unroll
-    for (int j = 0; j < TMAX / 64; ++j) {
-      const int tb = wave + 2 * j;
-      if (tb < ntb) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int t = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (t < T) atomicAdd(&dq[((long)b * T + t) * AE + h * AD + l31], acc[j][i]);
-        }
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int t = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (t < T) atomicAdd(&dq[((long)b * T + t) * AE + h * AD + l31], accq[i]);
     }
   }
 }
@@ -573,13 +642,14 @@ extern "C" int mt_extract_attn_fwd(const float* q, const mt_half* kv, int B, int
 extern "C" int mt_extract_attn_bwd(const float* q, const mt_half* kv, const float* out, const float* lse,
                                    const float* dout, int B, int T, int L, float* dq, mt_half* dkv, mt_stream_t stream) {
   if (!q || !kv || !out || !lse || !dout || !dq || !dkv || B < 1 || T < 1 || T > TMAX || L < 1) return MT_ERR_BAD_ARG;
-  const size_t shm = sizeof(float) * (2 * T * AD + 2 * TMAX) + sizeof(h16) * (T + AD) * RSTR;
+  const int TBk = cdiv(T, 32) * 32;
+  const size_t shm = sizeof(float) * (2 * TMAX) + sizeof(h16) * ((size_t)2 * TBk * KP + 2 * AD * TPV + (size_t)(T + AD) * RSTR);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)extract_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(extract_attn_bwd_kernel, dim3(cdiv(L, EBK * ETILES), AH, B), dim3(EBK), shm, (hipStream_t)stream, q,
+  hipLaunchKernelGGL(extract_attn_bwd_kernel, dim3(cdiv(L, EBK * ETILES), AH, B), dim3(256), shm, (hipStream_t)stream, q,
                      (const h16*)kv, out, lse, dout, T, L, dq, (h16*)dkv);
   MT_CHECK_LAUNCH();
   return MT_OK;
