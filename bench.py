@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--pathways", default="6", help="number of toy pathways (sizes 5, 6, ...) or 'real': the reference's 331-pathway "
                                                     "grouping sizes (tests/golden/pathway_sizes_331.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="run the step with Dropout / DropPath off (the parity configuration); "
+                                                             "default: on, as model.train() leaves them in the reference")
     ap.add_argument("--kernel-times", action="store_true", help="print the per-kernel time table (stderr)")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -97,6 +99,7 @@ def main():
     args.pathways = len(sizes)
     eng = Engine(cfg, sizes, dev)
     eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed=0))      # identical weights on every rank
+    eng.set_stochastic(not args.no_dropout, seed=20260 + rank)     # Dropout(0.25) / DropPath(<= 0.1): counter-based masks
     ts = TrainStep(eng)
     ts.set_projector(synth.projector_state(0))
     # synthetic slides, distinct per rank, resident in HBM (2 alternating slides per rank)
@@ -172,7 +175,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"Prov-GigaPath ModalAdapter train step, {L} patches x 1536-d, {args.pathways} pathways -> "
                                    f"{T - 1} gene tokens + 1 task token, 3 task passes, fp16 operands / fp32 accumulate, "
-                                   f"1 slide per GPU per step", "patches": L, "tokens": T, "parallelism": f"dp{world}"},
+                                   f"1 slide per GPU per step, train mode: "
+                                   + ("dropout / drop-path off (parity configuration)" if args.no_dropout else
+                                      f"Dropout({cfg.dropout}) on the embedded input and both backbone branches, DropPath(0..{cfg.drop_path_rate}) "
+                                      f"per layer and on the Extractor FFN (Philox masks regenerated in backward)"),
+                       "patches": L, "tokens": T, "parallelism": f"dp{world}", "dropout": not args.no_dropout},
             "loss": loss, "skipped_steps": skipped,
             "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / world / 1e12 / PEAK_F16_MFMA_TFLOPS,
             "roofline": {"kernel": "dilated_attn_bwd_kv_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS,

@@ -49,6 +49,29 @@ enum { MT_EPI_BIAS = 0,        /* C = acc + bias                                
                                   dilated-attention kernels read (DA:169-175 "b l (h d) -> (b h) l d")          */
 enum { MT_OUT_F16 = 0, MT_OUT_F32 = 1 };
 
+/* Train-mode stochastic ops (nn.Dropout, timm DropPath: ENC:149-152,169-170, FFN:142, ENC:339, AM:319-327) as
+ * counter-based masks: nothing is stored, the backward regenerates the mask of a site from (seed, step, site, element
+ * index) with Philox4x32 (7 rounds).  rng: device uint32[4] = {seed_lo, seed_hi, step, reserved}; mt_rng_advance
+ * increments `step` once per train step (inside the captured graph).  Element dropout: element (m, n) of a dense [M, D]
+ * activation is kept when its random word >= p * 2^32 and scaled by 1/(1-p).  DropPath: one Bernoulli per (path_site,
+ * pass), pass = m / rows_per_pass; a dropped pass is zeroed, a kept one scaled by 1/(1-path_p).  rng == NULL or both
+ * probabilities 0: identity. */
+typedef struct {
+  const unsigned* rng;
+  unsigned site;
+  float p;
+  unsigned path_site;
+  float path_p;
+  int rows_per_pass;
+} MtDropout;
+int mt_rng_advance(unsigned* rng, mt_stream_t stream);
+/* y(m,:) = drop(x(xmap(m),:)) for a dense fp32 y [M, D] (Encoder.prepare_forward's input dropout, ENC:339: one mask
+ * per task pass over the shared patch embedding) */
+int mt_dropout_f32(const float* x, long ldx, const MtRowMap* xmap, float* y, int M, int D, const MtDropout* drop,
+                   mt_stream_t stream);
+/* in place on rows: x(m,:) *= DropPath factor of pass m / rows_per_pass (token-side residual branches) */
+int mt_droppath_rows_f32(float* x, int M, int D, const MtDropout* drop, mt_stream_t stream);
+
 typedef struct {
   const float* bias;           /* [N] or NULL */
   const float* resid;          /* fp32 [*, ldr] (BIAS_RESID, INJECT) */
@@ -58,6 +81,7 @@ typedef struct {
   const float* pos_table;      /* [ngrids, N/2] 1-D sin-cos table (POSEMB), pos_embed.py:62-81 */
   const int* pos_row;          /* [M] grid row index  floor(coords[:,0]/256), SE:209-211 */
   const int* pos_col;          /* [M] grid col index */
+  MtDropout drop;              /* BIAS_RESID: C = resid + drop(acc + bias)  (ENC:149-154: dropout, DropPath, + residual) */
 } MtGemmEpilogue;
 
 /* C[M,N] = epilogue(A[M,K] @ W[N,K]^T); A, W fp16; fp32 accumulate on MFMA.  K % 64 == 0, lda % 8 == 0.
@@ -100,11 +124,12 @@ int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, int in_dtype
  * dx_dtype F32 with accumulate=1 adds into the fp32 residual-gradient stream (ENC:137-154 backward);
  * dw/db (fp32 [D], atomically accumulated) may be NULL for frozen norms (selective backward).
  * dx_f16 (dense fp16 [M,D], or NULL): a second, half-precision copy of the final dx -- the operand of the next dX GEMM
- * of the frozen layer below, written here instead of by a separate cast pass over the fp32 stream. */
+ * of the frozen layer below, written here instead of by a separate cast pass over the fp32 stream; dx_f16_drop (or
+ * NULL): the dropout / DropPath mask of the residual branch that GEMM differentiates, applied to the copy only. */
 int mt_layernorm_bwd(const void* dy, long lddy, const MtRowMap* dymap, int dy_dtype, const void* x, long ldx,
                      const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w, const float* stats, void* dx,
                      long lddx, const MtRowMap* dxmap, int dx_dtype, int accumulate, float* dw, float* db,
-                     mt_half* dx_f16, int M, int D, mt_stream_t stream);
+                     mt_half* dx_f16, const MtDropout* dx_f16_drop, int M, int D, mt_stream_t stream);
 
 /* ------------------------------------------------------- dilated attention ------------------------- */
 #define MT_MAX_BRANCHES 8
@@ -173,13 +198,14 @@ int mt_extract_attn_bwd(const float* q, const mt_half* kv, const float* out, con
  *   z[i] = ELU(W2_i ELU(W1_i g_i + b1_i) + b2_i).
  * params / grads: the flat fp32 parameter / gradient buffers; offs [G][4] = element offsets of (W1_i [latent, n_i],
  * b1_i, W2_i [latent, latent], b2_i) (W2 offsets multiples of 4); sizes [G] = n_i; goff [G] = offset of g_i in the
- * concatenated `genes` vector; a1, a2 [G, latent] pre-activations saved for the backward; latent must be 256. */
+ * concatenated `genes` vector; a1, a2 [G, latent] pre-activations saved for the backward; latent must be 256.
+ * alpha_drop (or NULL): train-mode nn.AlphaDropout(p) after each ELU, sites alpha_drop->site and site + 1. */
 int mt_gene_snn_fwd(const float* params, const long* offs, const int* sizes, const long* goff, const float* genes, int G,
-                    int latent, float* a1, float* a2, float* z, mt_stream_t stream);
+                    int latent, float* a1, float* a2, float* z, const MtDropout* alpha_drop, mt_stream_t stream);
 /* backward: grads (+)= dW1, db1, dW2, db2 for every pathway given dz [G, latent] (no input gradient: genes are data) */
 int mt_gene_snn_bwd(const float* params, float* grads, const long* offs, const int* sizes, const long* goff,
                     const float* genes, int G, int latent, const float* a1, const float* a2, const float* dz,
-                    mt_stream_t stream);
+                    const MtDropout* alpha_drop, mt_stream_t stream);
 
 /* Small dense multi-head attention over tokens (prompt self-attention AM:87): q,k,v fp32 [B,T,E], heads h. */
 int mt_token_mha_fwd(const float* q, const float* k, const float* v, int B, int T, int E, int heads, float* out,
@@ -188,7 +214,8 @@ int mt_token_mha_bwd(const float* q, const float* k, const float* v, const float
                      int T, int E, int heads, float* dq, float* dk, float* dv, mt_stream_t stream);
 
 /* ------------------------------------------------------------ elementwise -------------------------- */
-int mt_cast_f32_to_f16(const float* x, mt_half* y, long n, mt_stream_t stream);
+/* y = fp16(x); with `drop` (rows of D elements): y = fp16(drop(x)) -- the masked gradient of a dropped residual branch */
+int mt_cast_f32_to_f16(const float* x, mt_half* y, long n, const MtDropout* drop, int D, mt_stream_t stream);
 int mt_cast_f16_to_f32(const mt_half* x, float* y, long n, mt_stream_t stream);
 /* Derived fp16 weight cache of an fp32 nn.Linear weight [R, C]: as stored (forward, W[N,K]) or transposed
  * (the dX GEMM's W^T[K,N]); re-run for trainable weights after every optimiser step (SURVEY §8b ownership). */

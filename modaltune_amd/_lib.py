@@ -20,9 +20,13 @@ class MtRowMap(C.Structure):
     _fields_ = [("seg_rows", I), ("seg_stride", I), ("row0", I)]
 
 
+class MtDropout(C.Structure):
+    _fields_ = [("rng", P), ("site", C.c_uint), ("p", F), ("path_site", C.c_uint), ("path_p", F), ("rows_per_pass", I)]
+
+
 class MtGemmEpilogue(C.Structure):
     _fields_ = [("bias", P), ("resid", P), ("ldr", L), ("rmap", MtRowMap), ("colscale", P),
-                ("pos_table", P), ("pos_row", P), ("pos_col", P)]
+                ("pos_table", P), ("pos_row", P), ("pos_col", P), ("drop", MtDropout)]
 
 
 MT_MAX_BRANCHES = 8
@@ -34,6 +38,7 @@ class MtDilatedPlan(C.Structure):
 
 
 RM = C.POINTER(MtRowMap)
+DR = C.POINTER(MtDropout)
 EP = C.POINTER(MtGemmEpilogue)
 PL = C.POINTER(MtDilatedPlan)
 
@@ -46,21 +51,24 @@ SIGNATURES = {
     "mt_colsum_f16": [P, L, RM, I, I, P, P],
     "mt_sgemm_small": [P, L, L, L, P, L, L, L, P, I, P, L, L, L, I, I, I, I, I, I, P, P],
     "mt_layernorm_fwd": [P, L, RM, I, I, P, P, P, I, P, L, RM, I, P, I, I, P],
-    "mt_layernorm_bwd": [P, L, RM, I, P, L, RM, I, I, P, P, P, L, RM, I, I, P, P, P, I, I, P],
+    "mt_layernorm_bwd": [P, L, RM, I, P, L, RM, I, I, P, P, P, L, RM, I, I, P, P, P, DR, I, I, P],
     "mt_dilated_attn_fwd": [P, PL, P, P, P],
     "mt_dilated_mix_ln_fwd": [P, P, PL, P, P, P, P, P, P],
     "mt_dilated_mix_ln_bwd": [P, P, P, P, PL, P, P, P, P, P],
     "mt_dilated_attn_bwd_workspace_bytes": [PL],
     "mt_dilated_attn_bwd": [P, P, P, P, PL, P, P, I, P],
-    "mt_gene_snn_fwd": [P, P, P, P, P, I, I, P, P, P, P],
-    "mt_gene_snn_bwd": [P, P, P, P, P, P, I, I, P, P, P, P],
+    "mt_gene_snn_fwd": [P, P, P, P, P, I, I, P, P, P, DR, P],
+    "mt_gene_snn_bwd": [P, P, P, P, P, P, I, I, P, P, P, DR, P],
     "mt_inject_attn_fwd": [P, I, I, P, P, I, P, P, P],
     "mt_inject_attn_bwd": [P, P, P, P, I, I, P, P, I, P, P, P, P],
     "mt_extract_attn_fwd": [P, P, I, I, I, P, P, P, P, I, P],
     "mt_extract_attn_bwd": [P, P, P, P, P, I, I, I, P, P, P],
     "mt_token_mha_fwd": [P, P, P, I, I, I, I, P, P, P],
     "mt_token_mha_bwd": [P, P, P, P, P, I, I, I, I, P, P, P, P],
-    "mt_cast_f32_to_f16": [P, P, L, P],
+    "mt_cast_f32_to_f16": [P, P, L, DR, I, P],
+    "mt_rng_advance": [P, P],
+    "mt_dropout_f32": [P, L, RM, P, I, I, DR, P],
+    "mt_droppath_rows_f32": [P, I, I, DR, P],
     "mt_cast_f16_to_f32": [P, P, L, P],
     "mt_pack_weight_f16": [P, I, I, P, I, P],
     "mt_act_fwd": [P, P, L, I, P],

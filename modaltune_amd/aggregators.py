@@ -99,6 +99,15 @@ class LongNetGeneAdapter(Aggregator):
         self._dummy = torch.zeros(1, device=self.engine.device, requires_grad=True)
         self._versions = None
         self.training_grad = True
+        self.train(True)
+
+    def train(self, mode: bool = True):
+        """model.train() leaves Dropout / DropPath active in the reference (frozen != eval); eval() and
+        no_grad forwards run without them.  Set the config's dropout / drop_path_rate to 0 for parity comparisons."""
+        super().train(mode)
+        if hasattr(self, "engine"):
+            self.engine.stochastic = bool(mode) and (self.cfg.dropout > 0 or self.cfg.drop_path_rate > 0)
+        return self
 
     # ---- parameter / state_dict surface under the reference's key names (SURVEY A.9)
     def named_parameters(self, prefix: str = "", recurse: bool = True, remove_duplicate: bool = True) -> Iterator[Tuple[str, nn.Parameter]]:

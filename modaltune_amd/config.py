@@ -29,6 +29,7 @@ class GeneConfig:
     expansion_groups: float = 0.5
     expansion_dim: float = 0.5
     final_groups: int = 64
+    dropout: float = 0.25       # AlphaDropout in the pathway networks, Dropout in the mixer feed-forwards (train mode)
 
 
 @dataclasses.dataclass

@@ -70,6 +70,61 @@ MT_DEVINL float gelu_erf_grad(float x) {
   return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + er));   // Phi(x) + x phi(x)
 }
 
+// ---- counter-based dropout masks (include/modaltune_hip.h: MtDropout)
+struct DropArgs {
+  const uint32_t* rng; uint32_t site; float p; uint32_t path_site; float path_p; int rows_per_pass;
+  __host__ __device__ __forceinline__ bool active() const { return rng != nullptr && (p > 0.f || path_p > 0.f); }
+};
+static inline DropArgs make_drop(const MtDropout* d) {
+  DropArgs a;
+  if (d && d->rng && (d->p > 0.f || d->path_p > 0.f)) {
+    a.rng = d->rng; a.site = d->site; a.p = d->p; a.path_site = d->path_site; a.path_p = d->path_p;
+    a.rows_per_pass = d->rows_per_pass > 0 ? d->rows_per_pass : 1;
+  } else {
+    a.rng = nullptr; a.site = 0; a.p = 0.f; a.path_site = 0; a.path_p = 0.f; a.rows_per_pass = 1;
+  }
+  return a;
+}
+// Philox4x32 with 7 rounds (Salmon et al. 2011: passes BigCrush from 7 rounds up)
+MT_DEVINL void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+MT_DEVINL uint32_t drop_threshold(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f); }
+// scale factors of the 4 consecutive elements whose linear index starts at 4 * idx4, in row m of the activation
+MT_DEVINL f32x4 drop_scale4(const DropArgs& d, uint64_t idx4, int m) {
+  const uint32_t k0 = d.rng[0], k1 = d.rng[1], step = d.rng[2];
+  float pf = 1.f;
+  if (d.path_p > 0.f) {
+    uint32_t r[4];
+    philox4x32_7((uint32_t)(m / d.rows_per_pass), 0x9E3779B9u, d.path_site, step, k0, k1, r);
+    pf = r[0] >= drop_threshold(d.path_p) ? 1.f / (1.f - d.path_p) : 0.f;
+  }
+  f32x4 s = {pf, pf, pf, pf};
+  if (d.p > 0.f) {
+    uint32_t r[4];
+    philox4x32_7((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.site, step, k0, k1, r);
+    const uint32_t thr = drop_threshold(d.p);
+    const float keep = pf / (1.f - d.p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = r[e] >= thr ? keep : 0.f;
+  }
+  return s;
+}
+
+// keep flag of ONE element (linear index idx) of an element-dropout site (token-side tensors, AlphaDropout)
+MT_DEVINL bool drop_keep1(const DropArgs& d, uint32_t site, uint64_t idx) {
+  uint32_t r[4];
+  philox4x32_7((uint32_t)(idx >> 2), (uint32_t)(idx >> 34), site, d.rng[2], d.rng[0], d.rng[1], r);
+  return r[idx & 3] >= drop_threshold(d.p);
+}
+
 // 16-byte global load/store helpers
 MT_DEVINL h16x8 ldg8(const h16* p) { return *reinterpret_cast<const h16x8*>(p); }
 MT_DEVINL void stg8(h16* p, h16x8 v) { *reinterpret_cast<h16x8*>(p) = v; }

@@ -26,6 +26,7 @@ struct GemmNtArgs {
   const float* colscale;
   const float* pos_table; const int* pos_row; const int* pos_col;
   void* C; long ldc; RowMap cmap;
+  DropArgs drop;          // BIAS_RESID: C = resid + drop(acc + bias)
 };
 
 // LDS-DMA staging (global_load_lds_dwordx4): each wave-instruction drops 64 x 16 B = 1 KiB = 8 tile rows of 128 B
@@ -84,7 +85,10 @@ MT_DEVINL void gemm_epilogue(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16][BN 
       if (m >= g.m_end || n >= g.N) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * CS + cc]);
       v += bias4;
-      if (EPI == MT_EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+      if (EPI == MT_EPI_BIAS_RESID) {
+        if (g.drop.active()) v *= drop_scale4(g.drop, ((uint64_t)m * g.N + n) >> 2, m);     // dropout / DropPath of the branch
+        v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
+      }
       if (EPI == MT_EPI_INJECT) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
 #pragma unroll
@@ -611,6 +615,8 @@ extern "C" int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, 
   a.colscale = epi ? epi->colscale : nullptr;
   a.pos_table = epi ? epi->pos_table : nullptr;
   a.pos_row = epi ? epi->pos_row : nullptr; a.pos_col = epi ? epi->pos_col : nullptr;
+  a.drop = make_drop(epi ? &epi->drop : nullptr);
+  if (a.drop.active() && epilogue != MT_EPI_BIAS_RESID) return MT_ERR_UNSUPPORTED;
   a.C = C; a.ldc = ldc; a.cmap = make_rowmap(cmap);
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = out_dtype == MT_OUT_F32;

@@ -24,7 +24,17 @@ struct GeneArgs {
   float* a1; float* a2;  // [G][latent] pre-activations (saved)
   float* z;              // [G][latent] forward output
   const float* dz;       // [G][latent]
+  DropArgs adrop;        // nn.AlphaDropout after each ELU (gene_encoder.py:178-181): sites adrop.site, adrop.site + 1
 };
+
+// AlphaDropout(p): kept values pass, dropped ones become alpha' = -selu_scale * selu_alpha; then the affine (a, b) that
+// restores zero mean / unit variance (torch.nn.functional.alpha_dropout)
+constexpr float ALPHA_P = -1.7580993408473766f;
+struct AlphaAff { float a, b; };
+MT_DEVINL AlphaAff alpha_affine(float p) {
+  const float a = rsqrtf((1.f - p) * (1.f + p * ALPHA_P * ALPHA_P));
+  return AlphaAff{a, -a * ALPHA_P * p};
+}
 
 // y[j] = bias[j] + sum_k W[j][k] x[k]  (thread j), W row-major [GL][n] streamed through LDS, x in LDS
 MT_DEVINL float gemv_rows(const float* __restrict__ W, int n, const float* xs, float (*Ws)[GC + 1], float acc) {
@@ -72,10 +82,16 @@ __global__ __launch_bounds__(GL) void gene_snn_fwd_kernel(GeneArgs a) {
   }
   a.a1[(long)i * GL + j] = acc;
   __syncthreads();
-  xs[j] = elu(acc);
+  const bool ad = a.adrop.active() && a.adrop.p > 0.f;
+  const AlphaAff af = alpha_affine(a.adrop.p);
+  float h1 = elu(acc);
+  if (ad) h1 = fmaf(af.a, drop_keep1(a.adrop, a.adrop.site, (uint64_t)i * GL + j) ? h1 : ALPHA_P, af.b);
+  xs[j] = h1;
   float acc2 = gemv_rows(a.params + o[2], GL, xs, Ws, a.params[o[3] + j]);
   a.a2[(long)i * GL + j] = acc2;
-  a.z[(long)i * GL + j] = elu(acc2);
+  float zz = elu(acc2);
+  if (ad) zz = fmaf(af.a, drop_keep1(a.adrop, a.adrop.site + 1, (uint64_t)i * GL + j) ? zz : ALPHA_P, af.b);
+  a.z[(long)i * GL + j] = zz;
 }
 
 __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
@@ -85,9 +101,14 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
   const int n = a.sizes[i];
   const long* o = a.offs + 4L * i;
   const float pre1 = a.a1[(long)i * GL + j], pre2 = a.a2[(long)i * GL + j];
-  const float da2 = a.dz[(long)i * GL + j] * elu_grad(pre2);
+  const bool ad = a.adrop.active() && a.adrop.p > 0.f;
+  const AlphaAff af = alpha_affine(a.adrop.p);
+  const bool keep1 = !ad || drop_keep1(a.adrop, a.adrop.site, (uint64_t)i * GL + j);
+  const bool keep2 = !ad || drop_keep1(a.adrop, a.adrop.site + 1, (uint64_t)i * GL + j);
+  const float g2 = ad ? (keep2 ? af.a : 0.f) : 1.f, g1 = ad ? (keep1 ? af.a : 0.f) : 1.f;
+  const float da2 = a.dz[(long)i * GL + j] * g2 * elu_grad(pre2);
   da2s[j] = da2;
-  h1s[j] = elu(pre1);
+  h1s[j] = ad ? fmaf(af.a, keep1 ? elu(pre1) : ALPHA_P, af.b) : elu(pre1);
   a.grads[o[3] + j] += da2;
   __syncthreads();
   // dW2[r][c] += da2[r] h1[c]: one wave per row, 16-byte accesses
@@ -111,7 +132,7 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
 #pragma unroll 8
     for (int r = 0; r < GC; ++r) dh1 = fmaf(Ws[r][j], da2s[r0 + r], dh1);
   }
-  const float da1 = dh1 * elu_grad(pre1);
+  const float da1 = dh1 * g1 * elu_grad(pre1);
   a.grads[o[1] + j] += da1;
   da1s[j] = da1;
   __syncthreads();
@@ -126,10 +147,10 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
 }  // namespace
 
 extern "C" int mt_gene_snn_fwd(const float* params, const long* offs, const int* sizes, const long* goff, const float* genes,
-                               int G, int latent, float* a1, float* a2, float* z, mt_stream_t stream) {
+                               int G, int latent, float* a1, float* a2, float* z, const MtDropout* alpha_drop, mt_stream_t stream) {
   if (!params || !offs || !sizes || !goff || !genes || !a1 || !a2 || !z || G < 1) return MT_ERR_BAD_ARG;
   if (latent != GL) return MT_ERR_UNSUPPORTED;
-  GeneArgs a{params, nullptr, offs, sizes, goff, genes, a1, a2, z, nullptr};
+  GeneArgs a{params, nullptr, offs, sizes, goff, genes, a1, a2, z, nullptr, make_drop(alpha_drop)};
   hipLaunchKernelGGL(gene_snn_fwd_kernel, dim3(G), dim3(GL), 0, (hipStream_t)stream, a);
   MT_CHECK_LAUNCH();
   return MT_OK;
@@ -137,10 +158,11 @@ extern "C" int mt_gene_snn_fwd(const float* params, const long* offs, const int*
 
 extern "C" int mt_gene_snn_bwd(const float* params, float* grads, const long* offs, const int* sizes, const long* goff,
                                const float* genes, int G, int latent, const float* a1, const float* a2, const float* dz,
-                               mt_stream_t stream) {
+                               const MtDropout* alpha_drop, mt_stream_t stream) {
   if (!params || !grads || !offs || !sizes || !goff || !genes || !a1 || !a2 || !dz || G < 1) return MT_ERR_BAD_ARG;
   if (latent != GL) return MT_ERR_UNSUPPORTED;
-  GeneArgs a{params, grads, offs, sizes, goff, genes, const_cast<float*>(a1), const_cast<float*>(a2), nullptr, dz};
+  GeneArgs a{params, grads, offs, sizes, goff, genes, const_cast<float*>(a1), const_cast<float*>(a2), nullptr, dz,
+             make_drop(alpha_drop)};
   hipLaunchKernelGGL(gene_snn_bwd_kernel, dim3(G), dim3(GL), 0, (hipStream_t)stream, a);
   MT_CHECK_LAUNCH();
   return MT_OK;

@@ -76,7 +76,7 @@ struct LnBwdArgs {
   const void* x; long ldx; RowMap xmap;
   const float* w; const float* stats;
   void* dx; long lddx; RowMap dxmap; int accumulate;
-  float* dw; float* db; h16* dx16; int M;
+  float* dw; float* db; h16* dx16; DropArgs drop16; int M;
 };
 
 template <int D, typename DyT, typename InT, typename DxT, bool GELU, bool PARAM>
@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
       }
       if (a.accumulate) { const f32x4 old = Vec4<DxT>::load(dx + col); o += old; }
       Vec4<DxT>::store(dx + col, o);
-      if (a.dx16) Vec4<h16>::store(a.dx16 + (long)m * D + col, o);
+      if (a.dx16) {
+        if (a.drop16.active()) o *= drop_scale4(a.drop16, ((uint64_t)m * D + col) >> 2, m);
+        Vec4<h16>::store(a.dx16 + (long)m * D + col, o);
+      }
     }
   }
   if (PARAM) {
@@ -359,6 +362,38 @@ int ln_bwd_launch(const LnBwdArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------- elementwise ---------------------
+__global__ void cast_drop_f32_f16_kernel(const float* x, h16* y, long n, DropArgs d, int D) {    // n % 4 == 0, D % 4 == 0
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    f32x4 v = Vec4<float>::load(x + i);
+    v *= drop_scale4(d, (uint64_t)i >> 2, (int)(i / D));
+    Vec4<h16>::store(y + i, v);
+  }
+}
+// y(m,:) = drop(x(xmap(m),:)), dense fp32 y
+__global__ void dropout_f32_kernel(const float* x, long ldx, RowMap xmap, float* y, int M, int D, DropArgs d) {
+  const int per_row = D / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * per_row; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / per_row), c = (int)(i % per_row) * 4;
+    f32x4 v = Vec4<float>::load(x + xmap.map(m) * ldx + c);
+    v *= drop_scale4(d, ((uint64_t)m * D + c) >> 2, m);
+    Vec4<float>::store(y + (long)m * D + c, v);
+  }
+}
+__global__ void droppath_rows_kernel(float* x, int M, int D, DropArgs d) {
+  const int per_row = D / 4;
+  DropArgs dd = d;
+  dd.p = 0.f;                           // path factor only
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * per_row; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / per_row), c = (int)(i % per_row) * 4;
+    f32x4 v = Vec4<float>::load(x + (long)m * D + c);
+    v *= drop_scale4(dd, 0, m);
+    Vec4<float>::store(x + (long)m * D + c, v);
+  }
+}
+__global__ void rng_advance_kernel(uint32_t* rng) { if (threadIdx.x == 0 && blockIdx.x == 0) rng[2] += 1u; }
+
 __global__ void cast_f32_f16_kernel(const float* x, h16* y, long n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * blockDim.x * 4;
@@ -517,11 +552,12 @@ static int ln_bwd_types(const LnBwdArgs& a, int dy_dt, int in_dt, int dx_dt, int
 extern "C" int mt_layernorm_bwd(const void* dy, long lddy, const MtRowMap* dymap, int dy_dtype, const void* x,
                                 long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w,
                                 const float* stats, void* dx, long lddx, const MtRowMap* dxmap, int dx_dtype,
-                                int accumulate, float* dw, float* db, mt_half* dx_f16, int M, int D, mt_stream_t stream) {
+                                int accumulate, float* dw, float* db, mt_half* dx_f16, const MtDropout* dx_f16_drop, int M,
+                                int D, mt_stream_t stream) {
   if (!dy || !x || !w || !stats || !dx || M <= 0 || (!dw) != (!db)) return MT_ERR_BAD_ARG;
   if (dx_f16 && gelu_in) return MT_ERR_UNSUPPORTED;
   LnBwdArgs a{dy, lddy, make_rowmap(dymap), x, ldx, make_rowmap(xmap), w, stats, dx, lddx, make_rowmap(dxmap), accumulate, dw, db,
-              (h16*)dx_f16, M};
+              (h16*)dx_f16, make_drop(dx_f16 ? dx_f16_drop : nullptr), M};
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
     case 256: return ln_bwd_types<256>(a, dy_dtype, in_dtype, dx_dtype, gelu_in, s);
@@ -532,9 +568,37 @@ extern "C" int mt_layernorm_bwd(const void* dy, long lddy, const MtRowMap* dymap
   }
 }
 
-extern "C" int mt_cast_f32_to_f16(const float* x, mt_half* y, long n, mt_stream_t stream) {
+extern "C" int mt_cast_f32_to_f16(const float* x, mt_half* y, long n, const MtDropout* drop, int D, mt_stream_t stream) {
   if (!x || !y || n <= 0) return MT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (h16*)y, n);
+  const DropArgs d = make_drop(drop);
+  if (d.active()) {
+    if ((n & 3) || D <= 0 || (D & 3)) return MT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_drop_f32_f16_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (h16*)y, n, d, D);
+  } else {
+    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (h16*)y, n);
+  }
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_rng_advance(unsigned* rng, mt_stream_t stream) {
+  if (!rng) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_dropout_f32(const float* x, long ldx, const MtRowMap* xmap, float* y, int M, int D, const MtDropout* drop,
+                              mt_stream_t stream) {
+  if (!x || !y || M <= 0 || D <= 0 || (D & 3) || (ldx & 3)) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(ew_grid((long)M * D / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     make_rowmap(xmap), y, M, D, make_drop(drop));
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_droppath_rows_f32(float* x, int M, int D, const MtDropout* drop, mt_stream_t stream) {
+  if (!x || M <= 0 || D <= 0 || (D & 3)) return MT_ERR_BAD_ARG;
+  const DropArgs d = make_drop(drop);
+  if (!d.active() || d.path_p <= 0.f) return MT_OK;
+  hipLaunchKernelGGL(droppath_rows_kernel, dim3(ew_grid((long)M * D / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, M, D, d);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -131,6 +131,33 @@ class Engine:
         self._gene_sizes = torch.tensor(self.group_sizes, dtype=torch.int32, device=self.device)
         self._gene_goff = torch.from_numpy(goff).to(self.device)
         self._gene_total = int(sum(self.group_sizes))
+        # train-mode stochastic ops (fact 3 of the survey: the frozen backbone stays in train mode): counter-based masks
+        # from a device-side {seed_lo, seed_hi, step, 0}; off by default (parity is defined at p = 0)
+        self.stochastic = False
+        self.rng = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._drop_now = False
+        self._fresh_calls, self._site_base = 0, 0
+        dpr = np.linspace(0.0, float(cfg.drop_path_rate), cfg.depth) if cfg.depth > 1 else np.zeros(1)
+        self._layer_path_p = [float(v) for v in dpr]          # ENC:37-41
+
+    def set_stochastic(self, on: bool, seed: int = 0):
+        """Dropout(cfg.dropout) on the embedded input and after out_proj / fc2, per-layer DropPath on both backbone
+        branches, DropPath on the Extractor FFN branch -- as model.train() leaves them in the reference."""
+        self.stochastic = bool(on)
+        self.rng.copy_(torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF, 0, 0], dtype=torch.int32))
+
+    def _drop(self, site: int, p: float, path_site: int = 0, path_p: float = 0.0, rows_per_pass: int = 1):
+        if not self._drop_now or (p <= 0.0 and path_p <= 0.0):
+            return None
+        off = self._site_base          # distinct masks for every forward call that owns its tape (module-style loops)
+        return ops.dropout_spec(self.rng, site + off, p, path_site + off, path_p, rows_per_pass)
+
+    def _layer_drops(self, l: int, N: int):
+        """(attention branch, FFN branch) masks of backbone layer l (ENC:149-152, FFN:142 + ENC:169-170)."""
+        if l < 0:
+            return None, None
+        p, pp = float(self.cfg.dropout), self._layer_path_p[l]
+        return (self._drop(16 + 4 * l, p, 17 + 4 * l, pp, N), self._drop(18 + 4 * l, p, 19 + 4 * l, pp, N))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
@@ -192,6 +219,8 @@ class Engine:
         w: Dict[str, torch.Tensor] = {}
         w["x16"] = e16(L, cfg.in_chans)
         w["x0"] = e32(L, D)
+        if self.stochastic:
+            w["x0d"] = e32(B * L, D)          # per-pass input dropout (ENC:339) of the shared patch embedding
         w["prow"] = torch.empty(L, dtype=torch.int32, device=dev)
         w["pcol"] = torch.empty(L, dtype=torch.int32, device=dev)
         nint = len(cfg.interaction_indexes)
@@ -251,6 +280,11 @@ class Engine:
         tape = self.tape
         tape.reset()
         tape.grad_enabled = need_grad
+        self._drop_now = bool(self.stochastic and need_grad)
+        self._ext_calls = 0
+        if fresh and self._drop_now:     # several forwards may precede one backward (TM:175-177): the masks of a call are
+            self._fresh_calls += 1       # tied to the call, not to the device step counter alone
+        self._site_base = 4096 * (self._fresh_calls & 0xFFFFF) if fresh else 0
         self._ctx = dict(B=B, L=L, N=N, M=M, Mp=Mp, ws=ws)
         plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
         self._ctx["plan"] = plan
@@ -272,6 +306,12 @@ class Engine:
         # ---- interaction blocks (LVA:294-307, AM:484-523)
         nint = len(cfg.interaction_indexes)
         src, src_map = ws["x0"], rowmap(L, 0, 0)      # injector 0 reads the shared patch embedding (broadcast)
+        d_in = self._drop(1, float(cfg.dropout), rows_per_pass=L)
+        if d_in is not None:                          # Encoder.prepare_forward's Dropout: one mask per task pass
+            if "x0d" not in ws:
+                ws["x0d"] = torch.empty(B * L, D, dtype=F32, device=dev)
+            ops.dropout_f32(ws["x0"], ws["x0d"], B * L, D, d_in, xmap=rowmap(L, 0, 0))
+            src, src_map = ws["x0d"], rowmap(L, L, 0)
         for i, (la, lb) in enumerate(cfg.interaction_indexes):
             if i > 0 and cfg.use_prompt_sa:
                 c = self._prompt_self_attention(c, pe, f"prompt_selfattention.{i}.")
@@ -336,24 +376,32 @@ class Engine:
         z = Var(tape.new(1, G, g.latent_dim))
         a1, a2 = tape.new(G, g.latent_dim), tape.new(G, g.latent_dim)
         st = self.store
-        ops.gene_snn_fwd(st.flat, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim, a1, a2, z.data)
+        # train mode: AlphaDropout after each ELU (GE:178-181).  The gene encoder runs once per slide here and is shared by the
+        # task passes, so its masks are shared too (the reference redraws them in each of its three forward calls).
+        gp = float(g.dropout)
+        adrop = self._drop(300, gp)
+        ops.gene_snn_fwd(st.flat, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim, a1, a2, z.data,
+                         alpha_drop=adrop)
         z0 = z          # (closures bind late: `z` is rebound by the mixer loop below)
 
         def bwd_networks():
             if z0.grad is None:
                 return
             ops.gene_snn_bwd(st.flat, st.flat_grad, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim,
-                             a1, a2, z0.grad)
+                             a1, a2, z0.grad, alpha_drop=adrop)
         tape.record(bwd_networks)
         for k in range(g.depth):
             p = f"gene_encoder.mlp_mixer.{k}."
             n1 = tape.layernorm(z, P(p + "0.norm.weight"), P(p + "0.norm.bias"))
-            m1 = tape.axis_linear(n1, P(p + "0.fn.0.weight"), P(p + "0.fn.0.bias"), act=ops.ACT_GELU)
-            m2 = tape.axis_linear(m1, P(p + "0.fn.3.weight"), P(p + "0.fn.3.bias"))
+            # FeedForward = dense, GELU, Dropout, dense, Dropout (GE:184-192)
+            m1 = tape.dropout(tape.axis_linear(n1, P(p + "0.fn.0.weight"), P(p + "0.fn.0.bias"), act=ops.ACT_GELU),
+                              self._drop(310 + 4 * k, gp))
+            m2 = tape.dropout(tape.axis_linear(m1, P(p + "0.fn.3.weight"), P(p + "0.fn.3.bias")), self._drop(311 + 4 * k, gp))
             z = tape.add(z, m2)
             n2 = tape.layernorm(z, P(p + "1.norm.weight"), P(p + "1.norm.bias"))
-            f1 = tape.linear(n2, P(p + "1.fn.0.weight"), P(p + "1.fn.0.bias"), act=ops.ACT_GELU)
-            f2 = tape.linear(f1, P(p + "1.fn.3.weight"), P(p + "1.fn.3.bias"))
+            f1 = tape.dropout(tape.linear(n2, P(p + "1.fn.0.weight"), P(p + "1.fn.0.bias"), act=ops.ACT_GELU),
+                              self._drop(312 + 4 * k, gp))
+            f2 = tape.dropout(tape.linear(f1, P(p + "1.fn.3.weight"), P(p + "1.fn.3.bias")), self._drop(313 + 4 * k, gp))
             z = tape.add(z, f2)
         p = "gene_encoder.mlp_mixer."
         z = tape.layernorm(z, P(p + f"{g.depth}.weight"), P(p + f"{g.depth}.bias"))
@@ -497,20 +545,24 @@ class Engine:
                                                   ws[f"lsetot{l}"], ws[f"a1_{l}"])
         st1, stin, st2, stf = ws[f"st1_{l}"], ws[f"stin_{l}"], ws[f"st2_{l}"], ws[f"stf_{l}"]
         u16, t16 = ws["u16"], ws["t16"]
+        N_tok = ctx["N"]
+        d_attn, d_ffn = self._layer_drops(l, N_tok)
         ops.layernorm_fwd(hin, t[p + "self_attn_layer_norm.weight"], t[p + "self_attn_layer_norm.bias"], u16, st1, M, D)
         ops.gemm_nt(u16, f16[p + "qkv"].w, qkv, M, 3 * D, D, bias=f16[p + "bqkv"], epilogue=ops.EPI_QKV_HM)   # head-major q|k|v
         ops.dilated_attn_fwd(qkv, plan, obr, lsebr)
         ops.dilated_mix_ln_fwd(obr, lsebr, plan, t[p + "self_attn.inner_attn_ln.weight"], t[p + "self_attn.inner_attn_ln.bias"],
                                u16, stin, lsetot)
         ops.gemm_nt(u16, f16[p + "out"].w, hmid, M, D, D, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "self_attn.out_proj.bias"],
-                    resid=hin, ldr=D)
+                    resid=hin, ldr=D, drop=d_attn)
         ops.layernorm_fwd(hmid, t[p + "final_layer_norm.weight"], t[p + "final_layer_norm.bias"], u16, st2, M, D)
         ops.gemm_nt(u16, f16[p + "fc1"].w, a1, M, Fd, D, bias=t[p + "ffn.fc1.bias"])
         ops.layernorm_fwd(a1, t[p + "ffn.ffn_layernorm.weight"], t[p + "ffn.ffn_layernorm.bias"], t16, stf, M, Fd, gelu_in=True)
-        ops.gemm_nt(t16, f16[p + "fc2"].w, out, M, D, Fd, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "ffn.fc2.bias"], resid=hmid, ldr=D)
+        ops.gemm_nt(t16, f16[p + "fc2"].w, out, M, D, Fd, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "ffn.fc2.bias"], resid=hmid, ldr=D,
+                    drop=d_ffn)
 
         # nothing else touches dh between two layers of one interaction block: the lower layer can take fp16(dh) from here
         feeds_lower = all(l != a for a, _ in cfg.interaction_indexes)
+        d_lower_ffn = self._layer_drops(l - 1, N_tok)[1] if feeds_lower else None
 
         def bwd():
             dh, dy16, dt16, da1 = ws["dh"], ws["dy16"], ws["dt16"], ws["da1"]
@@ -518,19 +570,20 @@ class Engine:
             if ctx.get("dh16_valid"):             # the layer above left fp16(dh) behind (LN backward's second output)
                 src16 = ws["dh16"]
             else:
-                ops.cast_f32_to_f16(dh, dy16)
+                ops.cast_f32_to_f16(dh, dy16, drop=d_ffn, D=D)        # gradient of the (dropped) FFN branch output
                 src16 = dy16
             ops.gemm_nt(src16, f16[p + "fc2"].wt, dt16, M, Fd, D)
             ops.layernorm_bwd(dt16, a1, t[p + "ffn.ffn_layernorm.weight"], stf, da1, M, Fd, gelu_in=True)
             ops.gemm_nt(da1, f16[p + "fc1"].wt, dy16, M, D, Fd)
-            ops.layernorm_bwd(dy16, hmid, t[p + "final_layer_norm.weight"], st2, dh, M, D, accumulate=True, dx16=ws["dh16"])
+            ops.layernorm_bwd(dy16, hmid, t[p + "final_layer_norm.weight"], st2, dh, M, D, accumulate=True, dx16=ws["dh16"],
+                              dx16_drop=d_attn)
             # attention: hmid = hin + out_proj(LN(mix(dilated(qkv(LN(hin))))))
             ops.gemm_nt(ws["dh16"], f16[p + "out"].wt, u16, M, D, D)
             ops.dilated_mix_ln_bwd(u16, obr, lsebr, lsetot, plan, t[p + "self_attn.inner_attn_ln.weight"], stin, ws["dmixed"], ws["delta"])
             ops.dilated_attn_bwd(qkv, ws["dmixed"], lsetot, ws["delta"], plan, ws["attn_ws"], ws["dqkv16"])
             ops.gemm_nt(ws["dqkv16"], f16[p + "qkv"].wt, dy16, M, D, 3 * D)
             ops.layernorm_bwd(dy16, hin, t[p + "self_attn_layer_norm.weight"], st1, dh, M, D, accumulate=True,
-                              dx16=ws["dh16"] if feeds_lower else None)
+                              dx16=ws["dh16"] if feeds_lower else None, dx16_drop=d_lower_ffn if feeds_lower else None)
             ctx["dh16_valid"] = feeds_lower
         self.tape.record(bwd)
 
@@ -579,6 +632,16 @@ class Engine:
         tn = tape.layernorm(c1, P(fp + "norm.weight"), P(fp + "norm.bias"))
         f = tape.linear(tape.linear(tn, P(fp + "linear1.weight"), P(fp + "linear1.bias"), act=ops.ACT_RELU),
                         P(fp + "linear2.weight"), P(fp + "linear2.bias"))
+        # query + drop_path(ffn(query)) (AM:319,327): one Bernoulli per task pass
+        self._ext_calls = getattr(self, "_ext_calls", 0) + 1
+        d_path = self._drop(0, 0.0, 200 + self._ext_calls, float(cfg.drop_path_rate), T)
+        if d_path is not None:
+            ops.droppath_rows(f.data, B * T, D, d_path)          # in place (linear backward does not read its own output)
+
+            def bwd_path():
+                if f.grad is not None:
+                    ops.droppath_rows(f.grad, B * T, D, d_path)
+            tape.record(bwd_path)
         return tape.add(c1, f)
 
     # ------------------------------------------------------------------ fusion head (LVA:309-347)

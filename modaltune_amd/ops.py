@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import MtDilatedPlan, MtGemmEpilogue, MtRowMap, check, rowmap
+from ._lib import MtDilatedPlan, MtDropout, MtGemmEpilogue, MtRowMap, check, rowmap
 
 F16, F32 = 0, 1
 EPI_BIAS, EPI_BIAS_RESID, EPI_INJECT, EPI_POSEMB, EPI_QKV_HM = 0, 1, 2, 3, 4
@@ -52,10 +52,23 @@ def make_plan(branches, N: int, B: int) -> MtDilatedPlan:
     return p
 
 
+def dropout_spec(rng, site=0, p=0.0, path_site=0, path_p=0.0, rows_per_pass=1) -> MtDropout:
+    """MtDropout for one stochastic site (rng: device uint32[4] tensor {seed_lo, seed_hi, step, 0})."""
+    d = MtDropout()
+    d.rng, d.site, d.p, d.path_site, d.path_p, d.rows_per_pass = rng.data_ptr(), site, p, path_site, path_p, rows_per_pass
+    return d
+
+
+def _dr(d):
+    return C.byref(d) if d is not None else None
+
+
 def gemm_nt(A, W, out, M, N, K, *, lda=None, amap=None, ldc=None, cmap=None, epilogue=EPI_BIAS, bias=None, resid=None,
-            ldr=0, rmap=None, colscale=None, pos_table=None, pos_row=None, pos_col=None):
+            ldr=0, rmap=None, colscale=None, pos_table=None, pos_row=None, pos_col=None, drop=None):
     """out = epilogue(A[M,K] @ W[N,K]^T) (include/modaltune_hip.h: mt_gemm_nt_f16)."""
     epi = MtGemmEpilogue()
+    if drop is not None:
+        epi.drop = drop
     epi.bias, epi.resid, epi.ldr = (bias.data_ptr() if bias is not None else None,
                                     resid.data_ptr() if resid is not None else None, ldr)
     if rmap is not None:
@@ -95,11 +108,11 @@ def layernorm_fwd(x, w, b, y, stats, M, D, *, ldx=None, xmap=None, ldy=None, yma
 
 
 def layernorm_bwd(dy, x, w, stats, dx, M, D, *, lddy=None, dymap=None, ldx=None, xmap=None, lddx=None, dxmap=None,
-                  gelu_in=False, accumulate=False, dw=None, db=None, dx16=None):
+                  gelu_in=False, accumulate=False, dw=None, db=None, dx16=None, dx16_drop=None):
     check(_lib.load().mt_layernorm_bwd(_p(dy), lddy if lddy is not None else D, _rm(dymap), _dt(dy), _p(x),
                                        ldx if ldx is not None else D, _rm(xmap), _dt(x), int(gelu_in), _p(w), _p(stats),
                                        _p(dx), lddx if lddx is not None else D, _rm(dxmap), _dt(dx), int(accumulate),
-                                       _p(dw), _p(db), _p(dx16), M, D, _s()), "layernorm_bwd")
+                                       _p(dw), _p(db), _p(dx16), _dr(dx16_drop), M, D, _s()), "layernorm_bwd")
 
 
 def dilated_attn_fwd(qkv, plan, o_br, lse_br):
@@ -142,14 +155,14 @@ def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
         TIMER.setdefault(name, []).append((e0, e1))
 
 
-def gene_snn_fwd(params, offs, sizes, goff, genes, G, latent, a1, a2, z):
+def gene_snn_fwd(params, offs, sizes, goff, genes, G, latent, a1, a2, z, alpha_drop=None):
     check(_lib.load().mt_gene_snn_fwd(_p(params), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, _p(a1), _p(a2), _p(z),
-                                      _s()), "gene_snn_fwd")
+                                      _dr(alpha_drop), _s()), "gene_snn_fwd")
 
 
-def gene_snn_bwd(params, grads, offs, sizes, goff, genes, G, latent, a1, a2, dz):
+def gene_snn_bwd(params, grads, offs, sizes, goff, genes, G, latent, a1, a2, dz, alpha_drop=None):
     check(_lib.load().mt_gene_snn_bwd(_p(params), _p(grads), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, _p(a1),
-                                      _p(a2), _p(dz), _s()), "gene_snn_bwd")
+                                      _p(a2), _p(dz), _dr(alpha_drop), _s()), "gene_snn_bwd")
 
 
 def inject_attn_fwd(q, k, v, a, M, rows_per_pass, T, lse=None):
@@ -180,8 +193,20 @@ def token_mha_bwd(q, k, v, probs, dout, dq, dk, dv, B, T, E, heads):
                                        _s()), "token_mha_bwd")
 
 
-def cast_f32_to_f16(x, y, n=None):
-    check(_lib.load().mt_cast_f32_to_f16(_p(x), _p(y), n if n is not None else x.numel(), _s()), "cast")
+def cast_f32_to_f16(x, y, n=None, drop=None, D=0):
+    check(_lib.load().mt_cast_f32_to_f16(_p(x), _p(y), n if n is not None else x.numel(), _dr(drop), D, _s()), "cast")
+
+
+def rng_advance(rng):
+    check(_lib.load().mt_rng_advance(_p(rng), _s()), "rng_advance")
+
+
+def dropout_f32(x, y, M, D, drop, *, ldx=None, xmap=None):
+    check(_lib.load().mt_dropout_f32(_p(x), ldx if ldx is not None else D, _rm(xmap), _p(y), M, D, _dr(drop), _s()), "dropout")
+
+
+def droppath_rows(x, M, D, drop):
+    check(_lib.load().mt_droppath_rows_f32(_p(x), M, D, _dr(drop), _s()), "droppath_rows")
 
 
 def cast_f16_to_f32(x, y, n=None):

@@ -98,6 +98,23 @@ class Tape:
         self.record(bwd)
         return y
 
+    def dropout(self, x: Var, spec) -> Var:
+        """y = Dropout(x) with a counter-based mask (ops.dropout_spec); spec None = identity.  x dense [..., D], D % 4 == 0."""
+        if spec is None:
+            return x
+        D, R = x.cols, x.rows
+        y = Var(self.new(*x.data.shape))
+        ops.dropout_f32(x.data, y.data, R, D, spec)
+
+        def bwd():
+            if y.grad is None or not x.needs_grad:
+                return
+            tmp = self.new(*x.data.shape)
+            ops.dropout_f32(y.grad, tmp, R, D, spec)          # the same mask, regenerated
+            ops.axpy(x.g(), tmp, 1.0, x.g())
+        self.record(bwd)
+        return y
+
     def _colsum(self, dy, R, N, out):
         assert R <= self._ones.numel()
         ops.sgemm(dy, (1, N), self._ones, (0, 1), out, (1, 1), N, 1, R, accumulate=True)

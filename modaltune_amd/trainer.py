@@ -68,6 +68,8 @@ class TrainStep:
     def step(self, x, coords, genes, text, update: bool = True, clinical=None) -> torch.Tensor:
         """One train step on one slide.  Returns the (device) loss scalar; no host sync happens here."""
         eng = self.engine
+        if eng.stochastic:
+            ops.rng_advance(eng.rng)          # a fresh set of dropout / DropPath masks per step
         target = self.project_text(text)
         eng.store.flat_grad.zero_()
         logits = eng.forward(x, coords, genes, self.onehots, need_grad=True, clinical=clinical)
@@ -105,6 +107,8 @@ class TrainStep:
         world = torch.distributed.get_world_size(self.pg) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
 
         def fwd_bwd():
+            if eng.stochastic:
+                ops.rng_advance(eng.rng)
             target = self.project_text(self._stext)
             eng.store.flat_grad.zero_()
             logits = eng.forward(None, None, self._sgenes, self.onehots, need_grad=True, staged=True, geometry=(B, L),

@@ -612,3 +612,127 @@ def test_gene_encoder_331_pathways_vs_reference_golden(ops, golden_dir):
     y = eng._gene_encoder(genes)
     torch.cuda.synchronize()
     assert rel(y.data, torch.from_numpy(g["y"])) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ train-mode stochastic ops
+def _rng(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_dropout_masks_statistics_determinism_and_consistency(ops):
+    """Counter-based Dropout / DropPath masks: rates and scales, determinism in (seed, step, site), and the SAME mask
+    from every kernel that applies a site (GEMM epilogue forward; LayerNorm-backward fp16 copy and cast in backward)."""
+    M, D, rpp = 3000, 768, 1000
+    rng = torch.tensor([123, 456, 7, 0], dtype=torch.int32, device=DEV)
+    p, pp = 0.25, 0.3
+    spec = ops.dropout_spec(rng, 40, p, 41, pp, rpp)
+    ones = torch.ones(M, D, device=DEV)
+    mask = torch.zeros(M, D, device=DEV)
+    ops.dropout_f32(ones, mask, M, D, spec)
+    torch.cuda.synchronize()
+    m = mask.cpu()
+    for b in range(M // rpp):
+        blk = m[b * rpp:(b + 1) * rpp]
+        vals = torch.unique(blk)
+        assert len(vals) <= 2 and float(vals.min()) == 0.0
+        if float(vals.max()) > 0:       # kept pass: scale 1 / ((1-p)(1-pp)), element keep rate 1 - p
+            assert abs(float(vals.max()) - 1.0 / ((1 - p) * (1 - pp))) < 1e-5
+            assert abs(float((blk > 0).float().mean()) - (1 - p)) < 5e-3
+    mask2 = torch.zeros_like(mask)
+    ops.dropout_f32(ones, mask2, M, D, spec)
+    assert torch.equal(mask, mask2)                          # same (seed, step, site) -> same mask
+    ops.rng_advance(rng)
+    ops.dropout_f32(ones, mask2, M, D, spec)
+    torch.cuda.synchronize()
+    assert int(rng[2]) == 8 and not torch.equal(mask, mask2)     # next step -> new mask
+    rng[2] = 7
+    other = torch.zeros_like(mask)
+    ops.dropout_f32(ones, other, M, D, ops.dropout_spec(rng, 44, p, 45, pp, rpp))
+    assert not torch.equal(mask, other)                      # another site -> another mask
+    # GEMM epilogue: resid + drop(A W^T + bias)
+    gen = _rng(5)
+    K = 64
+    A = torch.randn(M, K, generator=gen).half().to(DEV)
+    W = (torch.randn(D, K, generator=gen) * 0.1).half().to(DEV)
+    bias = torch.randn(D, generator=gen).to(DEV)
+    resid = torch.randn(M, D, generator=gen).to(DEV)
+    plain = torch.zeros(M, D, device=DEV)
+    ops.gemm_nt(A, W, plain, M, D, K, bias=bias)
+    dropped = torch.zeros(M, D, device=DEV)
+    ops.gemm_nt(A, W, dropped, M, D, K, epilogue=ops.EPI_BIAS_RESID, bias=bias, resid=resid, ldr=D, drop=spec)
+    torch.cuda.synchronize()
+    assert rel(dropped, resid + plain * mask) < 1e-6
+    # backward producers of the masked fp16 gradient: cast and the LayerNorm-backward second output
+    gsrc = torch.randn(M, D, generator=gen).to(DEV)
+    c16 = torch.zeros(M, D, dtype=torch.float16, device=DEV)
+    ops.cast_f32_to_f16(gsrc, c16, drop=spec, D=D)
+    torch.cuda.synchronize()
+    assert torch.equal(c16, (gsrc * mask).half())
+    x = torch.randn(M, D, generator=gen).to(DEV)
+    w = (1 + 0.1 * torch.randn(D, generator=gen)).to(DEV)
+    y = torch.zeros(M, D, dtype=torch.float16, device=DEV)
+    st = torch.zeros(M, 2, device=DEV)
+    ops.layernorm_fwd(x, w, torch.zeros(D, device=DEV), y, st, M, D)
+    dy = torch.randn(M, D, generator=gen).half().to(DEV)
+    acc_a, acc_b = torch.zeros(M, D, device=DEV), torch.zeros(M, D, device=DEV)
+    d16_plain = torch.zeros(M, D, dtype=torch.float16, device=DEV)
+    d16_drop = torch.zeros(M, D, dtype=torch.float16, device=DEV)
+    ops.layernorm_bwd(dy, x, w, st, acc_a, M, D, accumulate=True, dx16=d16_plain)
+    ops.layernorm_bwd(dy, x, w, st, acc_b, M, D, accumulate=True, dx16=d16_drop, dx16_drop=spec)
+    torch.cuda.synchronize()
+    assert torch.equal(acc_a, acc_b)                         # the fp32 stream is not masked
+    assert torch.equal(d16_drop, (acc_b * mask).half())
+
+
+def test_gene_snn_alpha_dropout(ops):
+    """nn.AlphaDropout(p) after the pathway ELUs: dropped units take the constant a * alpha' + b, kept ones a * elu + b;
+    the backward regenerates the same masks (gradient of a kept unit = a * upstream, of a dropped one = 0)."""
+    G, Lt, n = 40, 256, 9
+    gen = _rng(11)
+    sizes = [n] * G
+    W1 = torch.randn(G, Lt, n, generator=gen) * 0.3
+    b1 = torch.randn(G, Lt, generator=gen) * 0.1
+    W2 = torch.randn(G, Lt, Lt, generator=gen) * 0.06
+    b2 = torch.randn(G, Lt, generator=gen) * 0.1
+    pieces, offs, cur = [], [], 0
+    for i in range(G):
+        row = []
+        for tns in (W1[i], b1[i], W2[i], b2[i]):
+            row.append(cur)
+            pieces.append(tns.reshape(-1))
+            pad = (-tns.numel()) % 4
+            if pad:
+                pieces.append(torch.zeros(pad))
+            cur += tns.numel() + pad
+        offs.append(row)
+    flat = torch.cat(pieces).to(DEV)
+    genes = torch.randn(G * n, generator=gen).to(DEV)
+    goff = torch.arange(G, dtype=torch.int64, device=DEV) * n
+    t_offs = torch.tensor(offs, dtype=torch.int64, device=DEV)
+    t_sizes = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+    rs = torch.tensor([9, 8, 3, 0], dtype=torch.int32, device=DEV)
+    p = 0.25
+    spec = ops.dropout_spec(rs, 300, p)
+    a1, a2, z, z0 = (torch.zeros(G, Lt, device=DEV) for _ in range(4))
+    ops.gene_snn_fwd(flat, t_offs, t_sizes, goff, genes, G, Lt, a1, a2, z0)
+    ops.gene_snn_fwd(flat, t_offs, t_sizes, goff, genes, G, Lt, a1, a2, z, alpha_drop=spec)
+    torch.cuda.synchronize()
+    alpha_p = -1.7580993408473766
+    a = ((1 - p) * (1 + p * alpha_p ** 2)) ** -0.5
+    b = -a * alpha_p * p
+    dropped = (z - (a * alpha_p + b)).abs() < 1e-6
+    assert abs(float(dropped.float().mean()) - p) < 0.02
+    # kept units of the second layer: a * elu(a2) + b with a2 computed from the (dropped) first layer
+    kept = ~dropped
+    assert rel(z[kept], a * torch.nn.functional.elu(a2[kept]) + b) < 1e-6
+    assert not torch.allclose(z, z0)
+    dz = torch.randn(G, Lt, generator=gen).to(DEV)
+    grads = torch.zeros_like(flat)
+    ops.gene_snn_bwd(flat, grads, t_offs, t_sizes, goff, genes, G, Lt, a1, a2, dz, alpha_drop=spec)
+    torch.cuda.synchronize()
+    # db2 = dz * a * keep2 * elu'(a2)
+    for i in (0, 17, 39):
+        db2 = grads[offs[i][3]:offs[i][3] + Lt]
+        pre = a2[i]
+        want = dz[i] * a * kept[i].float() * torch.where(pre > 0, torch.ones_like(pre), torch.exp(pre))
+        assert rel(db2, want) < 1e-5

@@ -111,8 +111,8 @@ def test_nn_module_dropin_api_matches_reference_golden(golden_dir):
                     num_heads=12, output_dim=256, init_values=0.0, geneclass_name="gene_mixer_group", with_cffn=True,
                     cffn_ratio=0.25, add_prompt_feature=True, use_extra_extractor=True, freeze_vit=True, with_cp=False,
                     use_prompt_sa=True, prompt_dropout=0.0, prompt_agg="avg", token_agg="sum", pretrained=False,
-                    dropout=0.25, drop_path_rate=0.1, mlp_ratio=4, global_pool=False, tile_size=256, max_wsi_size=262144,
-                    clinfeat_dim=5)
+                    dropout=0.0, drop_path_rate=0.0, mlp_ratio=4, global_pool=False, tile_size=256, max_wsi_size=262144,
+                    clinfeat_dim=5)        # (parity configuration: the stochastic ops are defined only at p = 0)
     model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, **json_cfg, multi_task=3).to("cuda")
     assert model.is_multi
     cfg = ModelConfig.from_json(json_cfg, multi_task=3)
@@ -295,3 +295,45 @@ def test_full_size_properties_L10000():
     lg = [float(ts2.step_graphed(x, inp["coords"], genes, text)) for _ in range(4)]
     assert ts2._graphs is not None
     assert all(abs(v - loss0) < 2e-4 * abs(loss0) for v in lg), (lg, loss0)
+
+
+def test_train_mode_stochastic_step_gradient_is_consistent(golden_dir):
+    """Dropout / DropPath on (Engine.set_stochastic): with the step counter pinned the masks repeat, the step is
+    deterministic, and the analytic gradient predicts the loss change along itself (i.e. forward and backward apply the
+    same masks); a different step draws different masks; need_grad=False (eval) ignores them."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(golden_dir, "model_L1500_d3.npz")
+    g, cfg, eng, ts, inp = _build(path)
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"]).cuda()
+    base_loss = float(ts.step(x, inp["coords"], genes, text, update=False))
+    eng.set_stochastic(True, seed=1234)
+
+    def run(step_no):
+        eng.rng[2] = step_no - 1                 # TrainStep.step advances the counter first
+        return float(ts.step(x, inp["coords"], genes, text, update=False))
+    l5 = run(5)
+    grad = eng.store.flat_grad.clone() / float(ts.scale)
+    assert run(5) == l5                                                                  # same masks, same step
+    g2 = eng.store.flat_grad / float(ts.scale)           # (fp32-atomic reductions: equal to rounding, not bitwise)
+    assert float((grad - g2).norm()) < 1e-4 * float(grad.norm())
+    l6 = run(6)
+    assert l6 != l5 and abs(l5 - base_loss) > 1e-6                                       # masks matter and change
+    gn = float(grad.norm())
+    base = eng.store.flat.clone()
+    eps = 2e-2 * l5 / gn
+    vals = []
+    for sgn in (+1.0, -1.0):
+        eng.store.flat.copy_(base + sgn * eps * grad / gn)
+        eng.refresh_trainable_caches()
+        vals.append(run(5))
+    eng.store.flat.copy_(base)
+    eng.refresh_trainable_caches()
+    assert abs((vals[0] - vals[1]) / (2 * eps) / gn - 1.0) < 0.05, (vals, l5, gn)
+    # eval path: no masks
+    oh = torch.eye(3, device="cuda")
+    with torch.no_grad():
+        ev = eng.forward(x, inp["coords"], genes, oh, need_grad=False)
+    assert _rel(ev.cpu().numpy(), g["f64_logits"]) < 1e-3
