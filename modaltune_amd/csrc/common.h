@@ -97,25 +97,28 @@ MT_DEVINL void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 MT_DEVINL uint32_t drop_threshold(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f); }
-// scale factors of the 4 consecutive elements whose linear index starts at 4 * idx4, in row m of the activation
-MT_DEVINL f32x4 drop_scale4(const DropArgs& d, uint64_t idx4, int m) {
-  const uint32_t k0 = d.rng[0], k1 = d.rng[1], step = d.rng[2];
-  float pf = 1.f;
-  if (d.path_p > 0.f) {
-    uint32_t r[4];
-    philox4x32_7((uint32_t)(m / d.rows_per_pass), 0x9E3779B9u, d.path_site, step, k0, k1, r);
-    pf = r[0] >= drop_threshold(d.path_p) ? 1.f / (1.f - d.path_p) : 0.f;
-  }
+// DropPath factor of one task pass: 0 or 1 / (1 - path_p)
+MT_DEVINL float drop_path_factor(const DropArgs& d, int pass) {
+  if (!(d.path_p > 0.f)) return 1.f;
+  uint32_t r[4];
+  philox4x32_7((uint32_t)pass, 0x9E3779B9u, d.path_site, d.rng[2], d.rng[0], d.rng[1], r);
+  return r[0] >= drop_threshold(d.path_p) ? 1.f / (1.f - d.path_p) : 0.f;
+}
+// scale factors of the 4 consecutive elements whose linear index starts at 4 * idx4, given their pass's DropPath factor
+MT_DEVINL f32x4 drop_elem4(const DropArgs& d, uint64_t idx4, float pf) {
   f32x4 s = {pf, pf, pf, pf};
   if (d.p > 0.f) {
     uint32_t r[4];
-    philox4x32_7((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.site, step, k0, k1, r);
+    philox4x32_7((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.site, d.rng[2], d.rng[0], d.rng[1], r);
     const uint32_t thr = drop_threshold(d.p);
     const float keep = pf / (1.f - d.p);
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] = r[e] >= thr ? keep : 0.f;
   }
   return s;
+}
+MT_DEVINL f32x4 drop_scale4(const DropArgs& d, uint64_t idx4, int m) {
+  return drop_elem4(d, idx4, drop_path_factor(d, m / d.rows_per_pass));
 }
 
 // keep flag of ONE element (linear index idx) of an element-dropout site (token-side tensors, AlphaDropout)

@@ -66,6 +66,12 @@ MT_DEVINL void gemm_epilogue(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16][BN 
     if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
     if (EPI == MT_EPI_INJECT) gm4 = *reinterpret_cast<const f32x4*>(g.colscale + n);
   }
+  // DropPath factors of the (at most two) task passes this tile touches, once per thread
+  const bool dropping = EPI == MT_EPI_BIAS_RESID && g.drop.active();
+  const int dpass0 = dropping ? m0 / g.drop.rows_per_pass : 0;
+  const int dsplit = (dpass0 + 1) * g.drop.rows_per_pass;        // first row of the next pass
+  const bool dfast = dropping && g.drop.rows_per_pass >= BM;
+  const float dpf0 = dfast ? drop_path_factor(g.drop, dpass0) : 1.f, dpf1 = dfast ? drop_path_factor(g.drop, dpass0 + 1) : 1.f;
 #pragma unroll
   for (int pass = 0; pass < BM / EROWS; ++pass) {
     const int rbase = pass * EROWS;
@@ -86,7 +92,9 @@ MT_DEVINL void gemm_epilogue(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16][BN 
       f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * CS + cc]);
       v += bias4;
       if (EPI == MT_EPI_BIAS_RESID) {
-        if (g.drop.active()) v *= drop_scale4(g.drop, ((uint64_t)m * g.N + n) >> 2, m);     // dropout / DropPath of the branch
+        if (dropping)       // dropout / DropPath of the branch
+          v *= dfast ? drop_elem4(g.drop, ((uint64_t)m * g.N + n) >> 2, m < dsplit ? dpf0 : dpf1)
+                     : drop_scale4(g.drop, ((uint64_t)m * g.N + n) >> 2, m);
         v += *reinterpret_cast<const f32x4*>(g.resid + g.rmap.map(m) * g.ldr + n);
       }
       if (EPI == MT_EPI_INJECT) {
