@@ -22,12 +22,6 @@ namespace {
 // S^T of tile t+1 in flight during the softmax of tile t -- measured 5 % slower: it needs 185 VGPRs = 2 waves/SIMD
 // against 142 = 3 waves/SIMD here, and these kernels are latency-bound, not pipe-bound.)
 // ------------------------------------------------------------------------------------------------
-#ifdef MT_DIAG
-#define DIAG_V(v) (VARIANT == (v))
-template <int VARIANT>
-#else
-#define DIAG_V(v) false
-#endif
 __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __restrict__ qkv, Plan p, h16* __restrict__ o_br,
                                                                float* __restrict__ lse_br) {
   __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];
@@ -736,15 +730,8 @@ extern "C" int mt_dilated_attn_fwd(const mt_half* qkv, const MtDilatedPlan* plan
   if (!qkv || !o_br || !lse_br || !plan_ok(plan)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
   const int nblk = p.blk_off[p.nbranch];
-#ifdef MT_DIAG
-  const char* ev = getenv("MT_DIAG_VARIANT");
-  const int variant = ev ? atoi(ev) : 0;
-#define MT_LAUNCH_V(v) case v: hipLaunchKernelGGL(dilated_attn_fwd_kernel<v>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv, p, (h16*)o_br, lse_br); break;
-  switch (variant) { MT_LAUNCH_V(0) MT_LAUNCH_V(1) MT_LAUNCH_V(2) MT_LAUNCH_V(3) MT_LAUNCH_V(4) MT_LAUNCH_V(5) default: return MT_ERR_BAD_ARG; }
-#else
   hipLaunchKernelGGL(dilated_attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const h16*)qkv, p,
                      (h16*)o_br, lse_br);
-#endif
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
