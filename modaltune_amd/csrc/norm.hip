@@ -257,26 +257,25 @@ __global__ __launch_bounds__(256) void ln_gelu_fwd_kernel(LnFwdArgs a) {
   }
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(LnBwdArgs a) {
-  constexpr int NC = D / 1024;
-  __shared__ float red[2][2][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = wave & 1, rsel = wave >> 1;
-  const int col0 = half * (D / 2) + lane * 8;
+// backward: WPR waves per row (a lane owns D / (64 WPR) columns in chunks of 8), one row per workgroup iteration
+template <int D, int WPR>
+__global__ __launch_bounds__(64 * WPR) void ln_gelu_bwd_kernel(LnBwdArgs a) {
+  constexpr int NC = D / (512 * WPR);
+  static_assert(NC * 512 * WPR == D, "row must split into 8-element chunks over the waves");
+  __shared__ float red[2][2][WPR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col0 = wave * (D / WPR) + lane * 8;
   f32x2 wr[NC][4];
 #pragma unroll
   for (int c = 0; c < NC; ++c) ldf8(a.w + col0 + c * 512, wr[c]);
   int it = 0;
-  for (int base = blockIdx.x * 2; base < a.M; base += gridDim.x * 2, it ^= 1) {
-    const int m = base + rsel;
-    const bool valid = m < a.M;
-    const int mc = valid ? m : a.M - 1;
-    const h16* dy = reinterpret_cast<const h16*>(a.dy) + a.dymap.map(mc) * a.lddy;
-    const h16* x = reinterpret_cast<const h16*>(a.x) + a.xmap.map(mc) * a.ldx;
+  for (int m = blockIdx.x; m < a.M; m += gridDim.x, it ^= 1) {
+    const h16* dy = reinterpret_cast<const h16*>(a.dy) + a.dymap.map(m) * a.lddy;
+    const h16* x = reinterpret_cast<const h16*>(a.x) + a.xmap.map(m) * a.ldx;
     h16x8 rx[NC], rd[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { rx[c] = ldg8(x + col0 + c * 512); rd[c] = ldg8(dy + col0 + c * 512); }
-    const float mean = a.stats[2 * (long)mc], rstd = a.stats[2 * (long)mc + 1];
+    const float mean = a.stats[2 * (long)m], rstd = a.stats[2 * (long)m + 1];
     const f32x2 rs = splat2(rstd), nmr = splat2(-mean * rstd);
     f32x2 xh[NC][4], g[NC][4], dgl[NC][4];
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
@@ -295,26 +294,26 @@ __global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(LnBwdArgs a) {
       }
     }
     const float p1 = wave_sum(s1[0] + s1[1]), p2 = wave_sum(s2[0] + s2[1]);
-    if (lane == 0) { red[it][0][wave] = p1; red[it][1][wave] = p2; }      // double-buffered: one barrier per row pair
+    if (lane == 0) { red[it][0][wave] = p1; red[it][1][wave] = p2; }      // double-buffered: one barrier per row
     __syncthreads();
-    const float c1 = (red[it][0][2 * rsel] + red[it][0][2 * rsel + 1]) * (1.0f / D);
-    const float c2 = (red[it][1][2 * rsel] + red[it][1][2 * rsel + 1]) * (1.0f / D);
-    if (valid) {
-      h16* dx = reinterpret_cast<h16*>(a.dx) + a.dxmap.map(m) * a.lddx;
-      const f32x2 nc1 = splat2(-c1), nc2 = splat2(-c2);
+    float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        f32x2 o[4];
+    for (int w2 = 0; w2 < WPR; ++w2) { c1 += red[it][0][w2]; c2 += red[it][1][w2]; }
+    c1 *= (1.0f / D); c2 *= (1.0f / D);
+    h16* dx = reinterpret_cast<h16*>(a.dx) + a.dxmap.map(m) * a.lddx;
+    const f32x2 nc1 = splat2(-c1), nc2 = splat2(-c2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (pk_fma2(xh[c][i], nc2, g[c][i]) + nc1) * (dgl[c][i] * rs);
-        if (a.accumulate) {
-          f32x2 old[4];
-          cvt8(ldg8(dx + col0 + c * 512), old);
+    for (int c = 0; c < NC; ++c) {
+      f32x2 o[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] += old[i];
-        }
-        stg8(dx + col0 + c * 512, pack8(o));
+      for (int i = 0; i < 4; ++i) o[i] = (pk_fma2(xh[c][i], nc2, g[c][i]) + nc1) * (dgl[c][i] * rs);
+      if (a.accumulate) {
+        f32x2 old[4];
+        cvt8(ldg8(dx + col0 + c * 512), old);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += old[i];
       }
+      stg8(dx + col0 + c * 512, pack8(o));
     }
   }
 }
@@ -535,7 +534,8 @@ static int ln_bwd_types(const LnBwdArgs& a, int dy_dt, int in_dt, int dx_dt, int
   if (gelu) {
     if constexpr (D % 1024 == 0) {
       if (dyh && inh && dxh && !a.dw && !(a.lddy & 7) && !(a.ldx & 7) && !(a.lddx & 7)) {
-        hipLaunchKernelGGL((ln_gelu_bwd_kernel<D>), dim3(ln_gelu_grid(a.M)), dim3(256), 0, s, a);
+        constexpr int WPR = (D % 1536 == 0) ? 3 : 2;        // 3072 -> three waves per row (16 columns per lane)
+        hipLaunchKernelGGL((ln_gelu_bwd_kernel<D, WPR>), dim3(min(a.M, 16384)), dim3(64 * WPR), 0, s, a);
         MT_CHECK_LAUNCH();
         return MT_OK;
       }
