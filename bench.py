@@ -169,6 +169,7 @@ def main():
         n_l, ms = summ["dilated_attn_bwd_kv"]
         launch_flops = 2.0 * 3 * fl["attn_layer"]
         achieved = launch_flops / (ms / n_l * 1e-3) / 1e12
+        exec_flops = 2.0 * 3 * fl["attn_layer_executed"]      # zero-padded tiles are skipped, not computed
         out = {
             "metric": "slides/sec (train step) at 10k patches x 1536-d", "value": value, "unit": "slides/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -186,6 +187,8 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS,
                          "traffic": RECORDED_KV_TRAFFIC.get((L, T)),
                          "avg_launch_ms": ms / n_l, "flops_per_launch": launch_flops,
+                         "flops_executed_per_launch": exec_flops,
+                         "mfma_frac_executed": exec_flops / (ms / n_l * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                          "traffic_source": ("recorded rocprofv3 --pmc passes (profiles/r01_pmc_hbm_attn_bwd.txt): 2 x FETCH_SIZE "
                                             "(gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, bytes per launch"
                                             if (L, T) in RECORDED_KV_TRAFFIC else None),

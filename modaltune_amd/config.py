@@ -177,6 +177,15 @@ def flops_per_slide_step(L: int, T: int, depth: int = 12, seg=None, tasks: int =
     patch = 2.0 * L * 1536 * D
     gemm_layer = 2.0 * N * (4 * D * D + 2 * D * F)
     attn_layer = sum(b.nseg * H * b.n * b.n * d * 4.0 for b in branch_table(N, seg))
+    # what the kernels execute: the zero padding at a segment / sequence end is skipped (attn.hip), so a sparse
+    # sequence with nv real entries costs nv^2 instead of n^2
+    attn_exec = 0.0
+    for b in branch_table(N, seg):
+        for j in range(b.nseg):
+            lim = min(b.seg, N - j * b.seg)
+            for r in range(b.ratio):
+                nv = min(b.n, max(0, -(-(lim - r) // b.ratio)))
+                attn_exec += (H // b.ratio) * nv * nv * d * 4.0
     inj = 2.0 * L * (D * E + E * E + E * E + E * D) + 4.0 * L * T * E + 2.0 * T * 2 * D * E
     ext = 2.0 * T * (D * E + E * E + E * E + E * D) + 4.0 * L * T * E + 2.0 * L * 2 * D * E + 2.0 * T * 2 * D * E
     adapter = 3 * inj + 5 * ext
@@ -184,4 +193,4 @@ def flops_per_slide_step(L: int, T: int, depth: int = 12, seg=None, tasks: int =
     bwd = depth * (gemm_layer + 2.5 * attn_layer) + 2 * adapter
     step = tasks * (fwd + bwd) - (tasks - 1) * patch
     return {"fwd_pass": fwd, "bwd_pass": bwd, "step": step, "gemm_layer": gemm_layer,
-            "attn_layer": attn_layer, "adapter": adapter, "patch": patch}
+            "attn_layer": attn_layer, "attn_layer_executed": attn_exec, "adapter": adapter, "patch": patch}

@@ -32,6 +32,11 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
   const float c = 0.14433756729740643f * LOG2E;   // 48^-1/2 * log2(e)
+  // Entries [nv, n) of the sparse sequence are zero padding (segment / sequence end): as QUERIES they produce nothing
+  // that is ever read, as KEYS they all have logit 0 and value 0.  A workgroup of padded queries exits; key tiles
+  // made only of padding are not computed -- their sum(P) share is added in closed form after the loop.
+  const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
+  if (w.qt * 128 >= nv) return;
 
   // ones columns (d = 48 and 52) so that O^T row 48 (both lane halves) accumulates sum(P); written once
   if (tid < 128) {
@@ -52,8 +57,9 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
 
   const StageIdx st(tid);
   const int ntile = (sq.n + 63) / 64;
+  const int nproc = (nv + 63) >> 6;      // tiles holding at least one real key
   // tiles [0, nfull) hold only real rows: loaded with a uniform base + constant 32-bit lane offset, no clamp, no select
-  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);
+  const int nfull = nv >> 6;
   const h16* kbase = hm_ptr(qkv, M, H + w.h, sq.row(0));
   const h16* vbase = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
   const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
@@ -176,9 +182,20 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   };
   int t = 0;
   for (; t + 1 < nfull; ++t) tile(t, std::false_type{}, std::false_type{}, std::true_type{});
-  for (; t < ntile - 1; ++t) tile(t, std::false_type{}, std::false_type{}, std::false_type{});
-  if (sq.n & 63) tile(ntile - 1, std::true_type{}, std::true_type{}, std::false_type{});
-  else tile(ntile - 1, std::true_type{}, std::false_type{}, std::false_type{});
+  for (; t < nproc - 1; ++t) tile(t, std::false_type{}, std::false_type{}, std::false_type{});
+  if (nproc == ntile && (sq.n & 63)) tile(nproc - 1, std::true_type{}, std::true_type{}, std::false_type{});
+  else tile(nproc - 1, std::true_type{}, std::false_type{}, std::false_type{});
+  const int rest = sq.n - nproc * 64;      // padded keys in the tiles not computed: logit 0, value 0
+  if (rest > 0) {
+    const float m_new = fmaxf(m_run, 0.f);
+    if (__any((m_new - m_run) * c > RESCALE_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      m_run = m_new;
+    }
+    o1[8] += (float)rest * __builtin_amdgcn_exp2f(-m_run * c);
+  }
 
   if (qvalid) {
     const float l = o1[8];           // O^T row 48 (lane half 0) / row 52 (lane half 1): both carry sum(P)
@@ -386,6 +403,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const long M = (long)p.B * p.N;
   const float c = 0.14433756729740643f * LOG2E;
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // padded queries get no gradient; padded keys have K = 0 and add nothing to dQ: neither is computed
+  const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
+  if (w.qt * 128 >= nv) return;
 
   if (tid < 128) {   // zero the never-written columns 48..63 of the transposed-layout tile (read as d rows 48..63)
     const int buf = tid >> 6, row = tid & 63;
@@ -409,8 +429,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const f32x2 c2 = {c, c}, nl22 = {nl2, nl2}, ndl2 = {ndl, ndl};
 
   const StageIdx st(tid);
-  const int ntile = (sq.n + 63) / 64;
-  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);   // tiles [0, nfull) hold only real rows
+  const int ntile = (nv + 63) >> 6;      // tiles holding at least one real key
+  const int nfull = nv >> 6;             // tiles [0, nfull) hold only real rows
   const h16* kbase = hm_ptr(qkv, M, H + w.h, sq.row(0));
   const h16* vbase = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
   const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
@@ -496,7 +516,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   };
   int t = 0;
   for (; t + 1 < nfull; ++t) tile(t, std::false_type{}, std::true_type{});
-  const int nmask = (sq.n & 63) ? ntile - 1 : ntile;          // tiles >= nmask contain keys >= n
+  const int nmask = (ntile * 64 > sq.n) ? ntile - 1 : ntile;  // tiles >= nmask contain keys >= n
   for (; t < nmask; ++t) tile(t, std::false_type{}, std::false_type{});
   for (; t < ntile; ++t) tile(t, std::true_type{}, std::false_type{});
   if (qvalid) {
@@ -541,6 +561,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   const float c = 0.14433756729740643f * LOG2E;
   const f32x2 c2 = {c, c};
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // padded keys get no gradient; padded queries have P' = 0: neither is computed
+  const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
+  if (w.qt * 128 >= nv) return;
 
   if (tid < 64) {
     *reinterpret_cast<h16x8*>(&Qt[tid * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Qt[tid * VSTR + 56]) = zero8;
@@ -559,8 +582,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   }
 
   const StageIdx st(tid);
-  const int ntile = (sq.n + 63) / 64;
-  const int nfull = __builtin_amdgcn_readfirstlane(sq.nvalid() >> 6);   // tiles [0, nfull) hold only real rows
+  const int ntile = (nv + 63) >> 6;      // tiles holding at least one real query
+  const int nfull = nv >> 6;             // tiles [0, nfull) hold only real rows
   const h16* qbase = hm_ptr(qkv, M, w.h, sq.row(0));
   const h16* dbase = hm_ptr(dmixed, M, w.h, sq.row(0));
   const float* lbase = lse_tot + sq.row(0) * H + w.h;

@@ -399,6 +399,57 @@ def test_dilated_attention_bwd_vs_oracle_autograd(ops, golden_dir, case):
         assert r < 2e-2, (name, r)
 
 
+@pytest.mark.parametrize("N", [1030, 1100, 1500, 2049])
+def test_dilated_attention_padded_segment_tail(ops, N):
+    """A short last segment: most of its sparse sequence is zero padding, which the kernels do not compute -- padded
+    key tiles enter sum(P) in closed form (forward) and are skipped outright (backward: K = 0 adds nothing to dQ,
+    padded keys / queries get no gradient).  Forward per-branch outputs + LSE and backward dq/dk/dv against the fp64
+    oracle with the reference's real segment lengths."""
+    from oracle import modaltune_oracle as O
+    gen = rng(N)
+    B = 1
+    segs, ratios = [1024, 5792, 32768, 185363, 1048576], [1, 2, 4, 8, 16]
+    qkv16 = (torch.randn(B, N, 2304, generator=gen) * 0.7).half()
+    ln_w = (1 + 0.1 * torch.randn(768, generator=gen))
+    ln_b = 0.1 * torch.randn(768, generator=gen)
+    dy = (torch.randn(B, N, 768, generator=gen) * 0.1).half()
+    qd = qkv16.double().requires_grad_(True)
+    q, k, v = (t.view(B, N, 16, 48) for t in qd.split(768, dim=-1))
+    mixed, outs, lses = O.dilated_attention_core(q, k, v, segs, ratios, return_branches=True)
+    yref = torch.nn.functional.layer_norm(mixed, (768,), ln_w.double(), ln_b.double(), 1e-5)
+    yref.backward(dy.double())
+    bt = branch_table(N, segs, ratios)
+    plan = ops.make_plan(bt, N, B)
+    M, nb = B * N, len(bt)
+    qkv_d = _hm(qkv16.to(DEV).view(M, 2304))
+    o_br = torch.zeros(nb, M, 768, dtype=torch.float16, device=DEV)
+    lse_br = torch.zeros(nb, M, 16, device=DEV)
+    ops.dilated_attn_fwd(qkv_d, plan, o_br, lse_br)
+    y = torch.zeros(M, 768, dtype=torch.float16, device=DEV)
+    stats = torch.zeros(M, 2, device=DEV)
+    lse_tot = torch.zeros(M, 16, device=DEV)
+    ops.dilated_mix_ln_fwd(o_br, lse_br, plan, ln_w.to(DEV), ln_b.to(DEV), y, stats, lse_tot)
+    dmixed = torch.zeros(M, 768, dtype=torch.float16, device=DEV)
+    delta = torch.zeros(nb, M, 16, device=DEV)
+    ops.dilated_mix_ln_bwd(dy.to(DEV).view(M, 768), o_br, lse_br, lse_tot, plan, ln_w.to(DEV), stats, dmixed, delta)
+    dqkv = torch.full((M, 2304), float("nan"), device=DEV, dtype=torch.float16)
+    wsb = torch.full((ops.dilated_attn_bwd_workspace_bytes(plan) // 2,), float("nan"), device=DEV, dtype=torch.float16)
+    ops.dilated_attn_bwd(qkv_d, dmixed, lse_tot, delta, plan, wsb, dqkv)
+    torch.cuda.synchronize()
+    for i in range(nb):
+        cov = lses[i].detach() > -1e7
+        got_o = o_br[i].view(B, N, 16, 48).double().cpu()
+        got_l = lse_br[i].view(B, N, 16).double().cpu()
+        assert float(((got_o - outs[i].detach()).abs() * cov.unsqueeze(-1)).max()) < 3e-3 * float(outs[i].abs().max())
+        assert float(((got_l - lses[i].detach()).abs() * cov).max()) < 2e-3
+    assert rel(y.view(B, N, 768), yref.detach()) < 4e-3
+    got = dqkv.view(B, N, 2304).double().cpu()
+    assert torch.isfinite(got).all()
+    for name, sl in (("dq", slice(0, 768)), ("dk", slice(768, 1536)), ("dv", slice(1536, 2304))):
+        r = rel(got[..., sl], qd.grad[..., sl])
+        assert r < 2e-2, (name, r)
+
+
 # ------------------------------------------------------------------------------------------ adapter attention
 def _mha_ref(q, k, v, heads):
     B, Lq, E = q.shape
