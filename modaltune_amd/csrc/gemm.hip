@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const h16* A, long lda, Row
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small strided fp32 GEMM (token side).  16x16 outputs per workgroup, K walked in 16-wide LDS tiles.
+// Small strided fp32 GEMM (token side): fp32 MFMA, operands straight from global memory.
 // ------------------------------------------------------------------------------------------------
 struct SgemmArgs {
   const float* A; long as0, as1, a_bs;
@@ -557,50 +557,94 @@ MT_DEVINL float apply_act(float v, int act) {
   }
 }
 
+// One workgroup = one 16x16 output tile; its four waves split K and each runs v_mfma_f32_16x16x4_f32 (fp32 operands,
+// fp32 accumulate -- the token side stays fp32) on operands loaded STRAIGHT from global memory into the MFMA lane
+// layout: lane (r = lane & 15, kq = lane >> 4) supplies row r of the tile and four consecutive k per 16-wide k block,
+// one 16-byte load when the operand is k-contiguous (AK / BK), coalesced scalar loads across r otherwise (the
+// transposed operands of the dW products).  No LDS in the k loop; the four partial tiles meet in LDS once at the end.
+// (The previous form -- one output per thread, both operands re-read from LDS for every FMA -- was LDS-bound at
+// 17 us for 195 x 192 x 768; these GEMMs are latency chains, so what matters is one deep batch of independent loads.)
+template <bool AK, bool BK_>
 __global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
-  constexpr int KC = 64;                       // K chunk per barrier pair
-  __shared__ float As[16][KC + 1], Bs[16][KC + 1];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  __shared__ float part[4][16][17];
+  __shared__ float rsum[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, bz = blockIdx.z;
-  const float* A = g.A + (long)bz * g.a_bs;
-  const float* B = g.B + (long)bz * g.b_bs;
+  const float* ap = g.A + (long)bz * g.a_bs + (long)min(m0 + r, g.M - 1) * g.as0;
+  const float* bp = g.B + (long)bz * g.b_bs + (long)min(n0 + r, g.N - 1) * g.bs0;
   float* C = g.C + (long)bz * g.c_bs;
-  // staging: thread -> (row = tid / 16, k = tid % 16 + 16 j), j = 0..3; the next chunk is prefetched into registers
-  // while the current one is consumed (these GEMMs are latency-bound: one global round trip per chunk otherwise)
-  const int sr = threadIdx.x >> 4, sk = threadIdx.x & 15;
-  const int am = m0 + sr, bn = n0 + sr;
-  float ra[KC / 16], rb[KC / 16];
-  auto gload = [&](int k0) {
+  // this wave's k range: a multiple of 16 per wave
+  const int kper = ((g.K + 63) / 64) * 16;
+  const int kb = wave * kper, ke = min(g.K, kb + kper);
+  const bool want_rs = g.rowsum != nullptr && blockIdx.x == 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float rs = 0.f;
+  int k0 = kb;
+  // full 64-wide blocks: 4 (x 2 operands) independent loads per lane in flight, then 16 MFMAs
+  for (; k0 + 64 <= ke; k0 += 64) {
+    f32x4 a[4], b[4];
 #pragma unroll
-    for (int j = 0; j < KC / 16; ++j) {
-      const int kk = k0 + sk + 16 * j;
-      ra[j] = (am < g.M && kk < g.K) ? A[am * g.as0 + kk * g.as1] : 0.f;
-      rb[j] = (bn < g.N && kk < g.K) ? B[bn * g.bs0 + kk * g.bs1] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 16 * j + 4 * kq;
+      if (AK) a[j] = *reinterpret_cast<const f32x4*>(ap + k);
+      else a[j] = (f32x4){ap[(long)k * g.as1], ap[(long)(k + 1) * g.as1], ap[(long)(k + 2) * g.as1], ap[(long)(k + 3) * g.as1]};
+      if (BK_) b[j] = *reinterpret_cast<const f32x4*>(bp + k);
+      else b[j] = (f32x4){bp[(long)k * g.bs1], bp[(long)(k + 1) * g.bs1], bp[(long)(k + 2) * g.bs1], bp[(long)(k + 3) * g.bs1]};
     }
-  };
-  float acc = 0.f, rs = 0.f;
-  const bool want_rs = g.rowsum != nullptr && blockIdx.x == 0 && tx == 0;    // one column of workgroups, one lane per row
-  gload(0);
-  for (int k0 = 0; k0 < g.K; k0 += KC) {
 #pragma unroll
-    for (int j = 0; j < KC / 16; ++j) { As[sr][sk + 16 * j] = ra[j]; Bs[sr][sk + 16 * j] = rb[j]; }
-    __syncthreads();
-    if (k0 + KC < g.K) gload(k0 + KC);
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int k = 0; k < KC; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
-    if (want_rs) {
-#pragma unroll
-      for (int k = 0; k < KC; ++k) rs += As[ty][k];
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][e], b[j][e], acc, 0, 0, 0);
+      if (want_rs) rs += (a[j][0] + a[j][1]) + (a[j][2] + a[j][3]);
     }
-    __syncthreads();
   }
-  if (want_rs && m0 + ty < g.M) g.rowsum[m0 + ty] += rs;
-  const int m = m0 + ty, n = n0 + tx;
+  // full 16-wide blocks (a wave's share of a short K is below 64)
+  for (; k0 + 16 <= ke; k0 += 16) {
+    const int k = k0 + 4 * kq;
+    f32x4 a, b;
+    if (AK) a = *reinterpret_cast<const f32x4*>(ap + k);
+    else a = (f32x4){ap[(long)k * g.as1], ap[(long)(k + 1) * g.as1], ap[(long)(k + 2) * g.as1], ap[(long)(k + 3) * g.as1]};
+    if (BK_) b = *reinterpret_cast<const f32x4*>(bp + k);
+    else b = (f32x4){bp[(long)k * g.bs1], bp[(long)(k + 1) * g.bs1], bp[(long)(k + 2) * g.bs1], bp[(long)(k + 3) * g.bs1]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    if (want_rs) rs += (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  // ragged rest: guarded scalar loads (zero beyond the range)
+  for (; k0 < ke; k0 += 16) {
+    float a[4], b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + 4 * kq + e;
+      const bool ok = k < ke;
+      const int kc = ok ? k : kb;
+      const float av = ap[(long)kc * g.as1], bv = bp[(long)kc * g.bs1];
+      a[e] = ok ? av : 0.f; b[e] = ok ? bv : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    if (want_rs) rs += (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  // accumulator element e of lane = C[m = 4 * kq + e][n = r]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[wave][4 * kq + e][r] = acc[e];
+  if (want_rs) {
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    if (kq == 0) rsum[wave][r] = rs;
+  }
+  __syncthreads();
+  const int tm = tid >> 4, tn = tid & 15;
+  const int m = m0 + tm, n = n0 + tn;
+  if (want_rs && tid < 16 && m0 + tid < g.M)
+    g.rowsum[m0 + tid] += (rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid]);
   if (m < g.M && n < g.N) {
-    if (g.bias) acc += g.bias[g.bias_on_m ? m : n];
-    acc = apply_act(acc, g.act);
+    float v = (part[0][tm][tn] + part[1][tm][tn]) + (part[2][tm][tn] + part[3][tm][tn]);
+    if (g.bias) v += g.bias[g.bias_on_m ? m : n];
+    v = apply_act(v, g.act);
     float* c = &C[m * g.cs0 + n * g.cs1];
-    *c = g.accumulate ? *c + acc : acc;
+    *c = g.accumulate ? *c + v : v;
   }
 }
 
@@ -680,7 +724,15 @@ extern "C" int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, con
                               mt_stream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || (rowsum && batch != 1)) return MT_ERR_BAD_ARG;
   SgemmArgs g{A, as0, as1, a_bs, B, bs0, bs1, b_bs, bias, bias_on_m, C, cs0, cs1, c_bs, M, N, K, act, accumulate, rowsum};
-  hipLaunchKernelGGL(sgemm_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16), batch), dim3(256), 0, (hipStream_t)stream, g);
+  // 16-byte loads along k need k-contiguous, 16-byte aligned rows
+  const bool ak = as1 == 1 && (as0 % 4) == 0 && (a_bs % 4) == 0 && ((uintptr_t)A & 15) == 0;
+  const bool bk = bs1 == 1 && (bs0 % 4) == 0 && (b_bs % 4) == 0 && ((uintptr_t)B & 15) == 0;
+  const dim3 grid(cdiv(N, 16), cdiv(M, 16), batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (ak && bk) hipLaunchKernelGGL((sgemm_small_kernel<true, true>), grid, dim3(256), 0, s, g);
+  else if (ak) hipLaunchKernelGGL((sgemm_small_kernel<true, false>), grid, dim3(256), 0, s, g);
+  else if (bk) hipLaunchKernelGGL((sgemm_small_kernel<false, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((sgemm_small_kernel<false, false>), grid, dim3(256), 0, s, g);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
