@@ -220,11 +220,19 @@ int mt_cast_f16_to_f32(const mt_half* x, float* y, long n, mt_stream_t stream);
 /* Derived fp16 weight cache of an fp32 nn.Linear weight [R, C]: as stored (forward, W[N,K]) or transposed
  * (the dX GEMM's W^T[K,N]); re-run for trainable weights after every optimiser step (SURVEY §8b ownership). */
 int mt_pack_weight_f16(const float* src, int R, int C, mt_half* dst, int transpose, mt_stream_t stream);
+/* The same for a whole list of weights in ONE launch (the per-step refresh of every trainable big-M weight).
+ * `items` is a DEVICE array of n_items records of 8 int64 each:
+ *   { src fp32 [rows, cols] , dst fp16 (or 0) , dst_t fp16 (or 0) , rows , cols , row_off , ld , ld_t }
+ * dst[(row_off + r) * ld + c] = dst_t[c * ld_t + row_off + r] = fp16(src[r * cols + c]); row_off / ld_t place the rows
+ * of one source inside a cache that concatenates several (the fused K|V projection). */
+int mt_pack_weights_f16(const long long* items, int n_items, mt_stream_t stream);
 /* y = act(x) / dx = dy * act'(x) on fp32 vectors (ELU GE:178, GELU GE:187, ReLU AM:286) */
 int mt_act_fwd(const float* x, float* y, long n, int act, mt_stream_t stream);
 int mt_act_bwd(const float* x, const float* dy, float* dx, long n, int act, mt_stream_t stream);
 /* y[i] = a[i] + alpha * b[i] */
 int mt_axpy(const float* a, const float* b, float alpha, float* y, long n, mt_stream_t stream);
+/* y[i] = a[i] + alpha * b[i % period]: a [period] row block broadcast over the batch (with_pos_embed, AM:64-65) */
+int mt_axpy_bcast(const float* a, const float* b, float alpha, float* y, long n, long period, mt_stream_t stream);
 /* strided row copies between fp32 buffers: dst(map(m), :) (+)= src(map(m), :) */
 int mt_copy_rows_f32(const float* src, long lds, const MtRowMap* smap, float* dst, long ldd, const MtRowMap* dmap,
                      int M, int D, int accumulate, mt_stream_t stream);

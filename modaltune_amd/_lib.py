@@ -71,9 +71,11 @@ SIGNATURES = {
     "mt_droppath_rows_f32": [P, I, I, DR, P],
     "mt_cast_f16_to_f32": [P, P, L, P],
     "mt_pack_weight_f16": [P, I, I, P, I, P],
+    "mt_pack_weights_f16": [P, I, P],
     "mt_act_fwd": [P, P, L, I, P],
     "mt_act_bwd": [P, P, P, L, I, P],
     "mt_axpy": [P, P, F, P, L, P],
+    "mt_axpy_bcast": [P, P, F, P, L, L, P],
     "mt_copy_rows_f32": [P, L, RM, P, L, RM, I, I, I, P],
     "mt_inject_resid_bwd": [P, L, RM, P, L, RM, P, P, P, L, RM, I, P, P, I, I, P],
     "mt_l2norm_rows": [P, P, I, I, P],

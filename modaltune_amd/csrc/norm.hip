@@ -425,6 +425,10 @@ __global__ void axpy_kernel(const float* a, const float* b, float alpha, float* 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = a[i] + alpha * b[i];
 }
+__global__ void axpy_bcast_kernel(const float* a, const float* b, float alpha, float* y, long n, long period) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = a[i] + alpha * b[i % period];
+}
 __global__ void copy_rows_kernel(const float* src, long lds, RowMap smap, float* dst, long ldd, RowMap dmap, int M,
                                  int D, int accumulate) {
   const int per_row = D / 4;
@@ -505,6 +509,39 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__
       const int r = r0 + ty + 8 * i, c = c0 + tx;
       if (r < R && c < C) dst[(long)r * C + c] = (h16)tile[ty + 8 * i][tx];
     }
+  }
+}
+
+// grouped form: blockIdx.x = item (8 int64 per record, see mt_pack_weights_f16), blockIdx.y strides over its 32x32 tiles;
+// one pass writes both the as-stored and the transposed fp16 copy
+__global__ __launch_bounds__(256) void pack_group_kernel(const long long* __restrict__ items) {
+  __shared__ float tile[32][33];
+  const long long* it = items + (long)blockIdx.x * 8;
+  const float* src = reinterpret_cast<const float*>(it[0]);
+  h16* dst = reinterpret_cast<h16*>(it[1]);
+  h16* dst_t = reinterpret_cast<h16*>(it[2]);
+  const int R = (int)it[3], C = (int)it[4], roff = (int)it[5];
+  const long ld = it[6], ld_t = it[7];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tiles_c = (C + 31) / 32, tiles = ((R + 31) / 32) * tiles_c;
+  for (int t = blockIdx.y; t < tiles; t += gridDim.y) {
+    const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      const float v = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+      tile[ty + 8 * i][tx] = v;
+      if (dst && r < R && c < C) dst[(long)(roff + r) * ld + c] = (h16)v;
+    }
+    __syncthreads();
+    if (dst_t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < C) dst_t[(long)c * ld_t + roff + r] = (h16)tile[tx][ty + 8 * i];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -614,6 +651,12 @@ extern "C" int mt_pack_weight_f16(const float* src, int R, int C, mt_half* dst, 
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
+extern "C" int mt_pack_weights_f16(const long long* items, int n_items, mt_stream_t stream) {
+  if (!items || n_items <= 0) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pack_group_kernel, dim3(n_items, 48), dim3(256), 0, (hipStream_t)stream, items);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
 extern "C" int mt_act_fwd(const float* x, float* y, long n, int act, mt_stream_t stream) {
   if (!x || !y || n <= 0) return MT_ERR_BAD_ARG;
   hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
@@ -629,6 +672,12 @@ extern "C" int mt_act_bwd(const float* x, const float* dy, float* dx, long n, in
 extern "C" int mt_axpy(const float* a, const float* b, float alpha, float* y, long n, mt_stream_t stream) {
   if (!a || !b || !y || n <= 0) return MT_ERR_BAD_ARG;
   hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, y, n);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_axpy_bcast(const float* a, const float* b, float alpha, float* y, long n, long period, mt_stream_t stream) {
+  if (!a || !b || !y || n <= 0 || period <= 0) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, y, n, period);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

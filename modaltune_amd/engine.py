@@ -177,6 +177,7 @@ class Engine:
             self._frozen16[p + "bqkv"] = torch.cat([t[p + "self_attn.q_proj.bias"], t[p + "self_attn.k_proj.bias"],
                                                     t[p + "self_attn.v_proj.bias"]]).contiguous()
         self._train16 = {}
+        self._pack_table = None
         for pref in self._cross_attn_prefixes():
             self._train16[pref + "q_proj"] = _W16([t[pref + "q_proj.weight"]], dev)
             self._train16[pref + "q_in"] = _W16([t[pref + "multihead_attn.q_proj_weight"]], dev)
@@ -190,8 +191,18 @@ class Engine:
         if not self._caches_ready:
             self._build_caches()
             return
-        for w in self._train16.values():
-            w.refresh()
+        # one grouped launch for all of them (records: include/modaltune_hip.h, mt_pack_weights_f16)
+        if getattr(self, "_pack_table", None) is None:
+            recs = []
+            for w in self._train16.values():
+                r = 0
+                for src in w.srcs:
+                    assert src.is_contiguous() and src.shape[1] == w.K
+                    recs.append([src.data_ptr(), w.w.data_ptr(), 0 if w.wt is None else w.wt.data_ptr(), src.shape[0], w.K, r,
+                                 w.K, w.N])
+                    r += src.shape[0]
+            self._pack_table = torch.tensor(recs, dtype=torch.int64, device=self.device)
+        ops.pack_weights(self._pack_table, self._pack_table.shape[0])
 
     def _cross_attn_prefixes(self) -> List[str]:
         out = []

@@ -217,6 +217,11 @@ def pack_weight(src, dst, R, C, transpose=False):
     check(_lib.load().mt_pack_weight_f16(_p(src), R, C, _p(dst), int(transpose), _s()), "pack_weight")
 
 
+def pack_weights(items, n_items):
+    """items: device int64 [n_items, 8] records (include/modaltune_hip.h: mt_pack_weights_f16)."""
+    check(_lib.load().mt_pack_weights_f16(_p(items), n_items, _s()), "pack_weights")
+
+
 def act_fwd(x, y, act, n=None):
     check(_lib.load().mt_act_fwd(_p(x), _p(y), n if n is not None else x.numel(), act, _s()), "act_fwd")
 
@@ -227,6 +232,11 @@ def act_bwd(x, dy, dx, act, n=None):
 
 def axpy(a, b, alpha, y, n=None):
     check(_lib.load().mt_axpy(_p(a), _p(b), float(alpha), _p(y), n if n is not None else a.numel(), _s()), "axpy")
+
+
+def axpy_bcast(a, b, alpha, y, period, n=None):
+    check(_lib.load().mt_axpy_bcast(_p(a), _p(b), float(alpha), _p(y), n if n is not None else a.numel(), period, _s()),
+          "axpy_bcast")
 
 
 def copy_rows(src, dst, M, D, *, lds=None, smap=None, ldd=None, dmap=None, accumulate=False):

@@ -13,19 +13,33 @@ import torch
 from . import ops
 
 
+_ACTIVE: Optional["Tape"] = None      # the tape whose forward is being recorded (set by Tape.reset)
+
+
 class Var:
     """A contiguous fp32 activation [..., C] with an optional (lazily zero-allocated) gradient."""
-    __slots__ = ("data", "grad", "needs_grad")
+    __slots__ = ("data", "grad", "needs_grad", "_tape")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = True):
         self.data = data
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
+        self._tape = _ACTIVE
 
     def g(self) -> torch.Tensor:
         if self.grad is None:
-            self.grad = torch.zeros_like(self.data)
+            self.grad = self._tape.zeros_like(self.data) if self._tape is not None else torch.zeros_like(self.data)
         return self.grad
+
+    def acc(self, d: torch.Tensor):
+        """grad += d, where d is a freshly produced buffer nobody else holds: the first contribution simply BECOMES
+        the gradient (no zero fill, no add launch)."""
+        if not self.needs_grad:
+            return
+        if self.grad is None:
+            self.grad = d
+        else:
+            ops.axpy(self.grad, d, 1.0, self.grad)
 
     @property
     def rows(self) -> int:
@@ -51,9 +65,33 @@ class Tape:
         self.back: List[Callable[[], None]] = []
         self._ones = torch.ones(4096, device=device)
         self.grad_enabled = True
+        # Zero-initialised gradient storage: one flat buffer cleared with ONE fill per step instead of a fill launch per
+        # gradient (~150 per step).  It is sized from the demand of the previous step (the first step falls back to
+        # individual fills); a captured step therefore must be preceded by two eager ones, which the trainer does.
+        self._arena: Optional[torch.Tensor] = None
+        self._arena_used = 0
+        self._arena_miss = 0
 
     def reset(self):
+        global _ACTIVE
+        _ACTIVE = self
         self.back.clear()
+        need = self._arena_used + self._arena_miss
+        if need > 0 and (self._arena is None or need > self._arena.numel()):
+            self._arena = torch.empty(need + need // 4 + 1024, device=self.device, dtype=torch.float32)
+        self._arena_used = self._arena_miss = 0
+        if self._arena is not None:
+            self._arena.zero_()
+
+    def zeros_like(self, t: torch.Tensor) -> torch.Tensor:
+        n = t.numel()
+        n_al = (n + 3) // 4 * 4                      # keep every gradient 16-byte aligned
+        if self._arena is not None and self._arena_used + n_al <= self._arena.numel():
+            v = self._arena[self._arena_used:self._arena_used + n].view(t.shape)
+            self._arena_used += n_al
+            return v
+        self._arena_miss += n_al
+        return torch.zeros_like(t)
 
     def record(self, fn: Callable[[], None]):
         if self.grad_enabled:
@@ -111,7 +149,7 @@ class Tape:
                 return
             tmp = self.new(*x.data.shape)
             ops.dropout_f32(y.grad, tmp, R, D, spec)          # the same mask, regenerated
-            ops.axpy(x.g(), tmp, 1.0, x.g())
+            x.acc(tmp)
         self.record(bwd)
         return y
 
@@ -167,9 +205,8 @@ class Tape:
             if y.grad is None:
                 return
             if add_rows is not None and add_rows.grad is not None:   # d pe[t] += sum over the batch of dy
-                reps = R // period
-                for r in range(reps):
-                    ops.axpy(add_rows.grad, y.grad.view(reps, period * D)[r], 1.0, add_rows.grad, period * D)
+                reps, per = R // period, period * D
+                ops.sgemm(self._ones, (0, 1), y.grad, (1, per), add_rows.grad, (per, 1), 1, per, reps, accumulate=True)
             train = w.grad is not None
             dx = x.g() if x.needs_grad else self.new(*x.data.shape)
             ops.layernorm_bwd(y.grad, x.data, w.data, stats, dx, R, D, accumulate=x.needs_grad,
@@ -184,8 +221,14 @@ class Tape:
         def bwd():
             if y.grad is None:
                 return
+            donated = a is b     # y.grad is dead after this closure: the first operand without a gradient takes it over
             for v in (a, b):
-                if v.needs_grad:
+                if not v.needs_grad:
+                    continue
+                if v.grad is None and not donated:
+                    v.grad = y.grad
+                    donated = True
+                else:
                     g = v.g()
                     ops.axpy(g, y.grad, 1.0, g)
         self.record(bwd)
@@ -196,18 +239,18 @@ class Tape:
         Bb = a.data.shape[0]
         per = p.data.numel()
         y = Var(self.new(*a.data.shape))
-        for bi in range(Bb):
-            ops.axpy(a.data[bi], p.data, 1.0, y.data[bi], per)
+        ops.axpy_bcast(a.data, p.data, 1.0, y.data, per)
 
         def bwd():
             if y.grad is None:
                 return
+            if p.grad is not None:       # dp[t, :] += sum_b dy[b, t, :] : a [1, Bb] x [Bb, per] product
+                ops.sgemm(self._ones, (0, 1), y.grad, (1, per), p.grad, (per, 1), 1, per, Bb, accumulate=True)
             if a.needs_grad:
-                g = a.g()
-                ops.axpy(g, y.grad, 1.0, g)
-            if p.grad is not None:
-                for bi in range(Bb):
-                    ops.axpy(p.grad, y.grad[bi], 1.0, p.grad, per)
+                if a.grad is None:
+                    a.grad = y.grad      # y.grad is dead after this closure
+                else:
+                    ops.axpy(a.grad, y.grad, 1.0, a.grad)
         self.record(bwd)
         return y
 
@@ -223,7 +266,6 @@ class Tape:
             dq, dk, dv = self.new(Bb, T, E), self.new(Bb, T, E), self.new(Bb, T, E)
             ops.token_mha_bwd(q.data, k.data, v.data, probs, out.grad, dq, dk, dv, Bb, T, E, heads)
             for var, d in ((q, dq), (k, dk), (v, dv)):
-                g = var.g()
-                ops.axpy(g, d, 1.0, g)
+                var.acc(d)
         self.record(bwd)
         return out
