@@ -119,6 +119,12 @@ int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B
 int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w,
                      const float* b, const float* add_rows, int add_period, void* y, long ldy, const MtRowMap* ymap,
                      int out_dtype, float* stats, int M, int D, mt_stream_t stream);
+/* h = x + drop(branch) ; y = fp16(LN(h) * w + b): the residual add of a backbone sub-layer (ENC:95-97,121-123 --
+ * x = residual stream fp32 [M, D], branch = fp16 output of the out_proj / fc2 GEMM, drop = that branch's Dropout +
+ * DropPath, same counters as the BIAS_RESID GEMM epilogue) riding on the LayerNorm that consumes the sum.
+ * h (fp32, != x) receives the new residual stream, stats the (mean, rstd) rows.  D = 768. */
+int mt_add_layernorm_fwd(const float* x, const mt_half* branch, const MtDropout* drop, const float* w, const float* b,
+                         float* h, mt_half* y, float* stats, int M, int D, mt_stream_t stream);
 
 /* dx (+)= LN backward.  dy fp16 or fp32 [M,D]; x as in forward (gelu_in: also backprop through the GELU).
  * dx_dtype F32 with accumulate=1 adds into the fp32 residual-gradient stream (ENC:137-154 backward);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mt_colsum_f16": [P, L, RM, I, I, P, P],
     "mt_sgemm_small": [P, L, L, L, P, L, L, L, P, I, P, L, L, L, I, I, I, I, I, I, P, P],
     "mt_layernorm_fwd": [P, L, RM, I, I, P, P, P, I, P, L, RM, I, P, I, I, P],
+    "mt_add_layernorm_fwd": [P, P, DR, P, P, P, P, P, I, I, P],
     "mt_layernorm_bwd": [P, L, RM, I, P, L, RM, I, I, P, P, P, L, RM, I, I, P, P, P, DR, I, I, P],
     "mt_dilated_attn_fwd": [P, PL, P, P, P],
     "mt_dilated_mix_ln_fwd": [P, P, PL, P, P, P, P, P, P],

@@ -71,6 +71,66 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   }
 }
 
+// h = x + drop(branch) ; y = LN(h) * w + b.  The residual add of a backbone sub-layer (branch = fp16 output of the
+// out_proj / fc2 GEMM, Dropout + DropPath as in the GEMM's BIAS_RESID epilogue: same counters, same masks) rides on the
+// LayerNorm that reads the sum anyway: the GEMM keeps a plain fp16 epilogue (MFMA-bound) and the fp32 residual stream
+// is read and written by this HBM-bound pass only.
+struct AddLnArgs {
+  const float* x; const h16* branch; DropArgs drop;
+  const float* w; const float* b;
+  float* h; h16* y; float* stats; int M;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(AddLnArgs a) {
+  constexpr int NC = D / 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 wr[NC], br[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    wr[c] = Vec4<float>::load(a.w + c * 256 + lane * 4);
+    br[c] = Vec4<float>::load(a.b + c * 256 + lane * 4);
+  }
+  const bool dropping = a.drop.active();
+  for (int m = blockIdx.x * 4 + wave; m < a.M; m += gridDim.x * 4) {
+    const float* x = a.x + (long)m * D;
+    const h16* bp = a.branch + (long)m * D;
+    f32x4 v[NC], bv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      v[c] = Vec4<float>::load(x + c * 256 + lane * 4);
+      bv[c] = Vec4<h16>::load(bp + c * 256 + lane * 4);
+    }
+    const float pf = dropping ? drop_path_factor(a.drop, m / a.drop.rows_per_pass) : 1.f;
+    float s = 0.f;
+    float* hrow = a.h + (long)m * D;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (dropping) bv[c] *= drop_elem4(a.drop, ((uint64_t)m * D + col) >> 2, pf);
+      v[c] += bv[c];
+      Vec4<float>::store(hrow + col, v[c]);
+      s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+    h16* y = a.y + (long)m * D;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * wr[c][e] + br[c][e];
+      Vec4<h16>::store(y + c * 256 + lane * 4, o);
+    }
+    if (lane == 0) { a.stats[2 * (long)m] = mean; a.stats[2 * (long)m + 1] = rstd; }
+  }
+}
+
 struct LnBwdArgs {
   const void* dy; long lddy; RowMap dymap;
   const void* x; long ldx; RowMap xmap;
@@ -563,6 +623,16 @@ extern "C" int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, i
     case 3072: return ln_fwd_types<3072>(a, in_dtype, out_dtype, gelu_in, s);
     default: return MT_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int mt_add_layernorm_fwd(const float* x, const mt_half* branch, const MtDropout* drop, const float* w,
+                                    const float* b, float* h, mt_half* y, float* stats, int M, int D, mt_stream_t stream) {
+  if (!x || !branch || !w || !b || !h || !y || !stats || M <= 0 || h == x) return MT_ERR_BAD_ARG;
+  if (D != 768) return MT_ERR_UNSUPPORTED;
+  AddLnArgs a{x, (const h16*)branch, make_drop(drop), w, b, h, (h16*)y, stats, M};
+  hipLaunchKernelGGL((add_ln_fwd_kernel<768>), dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, a);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
 }
 
 template <int D>

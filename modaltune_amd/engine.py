@@ -13,6 +13,7 @@ through all frozen layers, weight gradients exist only for adapter / gene / head
 """
 from __future__ import annotations
 
+
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -249,6 +250,7 @@ class Engine:
             w[f"hout{i}"] = e32(M, D)
         # transients shared by all layers
         w["u16"] = e16(M, D)
+        w["br16"] = e16(M, D)
         w["t16"] = e16(M, Fd)
         w["dh"] = e32(M, D)
         w["dy16"] = e16(M, D)
@@ -333,9 +335,10 @@ class Engine:
             else:
                 ops.copy_rows(ws[f"hout{i - 1}"], hin, B, D, smap=rowmap(1, N, 0), dmap=rowmap(1, N, 0))
             self._injector(i, c, pe, src, src_map, hin, first=(i == 0))
+            pend = None
             for l in range(la, lb + 1):
                 out = ws[f"hin{l + 1}"] if l < lb else ws[f"hout{i}"]
-                self._layer(l, out)
+                pend = self._layer(l, out, pend, defer=(l < lb))
             c = self._extractor(f"interactions.{i}.extractor.", c, pe, ws[f"hout{i}"])
             if i == nint - 1 and cfg.use_extra_extractor:
                 for j in range(2):
@@ -547,7 +550,11 @@ class Engine:
         tape.record(bwd)
 
     # ------------------------------------------------------------------ one frozen LongNet layer (A.4)
-    def _layer(self, l: int, out: torch.Tensor):
+    def _layer(self, l: int, out: torch.Tensor, pend=None, defer: bool = False):
+        """One frozen LongNet layer (ENC:78-125).  The residual adds ride on the LayerNorm that consumes the sum
+        (mt_add_layernorm_fwd): the out_proj / fc2 GEMMs write their fp16 branch with a plain epilogue.  `pend` is the
+        (stream, branch, dropout) of the layer below whose fc2 add is still outstanding; with `defer` this layer leaves
+        its own fc2 add to the layer above and returns such a triple instead of writing `out`."""
         cfg, ctx, t = self.cfg, self._ctx, self.store.tensors
         M, D, Fd, ws, plan = ctx["M"], cfg.embed_dim, cfg.ffn_dim, ctx["ws"], ctx["plan"]
         p = f"encoder.layers.{l}."
@@ -558,18 +565,28 @@ class Engine:
         u16, t16 = ws["u16"], ws["t16"]
         N_tok = ctx["N"]
         d_attn, d_ffn = self._layer_drops(l, N_tok)
-        ops.layernorm_fwd(hin, t[p + "self_attn_layer_norm.weight"], t[p + "self_attn_layer_norm.bias"], u16, st1, M, D)
+        br16 = ws["br16"]
+        if pend is None:
+            ops.layernorm_fwd(hin, t[p + "self_attn_layer_norm.weight"], t[p + "self_attn_layer_norm.bias"], u16, st1, M, D)
+        else:       # hin = hmid(l-1) + drop(fc2 branch of l-1)
+            ops.add_layernorm_fwd(pend[0], pend[1], t[p + "self_attn_layer_norm.weight"], t[p + "self_attn_layer_norm.bias"],
+                                  hin, u16, st1, M, D, drop=pend[2])
         ops.gemm_nt(u16, f16[p + "qkv"].w, qkv, M, 3 * D, D, bias=f16[p + "bqkv"], epilogue=ops.EPI_QKV_HM)   # head-major q|k|v
         ops.dilated_attn_fwd(qkv, plan, obr, lsebr)
         ops.dilated_mix_ln_fwd(obr, lsebr, plan, t[p + "self_attn.inner_attn_ln.weight"], t[p + "self_attn.inner_attn_ln.bias"],
                                u16, stin, lsetot)
-        ops.gemm_nt(u16, f16[p + "out"].w, hmid, M, D, D, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "self_attn.out_proj.bias"],
-                    resid=hin, ldr=D, drop=d_attn)
-        ops.layernorm_fwd(hmid, t[p + "final_layer_norm.weight"], t[p + "final_layer_norm.bias"], u16, st2, M, D)
+        ops.gemm_nt(u16, f16[p + "out"].w, br16, M, D, D, bias=t[p + "self_attn.out_proj.bias"])
+        ops.add_layernorm_fwd(hin, br16, t[p + "final_layer_norm.weight"], t[p + "final_layer_norm.bias"], hmid, u16, st2, M, D,
+                              drop=d_attn)       # hmid = hin + drop(out_proj branch)
         ops.gemm_nt(u16, f16[p + "fc1"].w, a1, M, Fd, D, bias=t[p + "ffn.fc1.bias"])
         ops.layernorm_fwd(a1, t[p + "ffn.ffn_layernorm.weight"], t[p + "ffn.ffn_layernorm.bias"], t16, stf, M, Fd, gelu_in=True)
-        ops.gemm_nt(t16, f16[p + "fc2"].w, out, M, D, Fd, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "ffn.fc2.bias"], resid=hmid, ldr=D,
-                    drop=d_ffn)
+        if defer:
+            ops.gemm_nt(t16, f16[p + "fc2"].w, br16, M, D, Fd, bias=t[p + "ffn.fc2.bias"])
+            nxt = (hmid, br16, d_ffn)
+        else:
+            ops.gemm_nt(t16, f16[p + "fc2"].w, out, M, D, Fd, epilogue=ops.EPI_BIAS_RESID, bias=t[p + "ffn.fc2.bias"], resid=hmid, ldr=D,
+                        drop=d_ffn)
+            nxt = None
 
         # nothing else touches dh between two layers of one interaction block: the lower layer can take fp16(dh) from here
         feeds_lower = all(l != a for a, _ in cfg.interaction_indexes)
@@ -597,6 +614,7 @@ class Engine:
                               dx16=ws["dh16"] if feeds_lower else None, dx16_drop=d_lower_ffn if feeds_lower else None)
             ctx["dh16_valid"] = feeds_lower
         self.tape.record(bwd)
+        return nxt
 
     # ------------------------------------------------------------------ extractor (A.2)
     def _extractor(self, pref: str, c: Var, pe: Param, hout: torch.Tensor) -> Var:

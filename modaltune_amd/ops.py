@@ -107,6 +107,12 @@ def layernorm_fwd(x, w, b, y, stats, M, D, *, ldx=None, xmap=None, ldy=None, yma
                                        _p(stats), M, D, _s()), "layernorm_fwd")
 
 
+def add_layernorm_fwd(x, branch, w, b, h, y, stats, M, D, drop=None):
+    """h = x + drop(branch); y = fp16(LN(h) * w + b) (include/modaltune_hip.h: mt_add_layernorm_fwd)."""
+    check(_lib.load().mt_add_layernorm_fwd(_p(x), _p(branch), _dr(drop), _p(w), _p(b), _p(h), _p(y), _p(stats), M, D, _s()),
+          "add_layernorm_fwd")
+
+
 def layernorm_bwd(dy, x, w, stats, dx, M, D, *, lddy=None, dymap=None, ldx=None, xmap=None, lddx=None, dxmap=None,
                   gelu_in=False, accumulate=False, dw=None, db=None, dx16=None, dx16_drop=None):
     check(_lib.load().mt_layernorm_bwd(_p(dy), lddy if lddy is not None else D, _rm(dymap), _dt(dy), _p(x),
@@ -307,6 +313,7 @@ dilated_mix_ln_fwd = _timed(lambda *a, **k: "dilated_mix_ln_fwd")(dilated_mix_ln
 dilated_mix_ln_bwd = _timed(lambda *a, **k: "dilated_mix_ln_bwd")(dilated_mix_ln_bwd)
 layernorm_fwd = _timed(lambda x, w, b, y, stats, M, D, **k: f"layernorm_fwd[{D}]" if M > 1024 else "token_side")(layernorm_fwd)
 layernorm_bwd = _timed(lambda dy, x, w, stats, dx, M, D, **k: f"layernorm_bwd[{D}]" if M > 1024 else "token_side")(layernorm_bwd)
+add_layernorm_fwd = _timed(lambda x, branch, w, b, h, y, stats, M, D, **k: f"add_layernorm_fwd[{D}]")(add_layernorm_fwd)
 cast_f32_to_f16 = _timed(lambda *a, **k: "cast")(cast_f32_to_f16)
 inject_attn_fwd = _timed(lambda *a, **k: "inject_attn_fwd")(inject_attn_fwd)
 inject_attn_bwd = _timed(lambda *a, **k: "inject_attn_bwd")(inject_attn_bwd)

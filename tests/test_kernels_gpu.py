@@ -733,6 +733,21 @@ def test_dropout_masks_statistics_determinism_and_consistency(ops):
     torch.cuda.synchronize()
     assert torch.equal(acc_a, acc_b)                         # the fp32 stream is not masked
     assert torch.equal(d16_drop, (acc_b * mask).half())
+    # the residual add riding on the next LayerNorm: h = resid + drop(branch), y = LN(h) -- same mask again
+    br16 = torch.randn(M, D, generator=gen).half().to(DEV)
+    lb = (0.1 * torch.randn(D, generator=gen)).to(DEV)
+    for sp, mk in ((None, torch.ones_like(mask)), (spec, mask)):
+        h = torch.zeros(M, D, device=DEV)
+        y2 = torch.zeros(M, D, dtype=torch.float16, device=DEV)
+        st2 = torch.zeros(M, 2, device=DEV)
+        ops.add_layernorm_fwd(resid, br16, w, lb, h, y2, st2, M, D, drop=sp)
+        torch.cuda.synchronize()
+        href = resid + br16.float() * mk
+        assert rel(h, href) < 1e-6
+        ref = torch.nn.functional.layer_norm(href.double(), (D,), w.double(), lb.double(), 1e-5)
+        assert rel(y2, ref) < 2e-3
+        assert rel(st2[:, 0], href.double().mean(-1)) < 1e-5
+        assert rel(st2[:, 1], 1.0 / torch.sqrt(href.double().var(-1, unbiased=False) + 1e-5)) < 1e-5
 
 
 def test_gene_snn_alpha_dropout(ops):
