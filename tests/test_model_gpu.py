@@ -74,6 +74,51 @@ def test_train_step_matches_reference_golden(golden_dir, name):
             assert err < 4e-2, (k, err)      # (cancellation-heavy small tensors, e.g. pathway_compression.weight, sit at 2-3 %)
 
 
+@pytest.mark.parametrize("L", [1, 2, 7, 63, 129])
+def test_tiny_bags_against_the_oracle(L):
+    """Edge sizes the fixtures do not hold: a single patch (N = 2: every dilated branch degenerates to one or two keys,
+    most of each sparse sequence is padding), bags below one 64-key tile, one row past a tile.  Reference: the fp64
+    oracle (pinned to the reference's golden vectors in test_oracle_golden.py) on the same seeded inputs."""
+    from modaltune_amd.config import segment_lengths
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    from oracle import modaltune_oracle as O
+    seed, ngrids = 300 + L, 16
+    sizes = synth.toy_group_sizes()
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)), slide_ngrids=ngrids)
+    cfg.validate()
+    sd_np = synth.synth_state_dict(cfg, sizes, seed)
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    # oracle (fp64, CPU)
+    F64 = torch.float64
+    sd = {k: torch.from_numpy(v).to(F64) for k, v in sd_np.items()}
+    psd = {k: torch.from_numpy(v).to(F64) for k, v in synth.projector_state(seed).items()}
+    ref_logits, ref_loss, ref_grads = O.train_step_loss_and_grads(
+        sd, cfg, synth.trainable_keys(cfg, sizes), torch.from_numpy(inp["x"]).to(F64), torch.from_numpy(inp["coords"]).to(F64),
+        [torch.from_numpy(a).to(F64) for a in inp["genes"]], torch.from_numpy(inp["text"]).to(F64), psd, segment_lengths())
+    # HIP
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(sd_np)
+    ts = TrainStep(eng)
+    ts.set_projector(synth.projector_state(seed))
+    loss = ts.step(torch.from_numpy(inp["x"]).cuda(), inp["coords"], [torch.from_numpy(a).cuda() for a in inp["genes"]],
+                   torch.from_numpy(inp["text"]), update=False)
+    torch.cuda.synchronize()
+    assert int(ts.found_inf) == 0
+    assert _rel(ts.last_logits.cpu().numpy(), ref_logits.numpy()) < 1e-3
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    grads = ts.unscaled_grads()
+    ref_max = max(float(v.norm()) for v in ref_grads.values())
+    bad = []
+    for n, r in ref_grads.items():
+        o, rn = float(grads[n].double().norm()), float(r.norm())
+        # (L = 1: softmax over a single patch is exactly 1, so the extractor's query-side gradients are exactly zero in
+        # fp64 and rounding noise, ~1e-5 of the largest gradient, here: hence the absolute term)
+        if abs(o - rn) > 2e-2 * rn + 1e-4 * ref_max:
+            bad.append((n, o, rn))
+    assert not bad, (ref_max, bad[:10])
+
+
 def test_optimizer_step_matches_oracle_adamw(golden_dir):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
