@@ -179,6 +179,61 @@ def test_sgemm_small(ops):
     assert rel(db, db0.double() + dy.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(195, 192, 768), (195, 768, 192), (192, 768, 195), (6, 3, 256), (3, 256, 6), (1, 4992, 3),
+                                   (17, 33, 1), (64, 64, 64), (16, 16, 1024), (195, 192, 200)])
+@pytest.mark.parametrize("layout", ["nt", "tn", "nn"])
+def test_sgemm_small_shapes_and_strides(ops, M, N, K, layout):
+    """The fp32-MFMA token-side GEMM over the shapes the step launches: k-contiguous operands (16-byte loads),
+    transposed operands (the dW products), ragged M / N / K (the k range is split over four waves in multiples of 16),
+    K below one MFMA k-block, rowsum rider on every layout."""
+    g = rng(M * 1000 + N * 10 + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(N, K, generator=g)
+    Ad = (A if layout != "tn" else A.t().contiguous()).to(DEV)            # tn: A stored [K, M]
+    Bd = (Bm if layout == "nt" else Bm.t().contiguous()).to(DEV)          # tn / nn: B stored [K, N]
+    a_str = (K, 1) if layout != "tn" else (1, M)
+    b_str = (K, 1) if layout == "nt" else (1, N)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    rs0 = torch.randn(M, generator=g)
+    rs = rs0.to(DEV).clone()
+    ops.sgemm(Ad, a_str, Bd, b_str, out, (N, 1), M, N, K, rowsum=rs)
+    torch.cuda.synchronize()
+    ref = A.double() @ Bm.double().t()
+    assert float((out.double().cpu() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert float((rs.double().cpu() - (rs0.double() + A.double().sum(1))).abs().max()) < 1e-4
+
+
+def test_pack_weights_grouped_and_broadcast_add(ops):
+    """mt_pack_weights_f16 (all trainable fp16 caches in one launch: stored + transposed copies, row offsets of a
+    concatenated cache, ragged 32x32 tiles) and mt_axpy_bcast."""
+    g = rng(11)
+    srcs = [torch.randn(192, 768, generator=g), torch.randn(192, 768, generator=g), torch.randn(768, 192, generator=g),
+            torch.randn(50, 70, generator=g)]
+    dev = [t.to(DEV) for t in srcs]
+    kv_w = torch.zeros(384, 768, dtype=torch.float16, device=DEV)
+    kv_t = torch.zeros(768, 384, dtype=torch.float16, device=DEV)
+    o_w = torch.zeros(768, 192, dtype=torch.float16, device=DEV)
+    o_t = torch.zeros(192, 768, dtype=torch.float16, device=DEV)
+    r_w = torch.zeros(50, 70, dtype=torch.float16, device=DEV)
+    recs = [[dev[0].data_ptr(), kv_w.data_ptr(), kv_t.data_ptr(), 192, 768, 0, 768, 384],
+            [dev[1].data_ptr(), kv_w.data_ptr(), kv_t.data_ptr(), 192, 768, 192, 768, 384],
+            [dev[2].data_ptr(), o_w.data_ptr(), o_t.data_ptr(), 768, 192, 0, 192, 768],
+            [dev[3].data_ptr(), r_w.data_ptr(), 0, 50, 70, 0, 70, 0]]
+    table = torch.tensor(recs, dtype=torch.int64, device=DEV)
+    ops.pack_weights(table, len(recs))
+    torch.cuda.synchronize()
+    kv = torch.cat([srcs[0], srcs[1]]).half()
+    assert torch.equal(kv_w.cpu(), kv) and torch.equal(kv_t.cpu(), kv.t())
+    assert torch.equal(o_w.cpu(), srcs[2].half()) and torch.equal(o_t.cpu(), srcs[2].half().t())
+    assert torch.equal(r_w.cpu(), srcs[3].half())
+    a = torch.randn(3, 65, 768, generator=g)
+    pe = torch.randn(65, 768, generator=g)
+    y = torch.zeros(3, 65, 768, device=DEV)
+    ops.axpy_bcast(a.to(DEV), pe.to(DEV), 1.0, y, 65 * 768)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), a + pe)
+
+
 # ------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("D", [256, 768, 2304, 3072])
 def test_layernorm_fwd_bwd_f32(ops, D):
