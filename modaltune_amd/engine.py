@@ -291,8 +291,8 @@ class Engine:
         if fresh:
             self.tape = Tape(self.device)
         tape = self.tape
-        tape.reset()
         tape.grad_enabled = need_grad
+        tape.reset()
         self._drop_now = bool(self.stochastic and need_grad)
         self._ext_calls = 0
         if fresh and self._drop_now:     # several forwards may precede one backward (TM:175-177): the masks of a call are

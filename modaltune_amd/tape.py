@@ -80,7 +80,7 @@ class Tape:
         if need > 0 and (self._arena is None or need > self._arena.numel()):
             self._arena = torch.empty(need + need // 4 + 1024, device=self.device, dtype=torch.float32)
         self._arena_used = self._arena_miss = 0
-        if self._arena is not None:
+        if self._arena is not None and self.grad_enabled:      # forward-only passes allocate no gradients
             self._arena.zero_()
 
     def zeros_like(self, t: torch.Tensor) -> torch.Tensor:
