@@ -539,10 +539,11 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 // sweeping the queries of the same sparse sequence in tiles of 64.
 //   S[q,key]  = Q . K^T            Q rows from LDS, K^T in registers
 //   dP[q,key] = dO . V^T           dO rows from LDS, V^T in registers
-//   P' = exp2(c S - L2[q] + log2(scale)) ; dS = P' (dP - delta[q])        (P' = P~ / sqrt(48))
+//   P' = exp2(c S - L2[q] + log2(scale)) ; dS = P' (dP - delta[q])        (P' = P~ / sqrt(48); c rides on K)
 //   dV^T[d,key] += dO^T[d,q] . P'  (rescaled by sqrt(48) once at the end) ; dK^T[d,key] += Q^T[d,q] . dS
-// LDS holds (-L2 + log2 scale) / c and -delta per query; they are read straight into the S / dP accumulators before the
-// MFMA chains, so the elementwise block is 2 packed mul, 2 exp and 2 packed converts per element pair.
+// LDS holds -L2 + log2 scale and -delta per query; they are read straight into the S / dP accumulators before the
+// MFMA chains, and the K fragments carry the softmax scale, so the elementwise block is 1 packed mul, 2 exp and 2 packed
+// converts per element pair.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
@@ -559,7 +560,6 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
   const float c = 0.14433756729740643f * LOG2E;
-  const f32x2 c2 = {c, c};
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   // padded keys get no gradient; padded queries have P' = 0: neither is computed
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
@@ -579,6 +579,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   for (int ks = 0; ks < 3; ++ks) {
     kf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, H + w.h, krow) + ks * 16 + hh * 8));
     vf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, 2 * H + w.h, krow) + ks * 16 + hh * 8));
+    // the softmax scale (in log2 units) rides on this lane's K fragment, which is only ever used for S: one multiply
+    // per WORKGROUP instead of one per score element (S' = Q . (c K)^T is the exp2 argument as it leaves the MFMA chain)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kf[ks][e] = (h16)((float)kf[ks][e] * c);
   }
 
   const StageIdx st(tid);
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     }
     if (tid < 64) {      // padded / out-of-range queries contribute nothing: -L2 = -big -> P' = 0
       const bool ok = FULL || ok2;
-      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) * (1.0f / c) : -1.0e30f;
+      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) : -1.0e30f;
       Dls[tid] = ok ? -rdl : 0.f;
     }
   };
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
       h16x8 pf[2], dsf[2];
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        const f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]} * c2);
+        const f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]});
         const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
         pf[i >> 3][i & 7] = (h16)pt[0]; pf[i >> 3][(i & 7) + 1] = (h16)pt[1];
         dsf[i >> 3][i & 7] = (h16)d[0]; dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
