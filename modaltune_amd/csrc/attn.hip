@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   const int nproc = (nv + 63) >> 6;      // tiles holding at least one real key
   // tiles [0, nfull) hold only real rows: loaded with a uniform base + constant 32-bit lane offset, no clamp, no select
   const int nfull = nv >> 6;
-  const h16* kbase = hm_ptr(qkv, M, H + w.h, sq.row(0));
-  const h16* vbase = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc(hm_ptr(qkv, M, H + w.h, sq.row(0)));
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc(hm_ptr(qkv, M, 2 * H + w.h, sq.row(0)));
   const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
   const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
   h16x8 rk0, rk1, rv0, rv1;
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   auto gload_k = [&](int t, auto full_tag) {
     const int kb = t * 64;
     if (decltype(full_tag)::value) {
-      const h16* b = kbase + (long)kb * sq.dr * HD;
-      rk0 = ldg8_off(b, c0); rk1 = ldg8_off(b, c1);
+      const uint32_t adv = (uint32_t)(kb * sq.dr * HD) * 2u;
+      rk0 = buf_ldg8(krs, c0, adv); rk1 = buf_ldg8(krs, c1, adv);
     } else {
       const int i0 = kb + st.row0, i1 = kb + st.row1;
       rk0 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   auto gload_v = [&](int t, auto full_tag) {
     const int kb = t * 64;
     if (decltype(full_tag)::value) {
-      const h16* b = vbase + (long)kb * sq.dr * HD;
-      rv0 = ldg8_off(b, c0); rv1 = ldg8_off(b, c1);
+      const uint32_t adv = (uint32_t)(kb * sq.dr * HD) * 2u;
+      rv0 = buf_ldg8(vrs, c0, adv); rv1 = buf_ldg8(vrs, c1, adv);
     } else {
       const int i0 = kb + st.row0, i1 = kb + st.row1;
       rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const StageIdx st(tid);
   const int ntile = (nv + 63) >> 6;      // tiles holding at least one real key
   const int nfull = nv >> 6;             // tiles [0, nfull) hold only real rows
-  const h16* kbase = hm_ptr(qkv, M, H + w.h, sq.row(0));
-  const h16* vbase = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc(hm_ptr(qkv, M, H + w.h, sq.row(0)));
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc(hm_ptr(qkv, M, 2 * H + w.h, sq.row(0)));
   const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
   const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
   h16x8 rk0, rk1, rv0, rv1;
@@ -440,9 +440,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   auto gload = [&](int t, auto full_tag) {      // first touched in lstore() (latency hides under the MFMAs)
     const int kb = t * 64;
     if (decltype(full_tag)::value) {
-      const long adv = (long)kb * sq.dr * HD;
-      rk0 = ldg8_off(kbase + adv, c0); rv0 = ldg8_off(vbase + adv, c0);
-      rk1 = ldg8_off(kbase + adv, c1); rv1 = ldg8_off(vbase + adv, c1);
+      const uint32_t adv = (uint32_t)(kb * sq.dr * HD) * 2u;
+      rk0 = buf_ldg8(krs, c0, adv); rv0 = buf_ldg8(vrs, c0, adv);
+      rk1 = buf_ldg8(krs, c1, adv); rv1 = buf_ldg8(vrs, c1, adv);
     } else {      // ragged tile: clamped rows, zeroed by a select in lstore()
       const int i0 = kb + st.row0, i1 = kb + st.row1;
       const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1);
@@ -588,10 +588,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   const StageIdx st(tid);
   const int ntile = (nv + 63) >> 6;      // tiles holding at least one real query
   const int nfull = nv >> 6;             // tiles [0, nfull) hold only real rows
-  const h16* qbase = hm_ptr(qkv, M, w.h, sq.row(0));
-  const h16* dbase = hm_ptr(dmixed, M, w.h, sq.row(0));
-  const float* lbase = lse_tot + sq.row(0) * H + w.h;
-  const float* dlbase = delta_br + ((long)w.br * M + sq.row(0)) * H + w.h;
+  const __amdgpu_buffer_rsrc_t qrs = make_rsrc(hm_ptr(qkv, M, w.h, sq.row(0)));
+  const __amdgpu_buffer_rsrc_t drs = make_rsrc(hm_ptr(dmixed, M, w.h, sq.row(0)));
+  const __amdgpu_buffer_rsrc_t lrs = make_rsrc(lse_tot + sq.row(0) * H + w.h);
+  const __amdgpu_buffer_rsrc_t dlrs = make_rsrc(delta_br + ((long)w.br * M + sq.row(0)) * H + w.h);
   const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
   const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
   const uint32_t cl = (uint32_t)(lane * sq.dr * H) * 4u;
@@ -601,10 +601,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   auto gload = [&](int t, auto full_tag) {      // first touched in lstore()
     const int qb = t * 64;
     if (decltype(full_tag)::value) {
-      const long adv = (long)qb * sq.dr * HD, advl = (long)qb * sq.dr * H;
-      rq0 = ldg8_off(qbase + adv, c0); rd0 = ldg8_off(dbase + adv, c0);
-      rq1 = ldg8_off(qbase + adv, c1); rd1 = ldg8_off(dbase + adv, c1);
-      rl2 = ldf_off(lbase + advl, cl); rdl = ldf_off(dlbase + advl, cl);
+      const uint32_t adv = (uint32_t)(qb * sq.dr * HD) * 2u, advl = (uint32_t)(qb * sq.dr * H) * 4u;
+      rq0 = buf_ldg8(qrs, c0, adv); rd0 = buf_ldg8(drs, c0, adv);
+      rq1 = buf_ldg8(qrs, c1, adv); rd1 = buf_ldg8(drs, c1, adv);
+      rl2 = buf_ldf(lrs, cl, advl); rdl = buf_ldf(dlrs, cl, advl);
     } else {      // ragged tile: clamped rows, neutralised in lstore()
       const int i0 = qb + st.row0, i1 = qb + st.row1, i2 = qb + lane;
       const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1), r2 = sq.row_clamped(i2);

@@ -139,6 +139,20 @@ MT_DEVINL h16x8 ldg8_off(const h16* base, uint32_t byte_off) {
 MT_DEVINL float ldf_off(const float* base, uint32_t byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// Full tiles go through BUFFER loads: resource = the sparse sequence's (wave-uniform) base, voffset = the lane's constant
+// 32-bit byte offset, soffset = the tile's advance in an SGPR -- no per-lane address arithmetic at all (with global
+// loads the loop-strength reducer kept one 64-bit pointer per load and lane: 11 v_lshl_add_u64 per tile in the dK/dV
+// kernel).  Offsets stay far below 2^31 (a sparse sequence spans at most N rows of 96 B x dilation).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+MT_DEVINL __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+MT_DEVINL h16x8 buf_ldg8(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+MT_DEVINL float buf_ldf(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 MT_DEVINL f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 MT_DEVINL f32x2 pk_exp2(f32x2 a) { return (f32x2){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])}; }
 
