@@ -548,10 +548,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
                                                                   Plan p, h16* __restrict__ ws) {
-  __shared__ __attribute__((aligned(16))) h16 Qs[64 * KSTR];
-  __shared__ __attribute__((aligned(16))) h16 Qt[64 * VSTR];
-  __shared__ __attribute__((aligned(16))) h16 Ds[64 * KSTR];
-  __shared__ __attribute__((aligned(16))) h16 Dt[64 * VSTR];
+  __shared__ __attribute__((aligned(16))) h16 Qx[64 * VSTR];      // swizzled images (attn_common.h: swz), each read both ways
+  __shared__ __attribute__((aligned(16))) h16 Dx[64 * VSTR];
   __shared__ __attribute__((aligned(16))) float L2s[64];
   __shared__ __attribute__((aligned(16))) float Dls[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -565,9 +563,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
   if (w.qt * 128 >= nv) return;
 
-  if (tid < 64) {
-    *reinterpret_cast<h16x8*>(&Qt[tid * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Qt[tid * VSTR + 56]) = zero8;
-    *reinterpret_cast<h16x8*>(&Dt[tid * VSTR + 48]) = zero8; *reinterpret_cast<h16x8*>(&Dt[tid * VSTR + 56]) = zero8;
+  if (tid < 64) {      // the zero columns d = 48..63 (logical chunks 6, 7), written once
+    *reinterpret_cast<h16x8*>(&Qx[swz(tid, 6)]) = zero8; *reinterpret_cast<h16x8*>(&Qx[swz(tid, 7)]) = zero8;
+    *reinterpret_cast<h16x8*>(&Dx[swz(tid, 6)]) = zero8; *reinterpret_cast<h16x8*>(&Dx[swz(tid, 7)]) = zero8;
   }
 
   // this lane's key: K^T / V^T fragments (B operands), element j of k-step ks = K[key][16 ks + 8 hh + j]
@@ -614,19 +612,16 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
       ok0 = sq.valid(i0); ok1 = sq.valid(i1); ok2 = sq.valid(i2);
     }
   };
+  const int sw0 = swz(st.row0, st.part0), sw1 = swz(st.row1, st.part1);      // staging slots in the swizzled images
   auto lstore = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     const h16x8 q0 = FULL ? rq0 : sel8(ok0, rq0), d0 = FULL ? rd0 : sel8(ok0, rd0);
-    *reinterpret_cast<h16x8*>(&Qs[st.row0 * KSTR + st.part0 * 8]) = q0;
-    *reinterpret_cast<h16x8*>(&Qt[st.row0 * VSTR + st.part0 * 8]) = q0;
-    *reinterpret_cast<h16x8*>(&Ds[st.row0 * KSTR + st.part0 * 8]) = d0;
-    *reinterpret_cast<h16x8*>(&Dt[st.row0 * VSTR + st.part0 * 8]) = d0;
+    *reinterpret_cast<h16x8*>(&Qx[sw0]) = q0;
+    *reinterpret_cast<h16x8*>(&Dx[sw0]) = d0;
     if (st.has1) {
       const h16x8 q1 = FULL ? rq1 : sel8(ok1, rq1), d1 = FULL ? rd1 : sel8(ok1, rd1);
-      *reinterpret_cast<h16x8*>(&Qs[st.row1 * KSTR + st.part1 * 8]) = q1;
-      *reinterpret_cast<h16x8*>(&Qt[st.row1 * VSTR + st.part1 * 8]) = q1;
-      *reinterpret_cast<h16x8*>(&Ds[st.row1 * KSTR + st.part1 * 8]) = d1;
-      *reinterpret_cast<h16x8*>(&Dt[st.row1 * VSTR + st.part1 * 8]) = d1;
+      *reinterpret_cast<h16x8*>(&Qx[sw1]) = q1;
+      *reinterpret_cast<h16x8*>(&Dx[sw1]) = d1;
     }
     if (tid < 64) {      // padded / out-of-range queries contribute nothing: -L2 = -big -> P' = 0
       const bool ok = FULL || ok2;
@@ -639,6 +634,13 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  // per-lane offsets into the swizzled images (the sub / s2 row-block offsets are multiples of 4 rows x 4: they leave the
+  // swizzle term unchanged and stay immediate): row reads of chunk 2 ks + hh, transposed reads of rows 4 hh + tq (a) and
+  // + 8 (b), column blocks d 0..31 (0) and 32..63 (1)
+  const int rrd[3] = {swz(l31, hh), swz(l31, 2 + hh), swz(l31, 4 + hh)};
+  const int trc = 2 * (grp & 1) + (tp >> 1), tro = 4 * (tp & 1);
+  const int tr_a0 = swz(4 * hh + tq, trc) + tro, tr_a1 = swz(4 * hh + tq, trc + 4) + tro;
+  const int tr_b0 = swz(4 * hh + tq + 8, trc) + tro, tr_b1 = swz(4 * hh + tq + 8, trc + 4) + tro;
   // cur_tag: tile t (in registers) is a full tile; next_tag: tile t + 1 is
   auto tile = [&](int t, auto cur_tag, auto next_tag) {
     __syncthreads();            // previous tile fully consumed
@@ -659,9 +661,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
       }
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qs[(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qx[sub * 32 * VSTR + rrd[ks]]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s, 0, 0, 0);
-        const h16x8 da = *reinterpret_cast<const h16x8*>(&Ds[(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        const h16x8 da = *reinterpret_cast<const h16x8*>(&Dx[sub * 32 * VSTR + rrd[ks]]);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp, 0, 0, 0);
       }
       h16x8 pf[2], dsf[2];
@@ -674,13 +676,13 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int roff = (sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp;
-        const h16x8 d0 = cat8(lds_tr4(&Dt[roff]), lds_tr4(&Dt[roff + 8 * VSTR]));
-        const h16x8 d1 = cat8(lds_tr4(&Dt[roff + 32]), lds_tr4(&Dt[roff + 8 * VSTR + 32]));
+        const int rb = (sub * 32 + s2 * 16) * VSTR;      // rows rb + 4 hh + tq and + 8; cols d 0..31 / 32..63
+        const h16x8 d0 = cat8(lds_tr4(&Dx[rb + tr_a0]), lds_tr4(&Dx[rb + tr_b0]));
+        const h16x8 d1 = cat8(lds_tr4(&Dx[rb + tr_a1]), lds_tr4(&Dx[rb + tr_b1]));
         dv0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, pf[s2], dv0, 0, 0, 0);
         dv1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, pf[s2], dv1, 0, 0, 0);
-        const h16x8 q0 = cat8(lds_tr4(&Qt[roff]), lds_tr4(&Qt[roff + 8 * VSTR]));
-        const h16x8 q1 = cat8(lds_tr4(&Qt[roff + 32]), lds_tr4(&Qt[roff + 8 * VSTR + 32]));
+        const h16x8 q0 = cat8(lds_tr4(&Qx[rb + tr_a0]), lds_tr4(&Qx[rb + tr_b0]));
+        const h16x8 q1 = cat8(lds_tr4(&Qx[rb + tr_a1]), lds_tr4(&Qx[rb + tr_b1]));
         dk0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, dsf[s2], dk0, 0, 0, 0);
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, dsf[s2], dk1, 0, 0, 0);
       }

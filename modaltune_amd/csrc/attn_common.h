@@ -100,6 +100,13 @@ MT_DEVINL WorkItem decode_branch(const Plan& p, int br, int bid) {
   return w;
 }
 
+// ONE LDS image of a 64-row x 48-col fp16 tile that serves both the row reads (ds_read_b128: A fragments of Q . K^T
+// style products) and the transposed reads (ds_read_b64_tr_b16: A fragments of Q^T . dS style products): rows of VSTR
+// halves (48 dwords: the four rows of a transposed read land 16 banks apart), and the 16-byte chunk c of row r stored
+// at chunk c ^ ((r >> 2) & 3) so that the 16 rows of a ds_read_b128 lane group, which share c, spread over all 64 banks.
+// Both patterns are conflict-free (checked exhaustively); chunks 6 and 7 of every row hold the zeros read as d = 48..63.
+MT_DEVINL int swz(int row, int chunk) { return row * VSTR + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
 MT_DEVINL h16x4 lds_tr4(const h16* p) {
   s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)p);
