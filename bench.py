@@ -52,7 +52,7 @@ def cpu_baseline_leg(cfg, sizes, L, seed, max_seconds=20.0):
 
 # HBM bytes per launch of the dominant kernel from PMC passes that cannot run inside this script (separate rocprofv3
 # runs, one counter per pass): {(patches, tokens): bytes}.  FETCH_SIZE 373 139 KB, WRITE_SIZE 174 393 KB at L = 10 000.
-RECORDED_KV_TRAFFIC = {(10000, 65): 2 * 332889 * 1024 + 174393 * 1024}
+RECORDED_KV_TRAFFIC = {(10000, 65): 2 * 331608 * 1024 + 174393 * 1024}
 
 
 def main():
