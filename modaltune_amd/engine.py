@@ -117,7 +117,8 @@ class Engine:
         self.pos_table = torch.from_numpy(sincos_1d_table(cfg.slide_ngrids, cfg.embed_dim // 2)).to(self.device)
         self._frozen16: Dict[str, _W16] = {}
         self._train16: Dict[str, _W16] = {}
-        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}          # (B, L) -> views of the flat storage
+        self._ws_store: Dict[int, dict] = {}                          # B -> {cap, flat buffers}
         self._caches_ready = False
         self.collect_taps = False      # tests: keep cls / token states after every interaction block
         self.taps: Dict[str, torch.Tensor] = {}
@@ -217,54 +218,61 @@ class Engine:
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, B: int, L: int, fresh: bool = False) -> Dict[str, torch.Tensor]:
+        """Activation / gradient buffers of one (B, L) geometry.  Bags are ragged (one slide per step, any L): the
+        storage is ONE set of flat buffers sized for the largest bag seen so far (grown by >= 25 % when a bigger one
+        arrives) and each geometry gets views of their heads -- no allocator traffic per step, no growth with the number
+        of distinct lengths.  fresh=True (module API: several forwards alive at once) allocates privately."""
         key = (B, L)
         if not fresh and key in self._ws:
             return self._ws[key]
-        if not fresh:
-            self._ws.clear()      # one resident geometry at a time
         cfg, dev = self.cfg, self.device
-        N, D, Fd, E = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim
-        M, Mp = B * N, B * L
+        D, Fd = cfg.embed_dim, cfg.ffn_dim
         nb = len(self.seg_lengths)
-        e16 = lambda *s: torch.empty(*s, dtype=H16, device=dev)
-        e32 = lambda *s: torch.empty(*s, dtype=F32, device=dev)
-        w: Dict[str, torch.Tensor] = {}
-        w["x16"] = e16(L, cfg.in_chans)
-        w["x0"] = e32(L, D)
-        if self.stochastic:
-            w["x0d"] = e32(B * L, D)          # per-pass input dropout (ENC:339) of the shared patch embedding
-        w["prow"] = torch.empty(L, dtype=torch.int32, device=dev)
-        w["pcol"] = torch.empty(L, dtype=torch.int32, device=dev)
-        nint = len(cfg.interaction_indexes)
-        for l in range(cfg.depth):
-            w[f"hin{l}"] = e32(M, D)
-            w[f"hmid{l}"] = e32(M, D)
-            w[f"qkv{l}"] = e16(M, 3 * D)
-            w[f"obr{l}"] = e16(nb, M, D)
-            w[f"lsebr{l}"] = e32(nb, M, 16)
-            w[f"lsetot{l}"] = e32(M, 16)
-            w[f"a1_{l}"] = e16(M, Fd)
-            for s in ("st1", "stin", "st2", "stf"):
-                w[f"{s}_{l}"] = e32(M, 2)
-        for i in range(nint):
-            w[f"hout{i}"] = e32(M, D)
-        # transients shared by all layers
-        w["u16"] = e16(M, D)
-        w["br16"] = e16(M, D)
-        w["t16"] = e16(M, Fd)
-        w["dh"] = e32(M, D)
-        w["dy16"] = e16(M, D)
-        w["dh16"] = e16(M, D)
-        w["dt16"] = e16(M, Fd)
-        w["da1"] = e16(M, Fd)
-        w["dmixed"] = e16(M, D)
-        w["delta"] = e32(nb, M, 16)
-        plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
-        w["attn_ws"] = torch.empty(ops.dilated_attn_bwd_workspace_bytes(plan) // 2, dtype=H16, device=dev)
-        w["dqkv16"] = e16(M, 3 * D)
-        w["scratch32"] = e32(Mp, D)
-        if not fresh:
-            self._ws[key] = w
+
+        def spec(Lx):       # name -> (dtype, shape) at bag length Lx
+            N = Lx + 1
+            M, Mp = B * N, B * Lx
+            sp = {"x16": (H16, (Lx, cfg.in_chans)), "x0": (F32, (Lx, D)), "prow": (torch.int32, (Lx,)), "pcol": (torch.int32, (Lx,))}
+            if self.stochastic:
+                sp["x0d"] = (F32, (B * Lx, D))      # per-pass input dropout (ENC:339) of the shared patch embedding
+            for l in range(cfg.depth):
+                sp[f"hin{l}"] = (F32, (M, D)); sp[f"hmid{l}"] = (F32, (M, D)); sp[f"qkv{l}"] = (H16, (M, 3 * D))
+                sp[f"obr{l}"] = (H16, (nb, M, D)); sp[f"lsebr{l}"] = (F32, (nb, M, 16)); sp[f"lsetot{l}"] = (F32, (M, 16))
+                sp[f"a1_{l}"] = (H16, (M, Fd))
+                for st in ("st1", "stin", "st2", "stf"):
+                    sp[f"{st}_{l}"] = (F32, (M, 2))
+            for i in range(len(cfg.interaction_indexes)):
+                sp[f"hout{i}"] = (F32, (M, D))
+            # transients shared by all layers
+            for nm in ("u16", "br16", "dy16", "dh16", "dmixed"):
+                sp[nm] = (H16, (M, D))
+            for nm in ("t16", "dt16", "da1"):
+                sp[nm] = (H16, (M, Fd))
+            sp["dh"] = (F32, (M, D)); sp["delta"] = (F32, (nb, M, 16)); sp["dqkv16"] = (H16, (M, 3 * D))
+            sp["scratch32"] = (F32, (Mp, D))
+            plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
+            sp["attn_ws"] = (H16, (ops.dilated_attn_bwd_workspace_bytes(plan) // 2,))
+            return sp
+
+        def numel(shape):
+            n = 1
+            for d in shape:
+                n *= d
+            return n
+
+        if fresh:
+            return {k: torch.empty(shape, dtype=dt, device=dev) for k, (dt, shape) in spec(L).items()}
+        store = self._ws_store.get(B)
+        if store is None or L > store["cap"] or (self.stochastic and "x0d" not in store["flat"]):
+            cap = L if store is None else max(L, store["cap"] + store["cap"] // 4)
+            self._ws_store.pop(B, None)
+            self._ws.clear()              # views of the old storage die with it
+            store = {"cap": cap, "flat": {k: torch.empty(numel(shape), dtype=dt, device=dev) for k, (dt, shape) in spec(cap).items()}}
+            self._ws_store[B] = store
+        if len(self._ws) > 64:
+            self._ws.clear()
+        w = {k: store["flat"][k][:numel(shape)].view(shape) for k, (dt, shape) in spec(L).items()}
+        self._ws[key] = w
         return w
 
     # ------------------------------------------------------------------ forward
