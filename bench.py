@@ -2,28 +2,90 @@
 """bench.py — slides/sec of the Modal-Adapter train step (BASELINE.json metric) on N MI355X.
 
 A "step" = one slide exactly as train_modaltune.py:195-240: frozen text projector, 3 task passes of the full
-model (frozen 12-layer LongNet backbone + Modal Adapter), KL distillation loss, backward, gradient all-reduce
-(N > 1), AdamW.  Inputs are synthetic and resident in HBM before the timed region.  One JSON line on rank 0.
+model (frozen 12-layer LongNet backbone + Modal Adapter), KL distillation loss, backward, bucketed gradient
+all-reduce started from inside the backward (N > 1), AdamW.  Inputs are synthetic and resident in HBM before the
+timed region.  One JSON line on rank 0.
+
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself: N fresh child processes
+(one per GPU, rendezvous on 127.0.0.1) are spawned BEFORE this process touches the GPU; under torchrun (RANK /
+WORLD_SIZE set) the process is one of the ranks.
 """
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0             # HBM3E spec (MI355X_MICROARCH.md; 6.3 TB/s is what a copy kernel reaches)
+# the reference itself, timed where it can be imported (BASELINE.md §2: the survey/build container, 8 cores)
+CPU_REFERENCE = {"value": 0.0054, "unit": "slides/s", "cores": 8, "kind": "reference",
+                 "sample": "BASELINE.md §2: reference modules (fp32, dropout 0, aten CPU flash stand-in), 1 timed step at L = 10 000 on the "
+                           "8-core build container: 185.6 s/slide (the reference cannot travel to the GPU box)"}
+# rocprofv3 --pmc passes of the dominant kernel cannot run inside this script (one counter group per run, gpurun refuses
+# tracing + PMC together): the committed summary file is parsed at run time instead of a literal
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_attn_bwd.txt")
+PMC_TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r01_pmc_hbm_attn_bwd.txt")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--patches", type=int, default=10000)
+    ap.add_argument("--pathways", default="6", help="number of toy pathways (sizes 5, 6, ...) or 'real': the reference's 331-pathway "
+                                                    "grouping sizes (tests/golden/pathway_sizes_331.json)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="run the step with Dropout / DropPath off (the parity configuration); "
+                                                             "default: on, as model.train() leaves them in the reference")
+    ap.add_argument("--kernel-times", action="store_true", help="print the per-kernel time table (stderr)")
+    ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--ragged", action="store_true", help="a different bag length every step (8 lengths in [0.5, 1] x --patches): "
+                                                          "the steady state of real data; runs the eager schedule")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """Self-launch: spawn --gpus fresh rank processes before any GPU call in this one; relay rank 0's JSON line."""
+    import torch      # (importing torch and counting devices does not initialise the GPU)
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    if n > ndev and args.backend == "nccl":
+        raise RuntimeError(f"--gpus {n} with the RCCL backend needs {n} GPUs, found {ndev} (rehearse with --backend gloo)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
 
 
 def cpu_baseline_leg(cfg, sizes, L, seed, max_seconds=20.0):
     """Times the CPU oracle (a port of the reference arithmetic, fp32, all host cores) on a bounded sample of the
     workload: ONE frozen LongNet layer forward+backward at N = L+1 tokens, 1 task pass; a slide step is 36 such
     layer passes (3 tasks x 12 layers; >= 98 % of the step FLOPs) -> slides/s = 1 / (36 t)."""
+    import torch
     from oracle import modaltune_oracle as O     # CPU baseline leg: the oracle as the thing timed, nothing else
     from modaltune_amd import synth
     from modaltune_amd.config import segment_lengths
@@ -50,32 +112,80 @@ def cpu_baseline_leg(cfg, sizes, L, seed, max_seconds=20.0):
                       f"step = 36 layer passes (3 tasks x 12 layers) -> {36 * t:.1f} s/slide"}
 
 
-# HBM bytes per launch of the dominant kernel from PMC passes that cannot run inside this script (separate rocprofv3
-# runs, one counter per pass): {(patches, tokens): bytes}.  FETCH_SIZE 373 139 KB, WRITE_SIZE 174 393 KB at L = 10 000.
-RECORDED_KV_TRAFFIC = {(10000, 65): 2 * 331608 * 1024 + 174393 * 1024}
+def recorded_traffic(kernel: str, L: int, T: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/pmc_hbm.sh + tools/pmc_summary.py
+    at L = 10 000, T = 65): 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, KiB -> bytes."""
+    if (L, T) != (10000, 65):
+        return None, None
+    for path in (PMC_TRAFFIC_FILE, PMC_TRAFFIC_FALLBACK):
+        if not os.path.exists(path):
+            continue
+        vals, cur = {}, None
+        for line in open(path):
+            if not line.startswith(" "):
+                cur = line.strip()
+            elif cur is not None and kernel in cur:
+                m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", line)
+                if m:
+                    vals[m.group(1)] = float(m.group(2))
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def kernel_rooflines(summ, prof_steps, fl, L, T, B=3):
+    """Achieved rate of every big kernel against the roofline that bounds it.  MFMA-bound: algorithmic FLOPs per launch
+    (2mnk GEMMs, attention products per DESIGN §4) / mean launch time; HBM-bound: algorithmic bytes per launch
+     / mean launch time.  Keys as ops.TIMER names them."""
+    N = L + 1
+    M = B * N
+    rows = []
+
+    def add(key, bound, work, label=None):
+        if key not in summ:
+            return
+        n, ms = summ[key]
+        t = ms / n * 1e-3
+        if bound == "mfma":
+            ach, peak, unit = work / t / 1e12, PEAK_F16_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = work / t / 1e9, PEAK_HBM_GBS, "GB/s"
+        rows.append({"kernel": label or key, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                     "frac": round(ach / peak, 4), "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms / prof_steps, 3)})
+
+    a = B * fl["attn_layer"]
+    add("dilated_attn_fwd", "mfma", a)
+    add("dilated_attn_bwd_kv", "mfma", 2.0 * a)
+    add("dilated_attn_bwd_q", "mfma", 1.5 * a)
+    for k in list(summ):
+        m = re.match(r"gemm_nt\[(\d+)x(\d+)x(\d+)\]", k)
+        if m and int(m.group(1)) >= 8192:
+            mm, nn, kk = (int(v) for v in m.groups())
+            add(k, "mfma", 2.0 * mm * nn * kk)
+    D, F = 768, 3072
+    add("add_layernorm_fwd[768]", "hbm", M * D * (4 + 2 + 4 + 2.0))           # x fp32 + branch fp16 read; h fp32 + y fp16 written
+    add("layernorm_fwd[3072]", "hbm", M * F * (2 + 2.0))                      # a1 fp16 read, t16 fp16 written
+    add("layernorm_bwd[3072]", "hbm", M * F * (2 + 2 + 2.0))                  # dy, a1 read; da1 written
+    add("layernorm_bwd[768]", "hbm", M * D * (2 + 4 + 4 + 4 + 2.0))           # dy fp16, x fp32, dx fp32 read-modify-write, dx16
+    add("dilated_mix_ln_fwd", "hbm", M * D * 2.0 * (1 + 31 / 16.0) + M * D * 2.0)   # covered branch rows (sum 1/r) + y
+    add("dilated_mix_ln_bwd", "hbm", M * D * 2.0 * (1 + 31 / 16.0) + 2 * M * D * 2.0)
+    return rows
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--patches", type=int, default=10000)
-    ap.add_argument("--pathways", default="6", help="number of toy pathways (sizes 5, 6, ...) or 'real': the reference's 331-pathway "
-                                                    "grouping sizes (tests/golden/pathway_sizes_331.json)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dropout", action="store_true", help="run the step with Dropout / DropPath off (the parity configuration); "
-                                                             "default: on, as model.train() leaves them in the reference")
-    ap.add_argument("--kernel-times", action="store_true", help="print the per-kernel time table (stderr)")
-    ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np  # noqa: F401
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("MT_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # MT_BENCH_DEVICE: rehearsals only
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -85,7 +195,7 @@ def main():
             torch.distributed.init_process_group(args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
 
-    from modaltune_amd import ops, synth
+    from modaltune_amd import dp, ops, synth
     from modaltune_amd.config import ModelConfig, flops_per_slide_step
     from modaltune_amd.engine import Engine
     from modaltune_amd.trainer import TrainStep
@@ -93,27 +203,31 @@ def main():
     L = args.patches
     cfg = ModelConfig()                       # Prov-GigaPath ModalAdapter config (modaltune_gigapath_config.json)
     if args.pathways == "real":
-        sizes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "pathway_sizes_331.json")))
+        sizes = json.load(open(os.path.join(ROOT, "tests", "golden", "pathway_sizes_331.json")))
     else:
         sizes = synth.toy_group_sizes(int(args.pathways))
     args.pathways = len(sizes)
     eng = Engine(cfg, sizes, dev)
-    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed=0))      # identical weights on every rank
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed=0))      # identical weights on every rank ...
+    dp.broadcast_params_(eng.store.flat)                                 # ... and DDP's constructor broadcast on top
     eng.set_stochastic(not args.no_dropout, seed=20260 + rank)     # Dropout(0.25) / DropPath(<= 0.1): counter-based masks
     ts = TrainStep(eng)
     ts.set_projector(synth.projector_state(0))
-    # synthetic slides, distinct per rank, resident in HBM (2 alternating slides per rank)
+    # synthetic slides, distinct per rank, resident in HBM (2 alternating slides per rank; --ragged: 8 lengths)
+    lengths = [L, L] if not args.ragged else [int(L * f) for f in (1.0, 0.62, 0.87, 0.5, 0.95, 0.71, 0.56, 0.8)]
     slides = []
-    for j in range(2):
-        inp = synth.synth_inputs(L, sizes, seed=1000 + 17 * rank + j, grid=128 if L <= 128 * 128 else 512)
-        slides.append((torch.from_numpy(inp["x"]).to(dev).half().reshape(L, -1).contiguous(), inp["coords"],
+    for j, Lj in enumerate(lengths):
+        inp = synth.synth_inputs(Lj, sizes, seed=1000 + 17 * rank + j, grid=128 if Lj <= 128 * 128 else 512)
+        slides.append((torch.from_numpy(inp["x"]).to(dev).half().reshape(Lj, -1).contiguous(), torch.from_numpy(inp["coords"]).to(dev),
                        [torch.from_numpy(a).to(dev) for a in inp["genes"]], torch.from_numpy(inp["text"]).to(dev)))
+    if args.ragged:
+        ts.capture_after = 1 << 30      # every length is "new": the eager schedule is the steady state being measured
 
-    def run(n, graphed=True):
-        for i in range(n):
-            x, coords, genes, text = slides[i % 2]
+    def run(n, graphed=True, first=0):
+        for i in range(first, first + n):
+            x, coords, genes, text = slides[i % len(slides)]
             if graphed and not args.eager:
-                ts.step_graphed(x, coords, genes, text)      # hipGraph replay (2 eager warm-ups + capture happen in warm-up)
+                ts.step_graphed(x, coords, genes, text)      # eager visits + capture happen in warm-up; then hipGraph replay
             else:
                 ts.step(x, coords, genes, text, update=True)
 
@@ -123,34 +237,39 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    nwarm = max(args.warmup, len(slides) if args.ragged else 3)   # 2 eager visits + the capture step (same geometry)
     try:
-        run(max(args.warmup, 3))      # >= 3: two eager steps + the capture step of the graph path
+        run(nwarm)
     except Exception as e:            # graph capture unavailable -> same arithmetic with eager launches
         if args.eager:                # (every rank runs the same code on the same hardware: the fallback is symmetric)
             raise
         print(f"[bench] hipGraph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
         args.eager = True
-        ts._graphs, ts._gwarm, ts._gkey = None, 0, None
+        ts._gcache.clear()
+        ts._cap = None
+        ts.reducer.pending.clear(); ts.reducer.started.clear()
         torch.cuda.synchronize()
-        run(max(args.warmup, 3))
+        run(nwarm)
+    eng.check_inputs()
     barrier()
     t0 = time.perf_counter()
-    run(args.steps)
+    run(args.steps, first=nwarm)
     barrier()
     dt = time.perf_counter() - t0
     loss = float(ts.loss)
+    replays, eager_steps = ts.graph_replays, ts.eager_steps
     # per-kernel durations: HIP events on the launch stream around every launch of an eager, instrumented pass of the
     # same step (events cannot be recorded inside a replayed graph); not part of the timed region above
     prof_steps = min(args.steps, 3)
     ops.TIMER = {}
-    run(prof_steps, graphed=False)
+    run(prof_steps, graphed=False, first=nwarm + args.steps)
     barrier()
     timer, ops.TIMER = ops.TIMER, None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
-    skipped = max(args.warmup, 3) + args.steps + prof_steps - int(ts.step_dev)
+    skipped = nwarm + args.steps + prof_steps - int(ts.step_dev)
 
     if rank == 0:
         T = cfg.num_tokens
@@ -160,7 +279,7 @@ def main():
         tot_ms = sum(v[1] for v in summ.values())
         if args.kernel_times:
             for k, (n, ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
-                print(f"  {k:28s} launches/step {n / prof_steps:7.1f}  ms/step {ms / prof_steps:9.3f}  ({100 * ms / tot_ms:5.1f} %)",
+                print(f"  {k:32s} launches/step {n / prof_steps:7.1f}  ms/step {ms / prof_steps:9.3f}  ({100 * ms / tot_ms:5.1f} %)",
                       file=sys.stderr)
         # roofline of the dominant kernel (largest share of the step): the dK/dV kernel of the dilated-attention backward,
         # one launch per layer per step over all 5 branches and all 3 task passes.  Algorithmic FLOPs per launch: the four
@@ -170,6 +289,9 @@ def main():
         launch_flops = 2.0 * 3 * fl["attn_layer"]
         achieved = launch_flops / (ms / n_l * 1e-3) / 1e12
         exec_flops = 2.0 * 3 * fl["attn_layer_executed"]      # zero-padded tiles are skipped, not computed
+        traffic, traffic_file = recorded_traffic("dilated_attn_bwd_kv_kernel", L, T) if not args.ragged else (None, None)
+        table = kernel_rooflines(summ, prof_steps, fl, L, T) if not args.ragged else []
+        worst = min((r for r in table if r["ms_per_step"] >= 0.4), key=lambda r: r["frac"], default=None)
         out = {
             "metric": "slides/sec (train step) at 10k patches x 1536-d", "value": value, "unit": "slides/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -179,25 +301,33 @@ def main():
                                    f"1 slide per GPU per step, train mode: "
                                    + ("dropout / drop-path off (parity configuration)" if args.no_dropout else
                                       f"Dropout({cfg.dropout}) on the embedded input and both backbone branches, DropPath(0..{cfg.drop_path_rate}) "
-                                      f"per layer and on the Extractor FFN (Philox masks regenerated in backward)"),
-                       "patches": L, "tokens": T, "parallelism": f"dp{world}", "dropout": not args.no_dropout},
+                                      f"per layer and on the Extractor FFN (Philox masks regenerated in backward)")
+                                   + ("; ragged: bag lengths " + "/".join(str(v) for v in lengths) + " in rotation" if args.ragged else ""),
+                       "patches": L, "tokens": T, "parallelism": f"dp{world}", "dropout": not args.no_dropout,
+                       "backend": args.backend if world > 1 else None},
             "loss": loss, "skipped_steps": skipped,
             "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / world / 1e12 / PEAK_F16_MFMA_TFLOPS,
             "roofline": {"kernel": "dilated_attn_bwd_kv_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS,
-                         "traffic": RECORDED_KV_TRAFFIC.get((L, T)),
+                         "frac_basis": "algorithmic FLOPs (SURVEY §8d: the reference computes on zero-padded segments); the kernel "
+                                       "skips the padding -- mfma_frac_executed is the fraction of peak the MFMA pipe itself runs at",
+                         "traffic": traffic,
                          "avg_launch_ms": ms / n_l, "flops_per_launch": launch_flops,
                          "flops_executed_per_launch": exec_flops,
                          "mfma_frac_executed": exec_flops / (ms / n_l * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                         "traffic_source": ("recorded rocprofv3 --pmc passes (profiles/r01_pmc_hbm_attn_bwd.txt): 2 x FETCH_SIZE "
-                                            "(gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, bytes per launch"
-                                            if (L, T) in RECORDED_KV_TRAFFIC else None),
+                         "traffic_source": (f"{traffic_file}: rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs), "
+                                            "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 tallies 128-B read requests at 64 B)"
+                                            if traffic is not None else None),
                          "measured": f"HIP events around each launch, eager instrumented pass of {prof_steps} steps after the timed region"},
-            "launch": "eager" if args.eager else "hipGraph replay",
+            "roofline_worst": worst,
+            "roofline_kernels": table,
+            "launch": "eager" if (args.eager or args.ragged) else "hipGraph replay",
+            "graph_replays": replays, "eager_steps": eager_steps,
             "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(cfg, sizes, L, seed=0)
+            out["cpu_baseline_reference"] = CPU_REFERENCE
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

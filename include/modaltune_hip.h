@@ -265,11 +265,26 @@ int mt_distill_loss(const float* logits, const float* target, int R, int O, floa
 int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step_count, const int* step_dev /* device count of completed
                   steps (overrides step_count - 1) or NULL */, float grad_mult /* e.g. 1/world_size */,
-                  const float* scale, int* found_inf, mt_stream_t stream);
+                  const float* scale, int* found_inf, const float* lr_dev /* device scalar: the schedule's current
+                  learning rate (overrides lr; a captured graph replays with whatever it holds -- the reference steps
+                  GradualWarmupScheduler + CosineAnnealingLR every epoch, TM:151-154,242) or NULL */, mt_stream_t stream);
 /* GradScaler.update on device (TM:237): *found_inf ? scale *= backoff : (every `interval` clean steps scale *= growth) */
 int mt_scaler_update(float* scale, int* growth_tracker, int* found_inf, int* step_dev /* ++ on a clean step, or NULL */,
                      float growth, float backoff, int interval, mt_stream_t stream);
 int mt_check_finite(const float* g, long n, int* found_inf, mt_stream_t stream);
+
+/* ---------------------------------------------------------- module bridge / input boundary --------- */
+/* s[0] = target / max|x|, s[1] = 1 / s[0] (both 1 when the maximum is 0 or not finite): device-side rescale of the
+ * gradient torch hands to the nn.Module bridge (loss.backward(), TM:235) into the fp16 range of the activation-gradient
+ * stream, without a host read-back. */
+int mt_absmax_scale(const float* x, long n, float target, float* s, mt_stream_t stream);
+/* y[i] = a[i] + (*alpha) * b[i] with alpha a DEVICE scalar (a may be NULL: y = (*alpha) * b) */
+int mt_axpy_dev(const float* a, const float* b, const float* alpha, float* y, long n, mt_stream_t stream);
+/* LongNetViT.coords_to_pos (SE:198-211) on the device: prow[i] = floor(coords[i][0] / tile), pcol[i] = floor(coords[i][1]
+ * / tile) for fp32 coords [L, 2]; cells outside [0, ngrids) are clamped and *err (device int, or NULL) is OR-ed with 1 --
+ * the host raises when it next looks (the reference would index out of bounds, SE:116-120,237). */
+int mt_coords_to_grid(const float* coords, int L, float tile, int ngrids, int* prow, int* pcol, int* err,
+                      mt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -81,9 +81,12 @@ SIGNATURES = {
     "mt_inject_resid_bwd": [P, L, RM, P, L, RM, P, P, P, L, RM, I, P, P, I, I, P],
     "mt_l2norm_rows": [P, P, I, I, P],
     "mt_distill_loss": [P, P, I, I, F, P, P, P, P],
-    "mt_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, P, F, P, P, P],
+    "mt_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, P, F, P, P, P, P],
     "mt_scaler_update": [P, P, P, P, F, F, I, P],
     "mt_check_finite": [P, L, P, P],
+    "mt_absmax_scale": [P, L, F, P, P],
+    "mt_axpy_dev": [P, P, P, P, L, P],
+    "mt_coords_to_grid": [P, I, F, I, P, P, P, P],
 }
 _RESTYPE = {"mt_status_string": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long}
 

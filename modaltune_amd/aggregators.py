@@ -42,15 +42,17 @@ class Aggregator(nn.Module):
 
 
 class _ModelFn(torch.autograd.Function):
-    """autograd bridge: forward runs the HIP engine (own tape + workspace per call); backward replays that call's
-    tape.  Parameter gradients are accumulated by the kernels into the flat gradient buffer and surfaced as
-    `param.grad` views, so torch optimisers / GradScaler / DDP-style hooks see ordinary gradients."""
+    """autograd bridge: forward runs the HIP engine (own tape + workspace per call); backward replays that call's tape.
+    The trainable parameters are REAL inputs of the Function and their gradients its outputs, so autograd's
+    AccumulateGrad nodes run as for any module: `param.grad` accumulates over the three forward calls of a step
+    (TM:175-177), torch optimisers / GradScaler see ordinary gradients, and DistributedDataParallel's reducer hooks fire
+    (utils/base_trainer.py:205-211 wraps the model in DDP)."""
 
     @staticmethod
-    def forward(ctx, dummy, module, x, coords, genes, onehots, need, clinical=None):
+    def forward(ctx, module, x, coords, genes, onehots, need, clinical, *params):
         eng = module.engine
         logits = eng.forward(x, coords, genes, onehots, need_grad=need, fresh=need, clinical=clinical)
-        ctx.module, ctx.call = module, (eng.last_call if need else None)
+        ctx.module, ctx.call, ctx.nparams = module, (eng.last_call if need else None), len(params)
         return logits.clone()
 
     @staticmethod
@@ -58,26 +60,22 @@ class _ModelFn(torch.autograd.Function):
         module, eng = ctx.module, ctx.module.engine
         if ctx.call is None:
             raise RuntimeError("backward through a forward that ran with gradients disabled")
-        params = module._trainable
-        fresh = any(p.grad is None for p in params.values())
         store = eng.store
-        # fp16 activation-gradient stream: run the tape on rescaled dlogits (max |.| -> 2^10), then unscale
-        amax = float(dlogits.abs().max())
-        if not (amax > 0.0) or amax != amax or amax == float("inf"):
-            s = 1.0
-        else:
-            s = 1024.0 / amax
-        acc = None if fresh else store.flat_grad.clone()
+        # The tape runs an fp16 activation-gradient stream: rescale the incoming gradient to max |.| = 2^10 on the DEVICE
+        # (no read-back), run the tape, and undo the scale while copying the flat gradient out.
+        dl = dlogits.to(F32).contiguous()
+        s = torch.empty(2, dtype=F32, device=dl.device)
+        ops.absmax_scale(dl, s, 1024.0)
+        scaled = torch.empty_like(dl)
+        ops.axpy_dev(None, dl, s[0:1], scaled)
+        hook, eng.grad_ready_hook = eng.grad_ready_hook, None      # (a TrainStep sharing the engine must not see this pass)
         store.flat_grad.zero_()
-        eng.backward(dlogits.to(F32) * s, call=ctx.call)
-        if acc is None:
-            ops.axpy(torch.zeros_like(store.flat_grad), store.flat_grad, 1.0 / s, store.flat_grad)
-        else:
-            ops.axpy(acc, store.flat_grad, 1.0 / s, store.flat_grad)
-        for k, p in params.items():
-            if p.grad is None:
-                p.grad = store.grads[k]
-        return torch.zeros(1, device=dlogits.device), None, None, None, None, None, None, None
+        eng.backward(scaled, call=ctx.call)
+        eng.grad_ready_hook = hook
+        out = torch.empty_like(store.flat_grad)
+        ops.axpy_dev(None, store.flat_grad, s[1:2], out)
+        grads = tuple(out[o:o + n].view(shape) for o, n, shape in module._slots)
+        return (None,) * 7 + grads
 
 
 @Aggregator.register("longnetvit_gene_adapter")
@@ -96,7 +94,7 @@ class LongNetGeneAdapter(Aggregator):
         for k, shape, kind, train in self.engine.store.specs:
             self._params[k] = nn.Parameter(self.engine.store.tensors[k], requires_grad=bool(train))
         self._trainable = OrderedDict((k, p) for k, p in self._params.items() if p.requires_grad)
-        self._dummy = torch.zeros(1, device=self.engine.device, requires_grad=True)
+        self._slots = [self.engine.store.slots[k] for k in self._trainable]      # (offset, numel, shape) in the flat buffers
         self._versions = None
         self.training_grad = True
         self.train(True)
@@ -153,7 +151,8 @@ class LongNetGeneAdapter(Aggregator):
         need = torch.is_grad_enabled() and self.training_grad     # (grad mode is off inside Function.forward)
         if not self.CLINICAL:
             clinical = None                      # the base adapter ignores `clinical` like the reference's **kwargs
-        return _ModelFn.apply(self._dummy, self, x, coords, genes, task_onehots.to(self.engine.device, F32), need, clinical)
+        return _ModelFn.apply(self, x, coords, genes, task_onehots.to(self.engine.device, F32), need, clinical,
+                              *self._trainable.values())
 
 
 @Aggregator.register("longnetvit_gene_clinical_adapter")

@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256) void distill_loss_kernel(const float* __restri
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                              float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float grad_mult,
-                             const float* __restrict__ scale, const int* __restrict__ found_inf, const int* __restrict__ step_dev) {
+                             const float* __restrict__ scale, const int* __restrict__ found_inf, const int* __restrict__ step_dev,
+                             const float* __restrict__ lr_dev) {
   if (found_inf && *found_inf) return;       // GradScaler.step: skip the whole update when a grad is inf/nan
+  if (lr_dev) lr = *lr_dev;                  // the schedule's current learning rate lives on the device (graph replays read it)
   if (step_dev) {                            // optimiser step count lives on the device (skipped steps do not count)
     const float st = (float)(*step_dev + 1);
     bc1 = 1.0f - powf(b1, st);
@@ -107,6 +109,44 @@ __global__ void scaler_update_kernel(float* scale, int* tracker, int* found_inf,
   *found_inf = 0;
 }
 
+
+// s[0] = target / max|x| (1 when the maximum is 0 or not finite), s[1] = 1 / s[0]: the device-side loss-scale of the
+// nn.Module bridge (no host read-back of the incoming gradient's range).  One workgroup; n is a few hundred.
+__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ x, long n, float target, float* __restrict__ s) {
+  __shared__ float red[256];
+  float m = 0.f;
+  bool bad = false;
+  for (long i = threadIdx.x; i < n; i += 256) { const float v = fabsf(x[i]); bad |= !(v <= 3.0e38f); m = fmaxf(m, v); }
+  red[threadIdx.x] = bad ? __builtin_inff() : m; __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]); __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const float a = red[0];
+    const float sc = (a > 0.f && a <= 3.0e38f) ? target / a : 1.0f;
+    s[0] = sc; s[1] = 1.0f / sc;
+  }
+}
+
+// y = a + (*alpha) * b (a may be null: y = (*alpha) * b)
+__global__ void axpy_dev_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ alpha,
+                                float* __restrict__ y, long n) {
+  const float al = *alpha;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = (a ? a[i] : 0.f) + al * b[i];
+}
+
+// grid cell of every patch: row = floor(coords[:, 0] / tile), col = floor(coords[:, 1] / tile) (slide_encoder.py:209-211);
+// cells outside [0, ngrids) are clamped and reported through *err (checked by the host when it next synchronises)
+__global__ void coords_to_grid_kernel(const float* __restrict__ coords, int L, float tile, int ngrids, int* __restrict__ prow,
+                                      int* __restrict__ pcol, int* __restrict__ err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  const int r = (int)floorf(coords[2 * i] / tile), c = (int)floorf(coords[2 * i + 1] / tile);
+  const bool bad = r < 0 || c < 0 || r >= ngrids || c >= ngrids;
+  prow[i] = min(max(r, 0), ngrids - 1);
+  pcol[i] = min(max(c, 0), ngrids - 1);
+  if (bad && err) atomicOr(err, 1);
+}
+
 }  // namespace
 
 extern "C" int mt_l2norm_rows(const float* x, float* y, int R, int O, mt_stream_t stream) {
@@ -136,14 +176,14 @@ extern "C" int mt_distill_loss(const float* logits, const float* target, int R, 
 
 extern "C" int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int step_count, const int* step_dev, float grad_mult,
-                             const float* scale, int* found_inf, mt_stream_t stream) {
+                             const float* scale, int* found_inf, const float* lr_dev, mt_stream_t stream) {
   if (!p || !g || !m || !v || n <= 0 || (step_count < 1 && !step_dev)) return MT_ERR_BAD_ARG;
   if (step_count < 1) step_count = 1;
   const float bc1 = 1.0f - powf(beta1, (float)step_count);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step_count));
   const int grid = (int)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2s, grad_mult, scale, (const int*)found_inf, step_dev);
+                     weight_decay, bc1, bc2s, grad_mult, scale, (const int*)found_inf, step_dev, lr_dev);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
@@ -156,7 +196,31 @@ extern "C" int mt_check_finite(const float* g, long n, int* found_inf, mt_stream
   return MT_OK;
 }
 
-extern "C" int mt_version(void) { return 100; }
+extern "C" int mt_absmax_scale(const float* x, long n, float target, float* s, mt_stream_t stream) {
+  if (!x || !s || n <= 0 || !(target > 0.f)) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, target, s);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_axpy_dev(const float* a, const float* b, const float* alpha, float* y, long n, mt_stream_t stream) {
+  if (!b || !alpha || !y || n <= 0) return MT_ERR_BAD_ARG;
+  const int grid = (int)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+  hipLaunchKernelGGL(axpy_dev_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, alpha, y, n);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_coords_to_grid(const float* coords, int L, float tile, int ngrids, int* prow, int* pcol, int* err,
+                                 mt_stream_t stream) {
+  if (!coords || !prow || !pcol || L < 1 || !(tile > 0.f) || ngrids < 1) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(coords_to_grid_kernel, dim3((L + 255) / 256), dim3(256), 0, (hipStream_t)stream, coords, L, tile, ngrids, prow,
+                     pcol, err);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_version(void) { return 200; }
 
 extern "C" const char* mt_status_string(int status) {
   switch (status) {

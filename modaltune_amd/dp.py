@@ -7,7 +7,7 @@ gradients (utils/base_trainer.py:192-211, 283-286, 483-484).
 from __future__ import annotations
 
 import math
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -49,3 +49,79 @@ def broadcast_params_(flat: torch.Tensor, src: int = 0, group=None):
     """DDP's constructor broadcast: every rank starts from rank `src`'s trainable parameters."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
+
+
+# ------------------------------------------------------------------------------------------------
+# Bucketed gradient all-reduce, started while the backward still runs (SURVEY §8e; the reference wraps the model in
+# DistributedDataParallel, whose reducer does the same per 25 MB bucket: utils/base_trainer.py:205-211).
+#
+# The backward of the hot path finalises parameter gradients in a fixed order: fusion head and interaction block 2
+# first, then block 1, block 0, and last the gene encoder / gene_pe / task tokens (the gene tokens feed every block, so
+# their gradient closes only at the very end).  The flat gradient buffer is in state_dict order, so each of these
+# stages is a handful of contiguous ranges.
+# ------------------------------------------------------------------------------------------------
+def _merge_ranges(slots: Sequence[tuple]) -> List[tuple]:
+    """[(offset, numel)] of 16-byte aligned slots -> maximal contiguous (offset, length) ranges."""
+    out: List[list] = []
+    for off, n in sorted(slots):
+        n_al = (n + 3) // 4 * 4
+        if out and out[-1][0] + out[-1][1] == off:
+            out[-1][1] += n_al
+        else:
+            out.append([off, n_al])
+    return [(a, b) for a, b in out]
+
+
+def grad_buckets(slots: dict, n_interactions: int, n_flat: int) -> List[List[tuple]]:
+    """Bucket b (b = 0 .. n_interactions) = ranges of the flat gradient buffer that are final when the backward has
+    left interaction block n_interactions - 1 - b; the last bucket (everything else: gene encoder, gene_pe, task /
+    clinical tokens) closes with the backward itself.  `slots`: ParamStore.slots (key -> (offset, numel, shape))."""
+    stage_of = {}
+    last = n_interactions
+    for k in slots:
+        st = last
+        if k.startswith("interactions.") or k.startswith("prompt_selfattention."):
+            st = n_interactions - 1 - int(k.split(".")[1])
+        elif k.startswith("final_norm.") or k.startswith("final_project."):
+            st = 0
+        stage_of[k] = st
+    buckets = []
+    for b in range(last + 1):
+        buckets.append(_merge_ranges([(slots[k][0], slots[k][1]) for k in slots if stage_of[k] == b]))
+    covered = sum(n for bk in buckets for _, n in bk)
+    if covered != n_flat:
+        raise AssertionError(f"gradient buckets cover {covered} of {n_flat} elements")
+    return buckets
+
+
+class GradReducer:
+    """start(b): launch the SUM all-reduce of bucket b's ranges (asynchronous: RCCL runs it on its own stream behind
+    everything enqueued so far on the current stream); wait(): make the current stream wait for every collective in
+    flight.  These are the `mt_grad_allreduce_start / _wait` of SURVEY §8b; they live above the C ABI because the
+    communicator belongs to torch.distributed ("nccl" = RCCL over xGMI on the GPUs, gloo in the rehearsals)."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[List[tuple]], group=None):
+        self.flat, self.buckets, self.group = flat_grad, buckets, group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.views = [[flat_grad[o:o + n] for o, n in bk] for bk in buckets]
+        self.pending: list = []
+        self.started: set = set()
+
+    def start(self, b: int):
+        if self.world == 1 or b in self.started:
+            return
+        self.started.add(b)
+        for v in self.views[b]:
+            self.pending.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def start_rest(self):
+        for b in range(len(self.buckets)):
+            self.start(b)
+
+    def wait(self) -> int:
+        """Returns the world size (the mean is folded into AdamW as grad_mult = 1 / world)."""
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
+        self.started.clear()
+        return self.world

@@ -113,6 +113,8 @@ class Engine:
         self.group_sizes = list(group_sizes)
         self.store = ParamStore(cfg, group_sizes, self.device)
         self.tape = Tape(self.device)
+        self.tape.on_realloc = self._bump_generation
+        self._main_tape = self.tape
         self.seg_lengths = segment_lengths(cfg.max_wsi_size, cfg.tile_size)
         self.pos_table = torch.from_numpy(sincos_1d_table(cfg.slide_ngrids, cfg.embed_dim // 2)).to(self.device)
         self._frozen16: Dict[str, _W16] = {}
@@ -120,6 +122,14 @@ class Engine:
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}          # (B, L) -> views of the flat storage
         self._ws_store: Dict[int, dict] = {}                          # B -> {cap, flat buffers}
         self._caches_ready = False
+        # Bumped whenever storage that a captured hipGraph may point to is replaced (workspace growth, rebuilt fp16 weight
+        # caches, the stochastic toggle's extra buffer): graph owners (TrainStep, EmbeddingExtractor) key their captures on it.
+        self.generation = 0
+        # backward stages whose parameter gradients are final (data-parallel bucket boundaries): set by TrainStep
+        self.grad_ready_hook = None
+        self._coord_err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._pin_ring: List[tuple] = []      # pinned staging slots for host-side coords (no pageable-copy sync per step)
+        self._pin_next = 0
         self.collect_taps = False      # tests: keep cls / token states after every interaction block
         self.taps: Dict[str, torch.Tensor] = {}
         self.T = cfg.num_tokens
@@ -142,9 +152,14 @@ class Engine:
         dpr = np.linspace(0.0, float(cfg.drop_path_rate), cfg.depth) if cfg.depth > 1 else np.zeros(1)
         self._layer_path_p = [float(v) for v in dpr]          # ENC:37-41
 
+    def _bump_generation(self):
+        self.generation += 1
+
     def set_stochastic(self, on: bool, seed: int = 0):
         """Dropout(cfg.dropout) on the embedded input and after out_proj / fc2, per-layer DropPath on both backbone
         branches, DropPath on the Extractor FFN branch -- as model.train() leaves them in the reference."""
+        if bool(on) != self.stochastic:
+            self.generation += 1          # the input-dropout buffer comes / goes with the toggle
         self.stochastic = bool(on)
         self.rng.copy_(torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF, 0, 0], dtype=torch.int32))
 
@@ -165,6 +180,7 @@ class Engine:
     def load_state_dict(self, state, strict=True):
         self.store.load(state, strict)
         self._caches_ready = False
+        self.generation += 1              # captured graphs read the fp16 caches that are about to be rebuilt
 
     def _build_caches(self):
         t, dev, cfg = self.store.tensors, self.device, self.cfg
@@ -187,6 +203,7 @@ class Engine:
             self._train16[pref + "out_in"] = _W16([t[pref + "multihead_attn.out_proj.weight"]], dev)
             self._train16[pref + "output_proj"] = _W16([t[pref + "output_proj.weight"]], dev)
         self._caches_ready = True
+        self.generation += 1              # new fp16 cache tensors: graphs captured against the old ones are stale
 
     def refresh_trainable_caches(self):
         """Re-derive the fp16 copies of the trainable big-M weights after an optimiser step."""
@@ -267,6 +284,7 @@ class Engine:
             cap = L if store is None else max(L, store["cap"] + store["cap"] // 4)
             self._ws_store.pop(B, None)
             self._ws.clear()              # views of the old storage die with it
+            self.generation += 1          # ... and so do the graphs captured on them
             store = {"cap": cap, "flat": {k: torch.empty(numel(shape), dtype=dt, device=dev) for k, (dt, shape) in spec(cap).items()}}
             self._ws_store[B] = store
         if len(self._ws) > 64:
@@ -296,8 +314,9 @@ class Engine:
         N, D, Fd, E, T = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim, self.T
         M, Mp = B * N, B * L
         ws = self._workspace(B, L, fresh=fresh)
-        if fresh:
-            self.tape = Tape(self.device)
+        # fresh: this call owns its tape (several forwards alive at once); the engine's long-lived tape -- whose gradient
+        # arena captured graphs point into -- is put back before returning
+        self.tape = Tape(self.device) if fresh else self._main_tape
         tape = self.tape
         tape.grad_enabled = need_grad
         tape.reset()
@@ -334,6 +353,11 @@ class Engine:
             ops.dropout_f32(ws["x0"], ws["x0d"], B * L, D, d_in, xmap=rowmap(L, 0, 0))
             src, src_map = ws["x0d"], rowmap(L, L, 0)
         for i, (la, lb) in enumerate(cfg.interaction_indexes):
+            # Everything recorded from here on belongs to interaction block i (and the blocks above): when the backward
+            # reaches this marker, the gradients of interactions.{i}.* / prompt_selfattention.{i}.* (and of the head, for the
+            # last block) are final -- the data-parallel reducer starts their all-reduce while the blocks below still run.
+            if need_grad and self.grad_ready_hook is not None:
+                tape.record(lambda i=i: self.grad_ready_hook is not None and self.grad_ready_hook(i))
             if i > 0 and cfg.use_prompt_sa:
                 c = self._prompt_self_attention(c, pe, f"prompt_selfattention.{i}.")
             hin = ws[f"hin{la}"]
@@ -360,26 +384,61 @@ class Engine:
         logits = self._head(c, ws[f"hout{nint - 1}"])
         self._logits = logits
         self.last_call = (tape, logits)
+        self.tape = self._main_tape
         return logits.data
 
     def stage_inputs(self, x: torch.Tensor, coords, ws: Optional[Dict[str, torch.Tensor]] = None, B: Optional[int] = None):
-        """Host side of the input boundary: grid indices from coords (slide_encoder.py:198-211) and the fp16 copy of the
-        patch embeddings, written into the workspace's static buffers."""
+        """Input boundary: grid indices from coords (slide_encoder.py:198-211) and the fp16 copy of the patch embeddings,
+        written into the workspace's static buffers.  Nothing here synchronises the stream: device coords are binned by a
+        kernel (out-of-range cells raise at the next check_inputs()), host coords are checked on the host and travel
+        through a small ring of pinned slots."""
         cfg = self.cfg
         x = x.reshape(-1, x.shape[-1])
         L = x.shape[0]
         if ws is None:
             ws = self._workspace(B, L)
-        coords_np = coords.detach().cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords)
-        prow, pcol = coords_to_rowcol(coords_np.reshape(-1, 2), float(cfg.tile_size))
-        if int(prow.max()) >= cfg.slide_ngrids or int(pcol.max()) >= cfg.slide_ngrids or int(min(prow.min(), pcol.min())) < 0:
-            raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid")
-        ws["prow"].copy_(torch.from_numpy(prow.astype(np.int32)))
-        ws["pcol"].copy_(torch.from_numpy(pcol.astype(np.int32)))
-        if x.dtype == H16:
+        if torch.is_tensor(coords) and coords.is_cuda:
+            c = coords.reshape(-1, 2).to(F32).contiguous()
+            if c.shape[0] != L:
+                raise ValueError(f"coords has {c.shape[0]} rows for {L} patches")
+            ops.coords_to_grid(c, L, float(cfg.tile_size), cfg.slide_ngrids, ws["prow"], ws["pcol"], self._coord_err)
+        else:
+            coords_np = coords.detach().numpy() if torch.is_tensor(coords) else np.asarray(coords)
+            prow, pcol = coords_to_rowcol(coords_np.reshape(-1, 2), float(cfg.tile_size))
+            if prow.shape[0] != L:
+                raise ValueError(f"coords has {prow.shape[0]} rows for {L} patches")
+            if int(prow.max()) >= cfg.slide_ngrids or int(pcol.max()) >= cfg.slide_ngrids or int(min(prow.min(), pcol.min())) < 0:
+                raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid")
+            slot = self._pinned_slot(2 * L)
+            slot[:L].copy_(torch.from_numpy(prow.astype(np.int32)))
+            slot[L:2 * L].copy_(torch.from_numpy(pcol.astype(np.int32)))
+            ws["prow"].copy_(slot[:L], non_blocking=True)
+            ws["pcol"].copy_(slot[L:2 * L], non_blocking=True)
+            self._pin_ring[self._pin_last][1].record()
+        if x.dtype == H16 and x.is_cuda:
             ws["x16"].copy_(x)
         else:
             ops.cast_f32_to_f16(x.to(self.device, F32).contiguous(), ws["x16"])
+
+    def _pinned_slot(self, n: int) -> torch.Tensor:
+        """Next slot of a 4-deep ring of pinned int32 buffers; a slot is reused only after the copy that read it has run."""
+        if len(self._pin_ring) < 4:
+            self._pin_ring.append([torch.empty(max(n, 1 << 15), dtype=torch.int32, pin_memory=True), torch.cuda.Event()])
+            self._pin_last = len(self._pin_ring) - 1
+        else:
+            self._pin_last = self._pin_next
+            self._pin_next = (self._pin_next + 1) % 4
+            buf, ev = self._pin_ring[self._pin_last]
+            ev.synchronize()
+            if buf.numel() < n:
+                self._pin_ring[self._pin_last][0] = torch.empty(n + n // 4, dtype=torch.int32, pin_memory=True)
+        return self._pin_ring[self._pin_last][0]
+
+    def check_inputs(self):
+        """Raises if a device-side coords binning since the last call met a cell outside the positional grid (host sync)."""
+        if int(self._coord_err) != 0:
+            self._coord_err.zero_()
+            raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid")
 
     # ------------------------------------------------------------------ token-side pieces
     def _gene_encoder(self, genes: Sequence[torch.Tensor]) -> Var:

@@ -22,6 +22,8 @@ def multitask_forward(model, task_ids: Optional[Sequence[int]] = None, num_tasks
     if not model.is_multi:
         return model(**kwargs)
     num_tasks = num_tasks or model.cfg.multi_task
+    if task_ids is None:
+        task_ids = range(num_tasks)
     onehots = torch.eye(num_tasks, dtype=F32)[list(task_ids)]
     return model.forward_tasks(kwargs["x"], kwargs["coords"], kwargs["genes"], onehots, clinical=kwargs.get("clinical"))
 
@@ -37,8 +39,11 @@ class EmbeddingExtractor:
 
     @torch.no_grad()
     def __call__(self, x, coords, genes: Sequence[torch.Tensor], clinical=None) -> torch.Tensor:
-        """Logits (= the slide embeddings the probes consume) [len(task_ids), output_dim], on the device."""
+        """Logits (= the slide embeddings the probes consume) [len(task_ids), output_dim], on the device (a fresh
+        tensor per call: replays write a static buffer that is copied out)."""
         eng = self.engine
+        if not eng._caches_ready:
+            eng._build_caches()
         x = x.reshape(-1, x.shape[-1])
         L, B = x.shape[0], self.onehots.shape[0]
         if isinstance(genes, dict):
@@ -46,12 +51,14 @@ class EmbeddingExtractor:
         if not self.graphed:
             return eng.forward(x, coords, list(genes), self.onehots, need_grad=False, clinical=clinical)
         gflat = genes.reshape(-1) if torch.is_tensor(genes) else torch.cat([g.reshape(-1) for g in genes])
-        key = (L, int(gflat.numel()))
+        eng.stage_inputs(x, coords, B=B)          # (may grow the workspace: bumps eng.generation)
+        # the engine's generation is part of the key: a workspace that grew under another user of the engine (the trainer
+        # shares the B = 3 storage), rebuilt weight caches (load_state_dict) or a stochastic toggle retire the capture
+        key = (L, int(gflat.numel()), eng.generation)
         if key != self._key:
             self._key, self._graph, self._warm = key, None, 0
             self._sgenes = torch.empty(int(gflat.numel()), dtype=F32, device=self.dev)     # one flat static buffer
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
-        eng.stage_inputs(x, coords, B=B)
         self._sgenes.copy_(gflat)
         if self._sclin is not None:
             self._sclin.copy_(clinical.reshape(1, -1))
@@ -66,7 +73,7 @@ class EmbeddingExtractor:
             with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self._out = run()
         self._graph.replay()
-        return self._out
+        return self._out.clone()
 
 
 def get_features(extractor: EmbeddingExtractor, slides: Iterable[Dict]) -> Tuple[np.ndarray, List]:

@@ -268,9 +268,23 @@ def distill_loss(logits, target, loss, dlogits, R, O, loss_scale=1.0, scale_dev=
 
 
 def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_count, scale=None, found_inf=None, grad_mult=1.0,
-               step_dev=None):
+               step_dev=None, lr_dev=None):
     check(_lib.load().mt_adamw_step(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, step_count,
-                                    _p(step_dev), float(grad_mult), _p(scale), _p(found_inf), _s()), "adamw_step")
+                                    _p(step_dev), float(grad_mult), _p(scale), _p(found_inf), _p(lr_dev), _s()), "adamw_step")
+
+
+def absmax_scale(x, s, target=1024.0, n=None):
+    """s[0] = target / max|x|, s[1] = 1 / s[0] on the device (include/modaltune_hip.h: mt_absmax_scale)."""
+    check(_lib.load().mt_absmax_scale(_p(x), n if n is not None else x.numel(), float(target), _p(s), _s()), "absmax_scale")
+
+
+def axpy_dev(a, b, alpha_dev, y, n=None):
+    """y = a + (*alpha_dev) * b; a may be None."""
+    check(_lib.load().mt_axpy_dev(_p(a), _p(b), _p(alpha_dev), _p(y), n if n is not None else b.numel(), _s()), "axpy_dev")
+
+
+def coords_to_grid(coords, L, tile, ngrids, prow, pcol, err=None):
+    check(_lib.load().mt_coords_to_grid(_p(coords), L, float(tile), ngrids, _p(prow), _p(pcol), _p(err), _s()), "coords_to_grid")
 
 
 def scaler_update(scale, tracker, found_inf, step_dev=None, growth=2.0, backoff=0.5, interval=2000):
@@ -306,7 +320,7 @@ def _timed(name_fn):
     return deco
 
 
-gemm_nt = _timed(lambda A, W, out, M, N, K, **k: f"gemm_nt[{N}x{K}]")(gemm_nt)
+gemm_nt = _timed(lambda A, W, out, M, N, K, **k: f"gemm_nt[{M}x{N}x{K}]")(gemm_nt)
 gemm_tn = _timed(lambda A, B, out, M, N1, N2, **k: f"gemm_tn[{N1}x{N2}]")(gemm_tn)
 dilated_attn_fwd = _timed(lambda *a, **k: "dilated_attn_fwd")(dilated_attn_fwd)
 dilated_mix_ln_fwd = _timed(lambda *a, **k: "dilated_mix_ln_fwd")(dilated_mix_ln_fwd)

@@ -71,6 +71,7 @@ class Tape:
         self._arena: Optional[torch.Tensor] = None
         self._arena_used = 0
         self._arena_miss = 0
+        self.on_realloc: Optional[Callable[[], None]] = None     # owner hook: captured graphs point into the arena
 
     def reset(self):
         global _ACTIVE
@@ -79,6 +80,8 @@ class Tape:
         need = self._arena_used + self._arena_miss
         if need > 0 and (self._arena is None or need > self._arena.numel()):
             self._arena = torch.empty(need + need // 4 + 1024, device=self.device, dtype=torch.float32)
+            if self.on_realloc is not None:
+                self.on_realloc()
         self._arena_used = self._arena_miss = 0
         if self._arena is not None and self.grad_enabled:      # forward-only passes allocate no gradients
             self._arena.zero_()

@@ -3,27 +3,42 @@ frozen text projector -> 3 task passes (batched) -> KL distillation loss -> back
 unscale/skip -> data-parallel mean of the flat gradient buffer -> fused AdamW.
 
 Data parallelism follows the reference's intent (base_trainer.py:192-211: one process per GPU, DDP mean of the
-trainable gradients): slides shard over ranks, the only collective is one all-reduce of the flat fp32 gradient
-buffer per step (RCCL on GPUs, gloo in the CPU tests).
+trainable gradients): slides shard over ranks; the collective is a bucketed SUM all-reduce of the flat fp32 gradient
+buffer (RCCL on GPUs, gloo in the rehearsals) whose buckets are launched from inside the backward, as soon as the
+stage that owns them has run (dp.grad_buckets: head + interaction block 2, block 1, block 0, gene encoder), and waited
+for just before AdamW -- the collectives of the upper blocks run under the backward of the lower ones.
 """
 from __future__ import annotations
 
+from collections import OrderedDict
 from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
 
 from . import dp, ops
+from ._lib import rowmap
 from .engine import Engine, F32
 from .tape import Param, Var
+
+
+class _Captured:
+    """The hipGraphs of one bag geometry: `segs` = [(graph, bucket or None)] replayed in order; after a segment with a
+    bucket index the reducer starts that bucket (world_size > 1 cuts the backward at the bucket boundaries; on one GPU
+    the whole step, optimiser included, is a single segment)."""
+    __slots__ = ("segs", "visits", "logits")
+
+    def __init__(self):
+        self.segs, self.visits, self.logits = None, 0, None
 
 
 class TrainStep:
     def __init__(self, engine: Engine, lr: float = 1e-4 / 20, weight_decay: float = 0.01, betas=(0.9, 0.999),
                  eps: float = 1e-8, init_scale: float = 2.0 ** 15, growth_interval: int = 2000,
-                 process_group=None, task_ids: Sequence[int] = (0, 1, 2), text_rows: Sequence[int] = (0, 1, 3)):
+                 process_group=None, task_ids: Sequence[int] = (0, 1, 2), text_rows: Sequence[int] = (0, 1, 3),
+                 graph_cache_size: int = 8, capture_after: int = 2):
         self.engine, self.dev = engine, engine.device
-        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.wd, self.betas, self.eps = weight_decay, betas, eps
         n = engine.store.n_flat
         self.m = torch.zeros(n, dtype=F32, device=self.dev)
         self.v = torch.zeros(n, dtype=F32, device=self.dev)
@@ -32,13 +47,49 @@ class TrainStep:
         self.found_inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.growth_interval = growth_interval
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)   # completed optimiser steps (skips excluded)
+        # the learning rate lives on the device: AdamW reads it there, so a scheduler (the reference steps
+        # GradualWarmupScheduler + CosineAnnealingLR every epoch, TM:151-154,242) reaches captured graphs as well
+        self.lr_dev = torch.full((1,), float(lr), dtype=F32, device=self.dev)
+        self._lr = float(lr)
         self.pg = process_group
         self.task_ids, self.text_rows = list(task_ids), list(text_rows)
         nt = engine.cfg.multi_task
-        self.onehots = torch.eye(nt, dtype=F32, device=self.dev)[self.task_ids].contiguous()
+        if engine.cfg.is_multi:
+            self.onehots = torch.eye(nt, dtype=F32, device=self.dev)[self.task_ids].contiguous()
+        else:       # single-task model (is_multi False, TM:172-179): one pass, no task token; its [1, O] logits meet all 3 targets
+            self.onehots = torch.zeros(1, 1, dtype=F32, device=self.dev)
         self.loss = torch.zeros(1, dtype=F32, device=self.dev)
         self.proj: Optional[Dict[str, torch.Tensor]] = None
         self.last_logits: Optional[torch.Tensor] = None
+        # data-parallel reducer (buckets in the order the backward finalises them)
+        nint = len(engine.cfg.interaction_indexes)
+        self._nint = nint
+        self.reducer = dp.GradReducer(engine.store.flat_grad, dp.grad_buckets(engine.store.slots, nint, n), process_group)
+        # captured graphs: LRU over bag geometries (real data has a new length almost every slide: a geometry is captured
+        # only once it has been seen `capture_after` times, everything else runs the eager schedule)
+        self.graph_cache_size, self.capture_after = int(graph_cache_size), int(capture_after)
+        self._gcache: "OrderedDict[tuple, _Captured]" = OrderedDict()
+        self._ggen = -1
+        self._opt_graph = None
+        self._cap = None                    # state of a segmented capture in progress
+        self._static_key = None
+        self.graph_replays = 0
+        self.eager_steps = 0
+
+    # ------------------------------------------------------------------ learning-rate schedule hook
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float):
+        self.set_lr(value)
+
+    def set_lr(self, lr: float):
+        """Scheduler hook: call once per epoch / step with the schedule's value (fill kernel, no host sync); eager steps
+        and replays of already captured graphs both train with it from the next step on."""
+        self._lr = float(lr)
+        self.lr_dev.fill_(float(lr))
 
     # frozen random text projector (train_modaltune.py:44-59,114-116)
     def set_projector(self, state: Dict[str, "np.ndarray | torch.Tensor"]):
@@ -59,104 +110,190 @@ class TrainStep:
         r = Var(tape.new(*h.data.shape))
         ops.act_fwd(h.data, r.data, ops.ACT_RELU)
         h = tape.linear(r, fr(p["conv1.3.weight"].view(O, -1)), fr(p["conv1.3.bias"]))
-        # row L2 normalisation: y = h / ||h||  -> LayerNorm-free: use sgemm for the norms is overkill; R = 4 rows
         out = tape.new(len(self.text_rows), O)
         ops_l2norm_rows(h.data, out, self.text_rows)
         tape.grad_enabled = was
         return out
 
-    def step(self, x, coords, genes, text, update: bool = True, clinical=None) -> torch.Tensor:
-        """One train step on one slide.  Returns the (device) loss scalar; no host sync happens here."""
+    # ------------------------------------------------------------------ the step's two halves
+    def _world(self) -> int:
+        return self.reducer.world
+
+    def _on_grad_ready(self, block: int):
+        """Engine callback from inside the backward: the gradients of interaction block `block` (and above) are final."""
+        b = self._nint - 1 - block
+        if self._cap is not None:
+            self._segment_break(b)
+        else:
+            self.reducer.start(b)
+
+    def _fwd_bwd(self, x, coords, genes, text, clinical, staged_geometry=None, reduce: bool = True):
         eng = self.engine
+        eng.grad_ready_hook = self._on_grad_ready if (reduce and self._world() > 1) else None
         if eng.stochastic:
             ops.rng_advance(eng.rng)          # a fresh set of dropout / DropPath masks per step
         target = self.project_text(text)
         eng.store.flat_grad.zero_()
-        logits = eng.forward(x, coords, genes, self.onehots, need_grad=True, clinical=clinical)
+        if staged_geometry is None:
+            logits = eng.forward(x, coords, genes, self.onehots, need_grad=True, clinical=clinical)
+        else:
+            logits = eng.forward(None, None, genes, self.onehots, need_grad=True, staged=True, geometry=staged_geometry,
+                                 clinical=clinical)
         self.last_logits = logits
-        R, O = logits.shape
-        dlogits = torch.empty_like(logits)
-        ops.distill_loss(logits, target, self.loss, dlogits, R, O, 1.0, self.scale)
+        R, O = target.shape
+        if logits.shape[0] == R:
+            dlogits = torch.empty_like(logits)
+            ops.distill_loss(logits, target, self.loss, dlogits, R, O, 1.0, self.scale)
+        else:       # single-task: nn.KLDivLoss broadcasts the one logits row over the R text rows (TM:225-233)
+            rows = torch.empty(R, O, dtype=F32, device=self.dev)
+            ops.copy_rows(logits, rows, R, O, smap=rowmap(1, 0, 0))
+            drows = torch.empty_like(rows)
+            ops.distill_loss(rows, target, self.loss, drows, R, O, 1.0, self.scale)
+            dlogits = torch.empty(1, O, dtype=F32, device=self.dev)
+            ops.copy_rows(drows[0:1], dlogits, 1, O)
+            for r in range(1, R):
+                ops.copy_rows(drows[r:r + 1], dlogits, 1, O, accumulate=True)
         eng.backward(dlogits)
+
+    def _adam_and_refresh(self, world: int):
+        eng = self.engine
+        n = eng.store.n_flat
+        ops.check_finite(eng.store.flat_grad, n, self.found_inf)
+        ops.adamw_step(eng.store.flat, eng.store.flat_grad, self.m, self.v, n, self._lr, self.betas[0], self.betas[1], self.eps,
+                       self.wd, 0, scale=self.scale, found_inf=self.found_inf, grad_mult=1.0 / world, step_dev=self.step_dev,
+                       lr_dev=self.lr_dev)
+        ops.scaler_update(self.scale, self.tracker, self.found_inf, self.step_dev, 2.0, 0.5, self.growth_interval)
+        eng.refresh_trainable_caches()
+
+    def optimizer_step(self):
+        """Launch whatever buckets the backward has not started, wait for the collectives, AdamW + weight-cache refresh."""
+        self.reducer.start_rest()
+        world = self.reducer.wait()
+        self._adam_and_refresh(world)
+
+    def step(self, x, coords, genes, text, update: bool = True, clinical=None) -> torch.Tensor:
+        """One train step on one slide, eager launches.  Returns the (device) loss scalar; no host sync happens here."""
+        self._fwd_bwd(x, coords, genes, text, clinical, reduce=update)
+        self.eager_steps += 1
         if update:
             self.optimizer_step()
         return self.loss
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     def step_graphed(self, x, coords, genes, text, clinical=None) -> torch.Tensor:
-        """Same arithmetic as step(), replayed from a captured hipGraph: the ~900 kernel launches of a step are
-        recorded once (after two eager warm-up steps) and replayed with one host call; inputs are uploaded into static
-        buffers first.  With world_size > 1 the forward+backward graph and the optimiser graph are separate and the
-        gradient all-reduce runs between them."""
+        """Same arithmetic as step().  A bag geometry (patch count, gene count) that keeps coming back is captured into
+        hipGraphs after `capture_after` eager visits and replayed from then on (the ~900 launches of a step become a few
+        host calls); up to `graph_cache_size` geometries stay captured (LRU).  Inputs are uploaded into static buffers
+        first.  With world_size > 1 the capture is cut where a gradient bucket becomes final: the reducer starts that
+        bucket's all-reduce between two replays, and the optimiser graph runs after the wait."""
         eng = self.engine
+        if not eng._caches_ready:
+            eng._build_caches()
         x = x.reshape(-1, x.shape[-1])
         L = x.shape[0]
         B = self.onehots.shape[0]
         gflat = genes.reshape(-1) if torch.is_tensor(genes) else torch.cat([g.reshape(-1) for g in genes])
-        key = (L, int(gflat.numel()))
-        if getattr(self, "_gkey", None) != key:
-            self._gkey, self._graphs, self._gwarm = key, None, 0
+        skey = (int(gflat.numel()), tuple(text.shape))
+        if self._static_key != skey:
+            self._static_key = skey
             self._sgenes = torch.empty(int(gflat.numel()), dtype=F32, device=self.dev)     # one flat static buffer
             self._stext = torch.empty(tuple(text.shape), dtype=F32, device=self.dev)
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
-        eng.stage_inputs(x, coords, B=B)
-        self._sgenes.copy_(gflat)
-        self._stext.copy_(text)
+            self._gcache.clear()
+        eng.stage_inputs(x, coords, B=B)          # (may grow the workspace: bumps eng.generation)
+        self._sgenes.copy_(gflat, non_blocking=True)
+        self._stext.copy_(text, non_blocking=True)
         if self._sclin is not None:
-            self._sclin.copy_(clinical.reshape(1, -1))
-        world = torch.distributed.get_world_size(self.pg) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+            self._sclin.copy_(clinical.reshape(1, -1), non_blocking=True)
+        world = self._world()
+        if self._ggen != eng.generation:          # buffers the old captures point to are gone (visit counts stay)
+            for e in self._gcache.values():
+                e.segs = e.logits = None
+            self._opt_graph = None
+            self._ggen = eng.generation
+        key = (L, world, bool(eng.stochastic))
+        ent = self._gcache.get(key)
+        if ent is None:
+            ent = _Captured()
+            self._gcache[key] = ent
+            while len(self._gcache) > max(1, self.graph_cache_size):
+                self._gcache.popitem(last=False)
+        else:
+            self._gcache.move_to_end(key)
 
         def fwd_bwd():
-            if eng.stochastic:
-                ops.rng_advance(eng.rng)
-            target = self.project_text(self._stext)
-            eng.store.flat_grad.zero_()
-            logits = eng.forward(None, None, self._sgenes, self.onehots, need_grad=True, staged=True, geometry=(B, L),
-                                 clinical=self._sclin)
-            self.last_logits = logits
-            R, O = logits.shape
-            dlogits = torch.empty_like(logits)
-            ops.distill_loss(logits, target, self.loss, dlogits, R, O, 1.0, self.scale)
-            eng.backward(dlogits)
+            self._fwd_bwd(None, None, self._sgenes, self._stext, self._sclin, staged_geometry=(B, L))
 
-        if self._graphs is None and self._gwarm < 2:          # eager warm-up (allocator, lazy kernel attributes)
+        if ent.segs is None and ent.visits < self.capture_after:      # eager visits (allocator, lazy kernel attributes,
+            ent.visits += 1                                            # the tape's gradient arena sized from the last step)
             fwd_bwd()
+            self.eager_steps += 1
             self.optimizer_step()
-            self._gwarm += 1
             return self.loss
-        if self._graphs is None:
-            torch.cuda.synchronize()
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            if world == 1:
-                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                    fwd_bwd()
-                    self.optimizer_step()
-                self._graphs = (g1, None)
-            else:       # (thread_local: RCCL's watchdog thread must not invalidate the capture)
-                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                    fwd_bwd()
-                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                    self._adam_and_refresh(world)
-                self._graphs = (g1, g2)
-        g1, g2 = self._graphs
-        g1.replay()
-        if g2 is not None:
-            dp.allreduce_sum_(eng.store.flat_grad, self.pg)
-            g2.replay()
+        if ent.segs is None:
+            self._capture(ent, fwd_bwd, world)
+        for g, bucket in ent.segs:
+            g.replay()
+            if bucket is not None:
+                self.reducer.start(bucket)
+        self.last_logits = ent.logits
+        self.graph_replays += 1
+        if world > 1:
+            self.reducer.start_rest()
+            self.reducer.wait()
+            self._opt_graph.replay()
         return self.loss
 
-    def _adam_and_refresh(self, world: int):
-        eng = self.engine
-        n = eng.store.n_flat
-        ops.check_finite(eng.store.flat_grad, n, self.found_inf)
-        ops.adamw_step(eng.store.flat, eng.store.flat_grad, self.m, self.v, n, self.lr, self.betas[0], self.betas[1], self.eps,
-                       self.wd, 0, scale=self.scale, found_inf=self.found_inf, grad_mult=1.0 / world, step_dev=self.step_dev)
-        ops.scaler_update(self.scale, self.tracker, self.found_inf, self.step_dev, 2.0, 0.5, self.growth_interval)
-        eng.refresh_trainable_caches()
+    @property
+    def _graphs(self):
+        """Captured segment lists of the cached geometries (None when nothing is captured yet)."""
+        segs = [e.segs for e in self._gcache.values() if e.segs is not None]
+        return segs or None
 
-    def optimizer_step(self):
-        world = dp.allreduce_sum_(self.engine.store.flat_grad, self.pg)      # sum over ranks; mean folded into AdamW
-        self._adam_and_refresh(world)
+    def _capture(self, ent: _Captured, fwd_bwd, world: int):
+        torch.cuda.synchronize()
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(main)
+        pool = torch.cuda.graph_pool_handle()
+        segs = []
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()          # (thread_local: RCCL's watchdog thread must not invalidate the capture)
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
+            self._cap = {"segs": segs, "cur": g, "pool": pool}
+            try:
+                fwd_bwd()
+                if world == 1:
+                    self.optimizer_step()
+            except BaseException:
+                try:
+                    self._cap["cur"].capture_end()
+                except Exception:
+                    pass
+                self._cap = None
+                raise
+            self._cap["cur"].capture_end()
+            segs.append((self._cap["cur"], None))
+            self._cap = None
+            if world > 1 and self._opt_graph is None:
+                og = torch.cuda.CUDAGraph()
+                og.capture_begin(pool=pool, capture_error_mode="thread_local")
+                try:
+                    self._adam_and_refresh(world)
+                finally:
+                    og.capture_end()
+                self._opt_graph = og
+        main.wait_stream(side)
+        ent.segs, ent.logits = segs, self.last_logits
+
+    def _segment_break(self, bucket: int):
+        """Inside a capture with world_size > 1: close the current graph at a gradient-bucket boundary, open the next."""
+        cap = self._cap
+        cap["cur"].capture_end()
+        cap["segs"].append((cap["cur"], bucket))
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=cap["pool"], capture_error_mode="thread_local")
+        cap["cur"] = g
 
     def unscaled_grads(self) -> Dict[str, torch.Tensor]:
         s = float(self.scale)
@@ -164,8 +301,7 @@ class TrainStep:
 
 
 def ops_l2norm_rows(h: torch.Tensor, out: torch.Tensor, rows: Sequence[int]):
-    """out[i] = h[rows[i]] / ||h[rows[i]]|| via the LayerNorm-free path: sgemm computes the squared norm, then axpy scales.
-    R <= 4 rows of O = 256: done with two tiny kernels per row (host loop is 3 iterations)."""
+    """out[i] = h[rows[i]] / ||h[rows[i]]||: R <= 4 rows of O = 256, one tiny launch per row."""
     O = h.shape[-1]
     for i, r in enumerate(rows):
         ops.l2norm_row(h[r], out[i], O)

@@ -286,11 +286,20 @@ def distill_loss(logits, text_proj, temperature=1.0):
     logit = logits / logits.norm(dim=-1, keepdim=True)
     logp = F.log_softmax(logit / temperature, dim=1)
     p = F.softmax(text_proj[[0, 1, 3], :] / temperature, dim=1)
+    if logp.shape[0] != p.shape[0]:        # single-task model: [1, O] logits against 3 targets (nn.KLDivLoss broadcasts)
+        logp = logp.expand_as(p)
     return F.kl_div(logp, p, reduction="sum") * (temperature ** 2) * 10
 
 
 def multitask_logits(sd, cfg, x, coords, genes, seg_lengths, task_ids=(0, 1, 2), taps=None, clinical=None):
-    """multitask_forward (train_modaltune.py:156-179)."""
+    """multitask_forward (train_modaltune.py:156-179): one model call per task id, or a single call without a task token
+    when the model is single-task (is_multi False; the [1, O] logits then broadcast against the 3 text rows in the loss)."""
+    if not cfg.is_multi:
+        tp = {} if taps is not None else None
+        out = model_forward(sd, cfg, x, coords, genes, None, seg_lengths, taps=tp, clinical=clinical)
+        if taps is not None:
+            taps[0] = tp
+        return out
     eye = torch.eye(cfg.multi_task, dtype=x.dtype)
     outs = []
     for t in task_ids:

@@ -1,0 +1,102 @@
+"""Rank process of the multi-process GPU tests (tests/test_dp_gpu.py): `python tests/dp_worker.py MODE RANK WORLD PORT OUT`.
+
+Every rank uses GPU 0 and the gloo backend (one GPU per box; RCCL refuses two ranks on one device) -- the code path
+is the one `torch.distributed` runs over RCCL on a real node: dp.GradReducer's async all-reduces from inside the backward,
+segmented hipGraph capture, DistributedDataParallel's reducer hooks on the nn.Module bridge.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from modaltune_amd import dp, synth  # noqa: E402
+from modaltune_amd.config import ModelConfig  # noqa: E402
+
+L, SEED, NGRIDS, STEPS = 150, 5, 32, 4
+
+
+def _cfg():
+    return ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)), slide_ngrids=NGRIDS)
+
+
+def _slide(rank, sizes):
+    inp = synth.synth_inputs(L + 13 * rank, sizes, seed=900 + rank, grid=NGRIDS)
+    return (torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda(), [torch.from_numpy(a).cuda() for a in inp["genes"]],
+            torch.from_numpy(inp["text"]).cuda())
+
+
+def trainstep(rank, world, out):
+    """STEPS data-parallel steps (one slide per rank, eager visit -> capture -> replays); dumps the final flat weights."""
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    sizes = synth.toy_group_sizes()
+    cfg = _cfg()
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, SEED))
+    dp.broadcast_params_(eng.store.flat)
+    ts = TrainStep(eng, lr=1e-3, capture_after=1)
+    ts.set_projector(synth.projector_state(SEED))
+    x, coords, genes, text = _slide(rank, sizes)
+    losses = []
+    for _ in range(STEPS):
+        losses.append(float(ts.step_graphed(x, coords, genes, text)))
+    torch.cuda.synchronize()
+    nseg = max(len(s) for s in ts._graphs) if ts._graphs else 0
+    np.savez(out, flat=eng.store.flat.cpu().numpy(), losses=np.array(losses), replays=ts.graph_replays, nseg=nseg,
+             steps=int(ts.step_dev), buckets=len(ts.reducer.buckets))
+
+
+def ddp_module(rank, world, out):
+    """The reference's own multi-GPU form (utils/base_trainer.py:205-211): DistributedDataParallel around the nn.Module,
+    3 forward calls, loss.backward().  Dumps the local (unwrapped) gradients and the DDP-averaged ones."""
+    from modaltune_amd.aggregators import Aggregator
+    from oracle import modaltune_oracle as O
+    sizes = synth.toy_group_sizes()
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, depth=3, slide_ngrids=NGRIDS,
+                              interaction_indexes=[[0, 0], [1, 1], [2, 2]], dropout=0.0, drop_path_rate=0.0, multi_task=3)
+    cfg = model.cfg
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, sizes, SEED).items()}, strict=True)
+    x, coords, genes, text = _slide(rank, sizes)
+    gd = {i: g for i, g in enumerate(genes)}
+    psd = {k: torch.from_numpy(v).cuda() for k, v in synth.projector_state(SEED).items()}
+    target = O.projector_forward(text, psd)      # [4, 256]; distill_loss picks rows 0, 1, 3
+
+    def loss_of(m):
+        logits = torch.cat([m(x=x, coords=coords, genes=gd, clinical=[], task_token=torch.eye(3)[t].cuda()) for t in (0, 1, 2)], dim=0)
+        return O.distill_loss(logits, target)
+
+    model.train()
+    loss_of(model).backward()
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    params = dict(model.named_parameters())
+    local = torch.cat([params[k].grad.reshape(-1) for k in names]).clone()
+    for k in names:
+        params[k].grad = None
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+    loss_of(ddp).backward()
+    torch.cuda.synchronize()
+    avg = torch.cat([params[k].grad.reshape(-1) for k in names]).clone()
+    # second iteration: DDP's "expected to have finished reduction" check passes only if every hook fired
+    for k in names:
+        params[k].grad = None
+    loss_of(ddp).backward()
+    torch.cuda.synchronize()
+    avg2 = torch.cat([params[k].grad.reshape(-1) for k in names]).clone()
+    np.savez(out, local=local.cpu().numpy(), avg=avg.cpu().numpy(), avg2=avg2.cpu().numpy())
+
+
+if __name__ == "__main__":
+    mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        {"trainstep": trainstep, "ddp_module": ddp_module}[mode](rank, world, out)
+    finally:
+        dist.destroy_process_group()

@@ -186,23 +186,27 @@ GRAD_KEYS_FULL = ["interactions.0.injector.gamma", "interactions.1.injector.gamm
 
 
 def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32), ngrids=128, time_it=False, clinical=False,
-               token_agg=None):
+               token_agg=None, multi_task=3, adamw_steps=0, lr=1e-3):
+    """multi_task: width of the task one-hot (3: train_modaltune.py; 4: train_modaltune_pancancer.py:537-542, task ids 0..2
+    either way; 1: the single-task path, one model call, TM:172-179).  adamw_steps > 0: after the backward, take that many
+    torch.optim.AdamW steps exactly as the trainer does (TM:139-149,235-238; no GradScaler on the CPU) and record the
+    post-step weights of GRAD_KEYS_FULL and the loss of every step."""
     cfg_kw = dict(REF_CFG)
     cfg_kw.update(depth=depth, interaction_indexes=inter, slide_ngrids=ngrids, pretrained=False)
     if token_agg:
         cfg_kw["token_agg"] = token_agg
-    cfg = ModelConfig.from_json(cfg_kw, clinical=clinical)
+    cfg = ModelConfig.from_json(cfg_kw, multi_task=multi_task, clinical=clinical)
     sizes = synth.toy_group_sizes(6)
     groups = {i: ["g"] * n for i, n in enumerate(sizes)}
     sd = synth.synth_state_dict(cfg, sizes, seed)
     inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
     psd = synth.projector_state(seed)
     out = {"L": L, "depth": depth, "inter": np.array(inter), "seed": seed, "ngrids": ngrids, "sizes": np.array(sizes),
-           "clinical": int(clinical), "token_agg": cfg.token_agg}
+           "clinical": int(clinical), "token_agg": cfg.token_agg, "multi_task": multi_task}
     for dt in dtypes:
         tag = "f64" if dt == torch.float64 else "f32"
         model = Aggregator.create("longnetvit_gene_clinical_adapter" if clinical else "longnetvit_gene_adapter",
-                                  gene_group_defination=groups, **cfg_kw, multi_task=3)
+                                  gene_group_defination=groups, **cfg_kw, multi_task=multi_task)
         model.load_state_dict({k: tt(v, torch.float32) for k, v in sd.items()}, strict=True)
         model = model.to(dt)
         ref_shims.zero_dropout(model)
@@ -210,6 +214,8 @@ def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32
         proj = TM.Projection_layer(512, 256)
         proj.load_state_dict({k: tt(v, torch.float32) for k, v in psd.items()}, strict=True)
         proj = proj.to(dt)
+        for prm in proj.parameters():      # frozen random projector (TM:114-116)
+            prm.requires_grad = False
         taps = {}
 
         def hook(i):
@@ -224,12 +230,19 @@ def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32
         t0 = time.time()
         text = proj(tt(inp["text"], dt)); text = text / text.norm(dim=-1, keepdim=True)
         clin = tt(inp["clinical"], dt) if clinical else []
-        logits = torch.cat([model(x=x, coords=coords, genes=genes, clinical=clin, task_token=torch.eye(3, dtype=dt)[t])
-                            for t in (0, 1, 2)], dim=0)
+        def multitask_forward():      # TM:156-179
+            if model.is_multi:
+                return torch.cat([model(x=x, coords=coords, genes=genes, clinical=clin, task_token=torch.eye(multi_task, dtype=dt)[t])
+                                  for t in (0, 1, 2)], dim=0)
+            return model(x=x, coords=coords, genes=genes, clinical=clin)
+
+        def loss_of(logits):          # TM:225-233
+            logit = logits / logits.norm(dim=-1, keepdim=True)
+            return torch.nn.KLDivLoss(reduction="sum")(torch.nn.functional.log_softmax(logit / 1.0, dim=1),
+                                                       torch.nn.functional.softmax(text[[0, 1, 3], :] / 1.0, dim=1)) * 10
+        logits = multitask_forward()
         t1 = time.time()
-        logit = logits / logits.norm(dim=-1, keepdim=True)
-        loss = torch.nn.KLDivLoss(reduction="sum")(torch.nn.functional.log_softmax(logit / 1.0, dim=1),
-                                                  torch.nn.functional.softmax(text[[0, 1, 3], :] / 1.0, dim=1)) * 10
+        loss = loss_of(logits)
         loss.backward()
         t2 = time.time()
         for h in hs:
@@ -246,12 +259,29 @@ def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32
         if dt == torch.float64:
             for k in GRAD_KEYS_FULL:
                 kk = k.replace("interactions.2.", f"interactions.{len(inter) - 1}.")
-                out["f64_grad/" + kk] = dict(model.named_parameters())[kk].grad.numpy()
+                if kk in dict(model.named_parameters()):      # (no task_weight in the single-task model)
+                    out["f64_grad/" + kk] = dict(model.named_parameters())[kk].grad.numpy().copy()
             for i, lst in taps.items():
                 for t, (cls, c, xh) in enumerate(lst):
                     out[f"f64_tap/task{t}/cls{i}"] = cls
                     out[f"f64_tap/task{t}/c{i}"] = c.astype(np.float32)
                     out[f"f64_tap/task{t}/x{i}_head"] = xh
+        if adamw_steps and dt == torch.float64:
+            opt = torch.optim.AdamW([{"params": filter(lambda p: p.requires_grad, model.parameters()), "lr": lr}],
+                                    weight_decay=0.01, betas=(0.9, 0.999))
+            losses = [float(loss)]
+            for it in range(adamw_steps):
+                opt.step()
+                opt.zero_grad()
+                if it + 1 < adamw_steps:
+                    l2 = loss_of(multitask_forward())
+                    l2.backward()
+                    losses.append(float(l2))
+            out["adamw_lr"], out["adamw_steps"], out["f64_adamw_losses"] = lr, adamw_steps, np.array(losses)
+            for k in GRAD_KEYS_FULL:
+                kk = k.replace("interactions.2.", f"interactions.{len(inter) - 1}.")
+                if kk in dict(model.named_parameters()):
+                    out["f64_adamw/" + kk] = dict(model.named_parameters())[kk].detach().numpy().copy()
         if time_it:
             out[f"{tag}_time_fwd_bwd"] = np.array([t1 - t0, t2 - t1])
         print(name, tag, "loss", float(loss), "fwd %.2fs bwd %.2fs" % (t1 - t0, t2 - t1), flush=True)
@@ -265,6 +295,13 @@ if __name__ == "__main__":
         model_case("L37_d3_clin", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=14, clinical=True)
         model_case("L37_d3_clin_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=15, clinical=True, token_agg="cat")
         model_case("L37_d3_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=16, token_agg="cat")
+    if "pan" in which:    # pan-cancer trainer shape: one-hot width 4, task ids 0..2 (train_modaltune_pancancer.py:50-134,537-542)
+        model_case("L37_d3_pan", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=17, multi_task=4)
+        model_case("L129_d3_pan", 129, 3, [[0, 0], [1, 1], [2, 2]], seed=18, multi_task=4, dtypes=(torch.float64,))
+    if "single" in which:  # single-task path (multi_task = 1, is_multi False: one model call, no task token)
+        model_case("L37_d3_single", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=19, multi_task=1, dtypes=(torch.float64,))
+    if "adamw" in which:   # two optimiser steps of the reference trainer: post-AdamW weights
+        model_case("L37_d3_adamw", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=11, dtypes=(torch.float64,), adamw_steps=2, lr=1e-3)
     if "adapter" in which:
         unit_adapter()
     if "layer" in which:

@@ -43,8 +43,52 @@ def _worker(rank, world, port, n):
         dist.all_gather_object(gathered, dp.shard_indices(11, world, rank, epoch=1, seed=7))
         allidx = sorted(i for g in gathered for i in g)
         assert set(allidx) == set(range(11)) and len(allidx) == 12      # padded to a multiple of world
+        # bucketed reducer: buckets started out of order / twice, the rest at the end; every element reduced exactly once
+        from modaltune_amd import synth
+        from modaltune_amd.config import ModelConfig
+        from modaltune_amd.engine import ParamStore
+        cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)))
+        st = ParamStore(cfg, synth.toy_group_sizes(), "cpu")
+        buckets = dp.grad_buckets(st.slots, 3, st.n_flat)
+        assert len(buckets) == 4
+        st.flat_grad.copy_(torch.arange(st.n_flat, dtype=torch.float32) % 1000 * (rank + 1))
+        red = dp.GradReducer(st.flat_grad, buckets)
+        red.start(0); red.start(0); red.start(2)
+        red.start_rest()
+        assert red.wait() == world and not red.pending
+        want = torch.arange(st.n_flat, dtype=torch.float32) % 1000 * sum(r + 1 for r in range(world))
+        assert torch.equal(st.flat_grad, want)
     finally:
         dist.destroy_process_group()
+
+
+def test_grad_buckets_follow_the_backward_order():
+    """Bucket 0 = fusion head + interaction block 2 (+ its prompt self-attention), ..., last = gene encoder / gene_pe /
+    task tokens; together they tile the flat gradient buffer exactly once."""
+    from modaltune_amd import synth
+    from modaltune_amd.config import ModelConfig
+    from modaltune_amd.engine import ParamStore
+    for clinical in (False, True):
+        cfg = ModelConfig(clinical=clinical)
+        st = ParamStore(cfg, synth.toy_group_sizes(), "cpu")
+        buckets = dp.grad_buckets(st.slots, len(cfg.interaction_indexes), st.n_flat)
+        owner = torch.full((st.n_flat,), -1, dtype=torch.int64)
+        for b, ranges in enumerate(buckets):
+            for o, n in ranges:
+                assert (owner[o:o + n] == -1).all()
+                owner[o:o + n] = b
+        assert (owner >= 0).all()
+
+        def bucket_of(key):
+            return int(owner[st.slots[key][0]])
+        assert bucket_of("final_project.weight") == 0 and bucket_of("interactions.2.extra_extractors.1.ffn.linear1.weight") == 0
+        assert bucket_of("prompt_selfattention.2.q_proj.weight") == 0
+        assert bucket_of("interactions.1.injector.gamma") == 1 and bucket_of("prompt_selfattention.1.norm.bias") == 1
+        assert bucket_of("interactions.0.extractor.attn.q_proj.weight") == 2
+        assert bucket_of("gene_pe") == 3 and bucket_of("gene_encoder.pathway_compression.weight") == 3
+        assert bucket_of("task_weight.0.weight") == 3
+        if clinical:
+            assert bucket_of("clinical_mlp.0.weight") == 3
 
 
 def test_gloo_world2_allreduce_and_sharding():

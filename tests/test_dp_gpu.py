@@ -1,0 +1,133 @@
+"""Multi-process GPU tests of the data-parallel path: 2 fresh rank processes on GPU 0 over gloo.
+
+(a) TrainStep.step_graphed on a different slide per rank: eager visit, segmented hipGraph capture (the backward is cut
+    where a gradient bucket becomes final), replays; both ranks end with identical weights, equal to a single-process
+    run that averages the two slides' gradients.
+(b) the nn.Module bridge wrapped in DistributedDataParallel (utils/base_trainer.py:205-211): its reducer hooks fire and
+    param.grad is the mean of the per-rank gradients; a second iteration passes DDP's "finished reduction" check.
+(c) `bench.py --gpus 2 --backend gloo` launches its two ranks itself and prints n_gpus: 2.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(mode, tmp_path, world=2, timeout=600):
+    port = str(_free_port())
+    outs = [str(tmp_path / f"{mode}_{r}.npz") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, WORKER, mode, str(r), str(world), port, outs[r]], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode()[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
+    return [np.load(o) for o in outs]
+
+
+def test_two_rank_trainstep_matches_gradient_averaging(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker as W
+    from modaltune_amd import synth
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    r0, r1 = _run_ranks("trainstep", tmp_path)
+    assert int(r0["steps"]) == W.STEPS and int(r0["replays"]) == W.STEPS - 1      # one eager visit, then capture + replays
+    assert int(r0["nseg"]) == int(r0["buckets"]) == 4                              # the backward was cut at every bucket boundary
+    assert np.array_equal(r0["flat"], r1["flat"])                                  # same reduced gradient -> same weights, bitwise
+    assert not np.allclose(r0["losses"], r1["losses"])                             # (different slides)
+    # single-process reference: gradients of both slides summed, AdamW with grad_mult = 1/2
+    sizes = synth.toy_group_sizes()
+    cfg = W._cfg()
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, W.SEED))
+    ts = TrainStep(eng, lr=1e-3)
+    ts.set_projector(synth.projector_state(W.SEED))
+    slides = [W._slide(r, sizes) for r in range(2)]
+    ref_losses = []
+    for _ in range(W.STEPS):
+        acc = torch.zeros_like(eng.store.flat_grad)
+        ls = []
+        for x, coords, genes, text in slides:
+            ls.append(float(ts.step(x, coords, genes, text, update=False)))
+            acc += eng.store.flat_grad
+        eng.store.flat_grad.copy_(acc)
+        ts._adam_and_refresh(2)
+        ref_losses.append(ls)
+    torch.cuda.synchronize()
+    ref_losses = np.array(ref_losses)
+    assert np.allclose(r0["losses"], ref_losses[:, 0], rtol=2e-3), (r0["losses"], ref_losses[:, 0])
+    assert np.allclose(r1["losses"], ref_losses[:, 1], rtol=2e-3), (r1["losses"], ref_losses[:, 1])
+    ref = eng.store.flat.cpu().numpy()
+    moved = np.abs(ref - synth_flat(eng, cfg, sizes, W.SEED))
+    d = np.abs(r0["flat"] - ref)
+    # AdamW's normalised update is ~lr per step whatever the gradient's size: elements whose gradient is rounding noise may
+    # differ by up to 2 lr per step between two runs (fp32 atomics reorder); everything else agrees to a small fraction of lr
+    assert d.max() <= 2.0 * W.STEPS * 1e-3 + 1e-7
+    assert np.mean(d > 0.05 * 1e-3) < 0.02, (np.mean(d > 0.05 * 1e-3), d.max())
+    assert moved.mean() > 0.5e-3                                                   # (the weights did move)
+
+
+def synth_flat(eng, cfg, sizes, seed):
+    """The initial flat trainable buffer (state_dict order, 16-byte aligned slots)."""
+    from modaltune_amd import synth
+    sd = synth.synth_state_dict(cfg, sizes, seed)
+    out = np.zeros(eng.store.n_flat, dtype=np.float32)
+    for k, (o, n, _) in eng.store.slots.items():
+        out[o:o + n] = sd[k].reshape(-1)
+    return out
+
+
+def test_module_under_distributed_data_parallel(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r0, r1 = _run_ranks("ddp_module", tmp_path)
+    mean = 0.5 * (r0["local"].astype(np.float64) + r1["local"].astype(np.float64))
+    scale = np.abs(mean).max()
+    for r in (r0, r1):
+        assert np.abs(r["avg"] - mean).max() < 2e-3 * scale        # DDP averaged exactly what the flat all-reduce path sums
+        assert np.abs(r["avg2"] - mean).max() < 2e-3 * scale       # and a second iteration reduces again
+    assert np.array_equal(r0["avg"], r1["avg"])
+    assert np.abs(r0["local"] - r1["local"]).max() > 1e-3 * scale  # (the ranks saw different slides)
+
+
+def test_bench_launches_its_own_ranks():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--patches", "1024",
+                        "--steps", "3", "--warmup", "3", "--no-cpu-baseline"], env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
+    assert out["launch"] == "hipGraph replay" and out["graph_replays"] >= 3
+    assert out["value"] > 0 and out["skipped_steps"] == 0

@@ -1,0 +1,124 @@
+"""BASELINE config 2 geometry (N = 10 001 tokens, real segment lengths [1024, 5792, 32768, ...]) against the CPU oracle.
+
+The whole 12-layer step is out of the oracle's reach for a test, one frozen LongNet layer is not (bench.py's cpu_baseline
+leg times exactly this call): (a) Engine._layer forward + backward vs O.encoder_layer(..., attn_impl="flash") autograd;
+(b) the dilated-attention kernels alone (forward per-branch outputs + LSE, mix + inner LN, dq / dk / dv) vs the oracle's
+autograd on the same fp16-rounded q | k | v.  At this N the 5792-segment branch has two real segments (the second one
+ragged: 4209 rows -> sparse length 2105 of 2896, the rest zero padding) and the three long branches one padded segment each.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from modaltune_amd import synth  # noqa: E402
+from modaltune_amd.config import DILATED_RATIOS, ModelConfig, branch_table, segment_lengths  # noqa: E402
+
+N_FULL = 10001
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+def test_one_longnet_layer_fwd_bwd_at_N10001_vs_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd import ops
+    from modaltune_amd._lib import rowmap
+    from modaltune_amd.engine import Engine
+    from oracle import modaltune_oracle as O
+    torch.set_num_threads(min(32, torch.get_num_threads() or 1))
+    N, L, B, D = N_FULL, N_FULL - 1, 1, 768
+    cfg = ModelConfig(depth=1, interaction_indexes=((0, 0),))
+    sizes = synth.toy_group_sizes()
+    sd_np = synth.synth_state_dict(cfg, sizes, seed=31)
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(sd_np)
+    eng._build_caches()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1, N, D, generator=g)
+    dy = torch.randn(1, N, D, generator=g) * 0.05
+    # oracle (fp32, flash path -- the call bench.py's cpu_baseline leg times)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items() if k.startswith("encoder.layers.0.")}
+    xr = x.clone().requires_grad_(True)
+    yref = O.encoder_layer(xr, sd, "encoder.layers.0", segment_lengths(), DILATED_RATIOS, attn_impl="flash")
+    yref.backward(dy)
+    # HIP: the engine's layer schedule on a hand-built context (one pass, no adapters around it)
+    ws = eng._workspace(B, L)
+    plan = ops.make_plan(branch_table(N, eng.seg_lengths, DILATED_RATIOS), N, B)
+    eng._ctx = dict(B=B, L=L, N=N, M=B * N, Mp=B * L, ws=ws, plan=plan, patch_map=rowmap(L, N, 1))
+    eng._drop_now = False
+    tape = eng.tape
+    tape.grad_enabled = True
+    tape.reset()
+    ws["hin0"].copy_(x.view(N, D))
+    eng._layer(0, ws["hout0"], None, defer=False)
+    y = ws["hout0"].clone()
+    # activation gradients travel as fp16 scaled by the loss scale (GradScaler, TM:107): use the trainer's 2^15 / 64
+    scale = 512.0
+    ws["dh"].copy_((dy * scale).view(N, D))
+    eng._ctx["dh16_valid"] = False
+    tape.run_backward()
+    torch.cuda.synchronize()
+    dx = ws["dh"].clone() / scale
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+    ry, rdx = _rel(y.view(1, N, D), yref), _rel(dx.view(1, N, D), xr.grad)
+    print(f"layer at N={N}: y rel {ry:.2e}, dx rel {rdx:.2e}")
+    assert ry < 1e-3, ry            # output of the layer (residual stream) within the north-star tolerance
+    assert rdx < 2e-2, rdx
+
+
+def test_dilated_attention_kernels_at_N10001_vs_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd import ops
+    from oracle import modaltune_oracle as O
+    torch.set_num_threads(min(32, torch.get_num_threads() or 1))
+    N, B = N_FULL, 1
+    segs, ratios = segment_lengths(), list(DILATED_RATIOS)
+    gen = torch.Generator().manual_seed(N)
+    qkv16 = (torch.randn(B, N, 2304, generator=gen) * 0.7).half()
+    ln_w = 1 + 0.1 * torch.randn(768, generator=gen)
+    ln_b = 0.1 * torch.randn(768, generator=gen)
+    dy = (torch.randn(B, N, 768, generator=gen) * 0.1).half()
+    qd = qkv16.float().requires_grad_(True)
+    q, k, v = (t.view(B, N, 16, 48) for t in qd.split(768, dim=-1))
+    mixed, outs, lses = O.dilated_attention_core(q, k, v, segs, ratios, return_branches=True, impl="flash")
+    yref = torch.nn.functional.layer_norm(mixed, (768,), ln_w, ln_b, 1e-5)
+    yref.backward(dy.float())
+    bt = branch_table(N, segs, ratios)
+    assert [(b.seg, b.nseg, b.n) for b in bt] == [(1024, 10, 1024), (5792, 2, 2896), (10001, 1, 2501), (10001, 1, 1251), (10001, 1, 626)]
+    plan = ops.make_plan(bt, N, B)
+    M, nb = B * N, len(bt)
+    dev = "cuda"
+    qkv_d = qkv16.to(dev).view(M, 3, 16, 48).permute(1, 2, 0, 3).contiguous()          # head-major [3][16][M][48]
+    o_br = torch.zeros(nb, M, 768, dtype=torch.float16, device=dev)
+    lse_br = torch.zeros(nb, M, 16, device=dev)
+    ops.dilated_attn_fwd(qkv_d, plan, o_br, lse_br)
+    y = torch.zeros(M, 768, dtype=torch.float16, device=dev)
+    stats = torch.zeros(M, 2, device=dev)
+    lse_tot = torch.zeros(M, 16, device=dev)
+    ops.dilated_mix_ln_fwd(o_br, lse_br, plan, ln_w.to(dev), ln_b.to(dev), y, stats, lse_tot)
+    dmixed = torch.zeros(M, 768, dtype=torch.float16, device=dev)
+    delta = torch.zeros(nb, M, 16, device=dev)
+    ops.dilated_mix_ln_bwd(dy.to(dev).view(M, 768), o_br, lse_br, lse_tot, plan, ln_w.to(dev), stats, dmixed, delta)
+    dqkv = torch.full((M, 2304), float("nan"), device=dev, dtype=torch.float16)
+    wsb = torch.full((ops.dilated_attn_bwd_workspace_bytes(plan) // 2,), float("nan"), device=dev, dtype=torch.float16)
+    ops.dilated_attn_bwd(qkv_d, dmixed, lse_tot, delta, plan, wsb, dqkv)
+    torch.cuda.synchronize()
+    for i in range(nb):
+        cov = lses[i].detach() > -1e7
+        got_o = o_br[i].view(B, N, 16, 48).double().cpu()
+        got_l = lse_br[i].view(B, N, 16).double().cpu()
+        ref_o, ref_l = outs[i].detach().double(), lses[i].detach().double()
+        assert float(((got_o - ref_o).abs() * cov.unsqueeze(-1)).max()) < 3e-3 * float(ref_o.abs().max()), i
+        assert float(((got_l - ref_l).abs() * cov).max()) < 2e-3, i
+    assert _rel(y.view(B, N, 768), yref) < 4e-3
+    got = dqkv.view(B, N, 2304).double().cpu()
+    assert torch.isfinite(got).all()
+    for name, sl in (("dq", slice(0, 768)), ("dk", slice(768, 1536)), ("dv", slice(1536, 2304))):
+        r = _rel(got[..., sl], qd.grad[..., sl])
+        assert r < 2e-2, (name, r)

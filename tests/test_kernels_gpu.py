@@ -579,8 +579,11 @@ def test_token_mha(ops, T):
     dq, dk, dv = (torch.zeros(B, T, E, device=DEV) for _ in range(3))
     ops.token_mha_bwd(q.to(DEV), k.to(DEV), v.to(DEV), probs, do.to(DEV), dq, dk, dv, B, T, E, 12)
     torch.cuda.synchronize()
-    assert rel(out, ref) < 1.5e-3           # q (scaled) is rounded to fp16 for the MFMA score products, P to fp16 for P.V
-    assert rel(dq, qd.grad) < 3e-3          # ds is staged as fp16 for the MFMA reduction over the keys and rel(dk, kd.grad) < 1e-4 and rel(dv, vd.grad) < 1e-4
+    # the T x T prompt self-attention runs in fp32 throughout
+    assert rel(out, ref) < 1e-4
+    assert rel(dq, qd.grad) < 1e-4
+    assert rel(dk, kd.grad) < 1e-4
+    assert rel(dv, vd.grad) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------ loss / optimiser / misc

@@ -26,7 +26,8 @@ def _build(path):
     sizes = [int(s) for s in g["sizes"]]
     cfg = ModelConfig(depth=depth, interaction_indexes=tuple(tuple(int(i) for i in p) for p in g["inter"]), slide_ngrids=ngrids,
                       clinical=bool(int(g["clinical"])) if "clinical" in g.files else False,
-                      token_agg=str(g["token_agg"]) if "token_agg" in g.files else "sum")
+                      token_agg=str(g["token_agg"]) if "token_agg" in g.files else "sum",
+                      multi_task=int(g["multi_task"]) if "multi_task" in g.files else 3)
     eng = Engine(cfg, sizes, "cuda")
     eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed))
     ts = TrainStep(eng)
@@ -35,8 +36,11 @@ def _build(path):
     return g, cfg, eng, ts, inp
 
 
-@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12", "L37_d3_clin", "L37_d3_clin_cat", "L37_d3_cat"])
+@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12", "L37_d3_clin", "L37_d3_clin_cat", "L37_d3_cat",
+                                  "L37_d3_pan", "L129_d3_pan", "L37_d3_single"])
 def test_train_step_matches_reference_golden(golden_dir, name):
+    """(pan: the pan-cancer trainer's shape, one-hot width 4 with task ids 0..2, train_modaltune_pancancer.py:50-134,537-542;
+    single: multi_task = 1, one model call, the [1, O] logits against all three text rows.)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     path = os.path.join(golden_dir, f"model_{name}.npz")
@@ -52,7 +56,7 @@ def test_train_step_matches_reference_golden(golden_dir, name):
     logits = ts.last_logits.cpu().numpy()
     report = {}
     for i in range(len(cfg.interaction_indexes)):
-        for t in range(3):
+        for t in range(logits.shape[0]):
             report[f"cls{i}/t{t}"] = _rel(eng.taps[f"cls{i}"][t].cpu().numpy(), g[f"f64_tap/task{t}/cls{i}"].reshape(-1))
             report[f"c{i}/t{t}"] = _rel(eng.taps[f"c{i}"][t].cpu().numpy(), g[f"f64_tap/task{t}/c{i}"][0])
     report["logits"] = _rel(logits, g["f64_logits"])
@@ -382,3 +386,179 @@ def test_train_mode_stochastic_step_gradient_is_consistent(golden_dir):
     with torch.no_grad():
         ev = eng.forward(x, inp["coords"], genes, oh, need_grad=False)
     assert _rel(ev.cpu().numpy(), g["f64_logits"]) < 1e-3
+
+
+def test_two_adamw_steps_match_reference_trainer_golden(golden_dir):
+    """Post-AdamW weights: the reference trainer's torch.optim.AdamW stepped twice on the reference model
+    (tests/golden/make_golden.py `adamw`) vs two TrainStep steps (device GradScaler + fused AdamW).  AdamW's normalised
+    update moves every weight by ~lr per step, so an element whose gradient is rounding noise may land up to 2 lr per step
+    away; all others must agree to a small fraction of the distance travelled."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(golden_dir, "model_L37_d3_adamw.npz")
+    g, cfg, eng, ts, inp = _build(path)
+    lr, steps = float(g["adamw_lr"]), int(g["adamw_steps"])
+    ts.set_lr(lr)
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"])
+    before = {k: v.clone() for k, v in eng.store.tensors.items() if k in eng.store.grads}
+    losses = [float(ts.step(x, inp["coords"], genes, text, update=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    assert int(ts.step_dev) == steps and int(ts.found_inf) == 0
+    assert np.allclose(losses, g["f64_adamw_losses"], rtol=1e-3, atol=0), (losses, g["f64_adamw_losses"])
+    n = 0
+    for k in g.files:
+        if not k.startswith("f64_adamw/"):
+            continue
+        key = k[len("f64_adamw/"):]
+        ref, got, old = g[k].reshape(-1), eng.store.tensors[key].double().cpu().numpy().reshape(-1), before[key].double().cpu().numpy().reshape(-1)
+        travelled = np.abs(ref - old)
+        assert travelled.mean() > 0.5 * lr, key                      # (the reference really moved these weights)
+        d = np.abs(got - ref)
+        assert d.max() <= 2.0 * steps * lr * 1.01, (key, d.max())
+        assert np.mean(d > 0.1 * steps * lr) < 0.03, (key, float(np.mean(d > 0.1 * steps * lr)))
+        n += 1
+    assert n >= 6
+
+
+def test_ragged_lengths_through_one_trainstep():
+    """Real data: a new bag length almost every slide (datasets.py:274-281 subsamples only above 25 000).  Six lengths
+    through ONE TrainStep (lr 0, so every step sees the same weights): each loss equals a fresh engine's eager step on that
+    slide; a length that comes back is captured and replayed; after the first pass over the lengths nothing is allocated
+    on the device any more and nothing synchronises the stream."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    seed, ngrids = 41, 64
+    sizes = synth.toy_group_sizes()
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)), slide_ngrids=ngrids)
+    sd = synth.synth_state_dict(cfg, sizes, seed)
+    lengths = [700, 333, 1500, 64, 1029, 512]          # the largest is not first: the workspace grows twice
+    slides = []
+    for L in lengths:
+        inp = synth.synth_inputs(L, sizes, seed + L, grid=ngrids)
+        slides.append((torch.from_numpy(inp["x"]).cuda().half().reshape(L, -1), torch.from_numpy(inp["coords"]).cuda(),
+                       [torch.from_numpy(a).cuda() for a in inp["genes"]], torch.from_numpy(inp["text"]).cuda()))
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(sd)
+    ts = TrainStep(eng, lr=0.0, weight_decay=0.0, capture_after=2)
+    ts.set_projector(synth.projector_state(seed))
+    want = []
+    for x, coords, genes, text in slides:               # fresh engine per slide, plain eager step
+        e2 = Engine(cfg, sizes, "cuda")
+        e2.load_state_dict(sd)
+        t2 = TrainStep(e2, lr=0.0, weight_decay=0.0)
+        t2.set_projector(synth.projector_state(seed))
+        want.append(float(t2.step(x, coords, genes, text, update=True)))
+        del t2, e2
+    got = [[float(ts.step_graphed(*s)) for s in slides] for _ in range(2)]      # two eager passes over the six lengths
+    for row in got:
+        assert np.allclose(row, want, rtol=2e-4, atol=0), (row, want)
+    assert ts.graph_replays == 0 and ts._graphs is None
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_reserved()
+    row = [float(ts.step_graphed(*s)) for s in slides]                          # third visit: captured ...
+    row2 = [float(ts.step_graphed(*s)) for s in slides]                         # ... and replayed
+    assert np.allclose(row, want, rtol=2e-4, atol=0) and np.allclose(row2, want, rtol=2e-4, atol=0)
+    assert ts.graph_replays == 12 and len(ts._graphs) == 6
+    # steady state of the eager schedule (capture off): no allocator growth, same losses
+    ts2 = TrainStep(eng, lr=0.0, weight_decay=0.0, capture_after=1 << 30)
+    ts2.set_projector(synth.projector_state(seed))
+    for s in slides:
+        ts2.step_graphed(*s)
+    torch.cuda.synchronize()
+    mem1 = torch.cuda.memory_reserved()
+    row3 = [float(ts2.step_graphed(*s)) for s in slides]
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_reserved() == mem1, (mem1, torch.cuda.memory_reserved())
+    assert np.allclose(row3, want, rtol=2e-4, atol=0)
+    assert int(ts.step_dev) == 24 and mem0 > 0
+    eng.check_inputs()
+
+
+def test_lr_schedule_reaches_captured_graphs_and_eager_steps(golden_dir):
+    """the learning rate is a device scalar.  The reference steps GradualWarmupScheduler + CosineAnnealingLR every
+    epoch (TM:151-154,242): set_lr() between replays must change the update of an already captured graph."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(golden_dir, "model_L37_d3.npz")
+    g, cfg, eng, ts, inp = _build(path)
+    ts.capture_after = 1
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"]).cuda()
+    ts.set_lr(1e-4)
+    key = "interactions.0.injector.gamma"
+
+    def moved(fn):
+        w0 = eng.store.tensors[key].clone()
+        fn()
+        torch.cuda.synchronize()
+        return float((eng.store.tensors[key] - w0).abs().mean())
+    step = lambda: ts.step_graphed(x, inp["coords"], genes, text)
+    d_eager = moved(step)                   # eager visit
+    d_cap = moved(step)                     # capture + first replay
+    assert ts._graphs is not None
+    d_rep = moved(step)                     # replay
+    ts.set_lr(1e-3)
+    assert ts.lr == 1e-3
+    d_big = moved(step)                     # replay of the SAME graph, 10x the learning rate
+    ts.lr = 0.0                             # attribute form
+    d_zero = moved(step)
+    d_eager0 = moved(lambda: ts.step(x, inp["coords"], genes, text))
+    for d in (d_eager, d_cap, d_rep):
+        assert 0.3e-4 < d < 1.5e-4, (d_eager, d_cap, d_rep)
+    assert 5.0 < d_big / d_rep < 15.0, (d_big, d_rep)
+    assert d_zero < 1e-9 and d_eager0 < 1e-9          # (weight decay 0.01 x lr 0 = 0 as well)
+    assert ts.graph_replays == 4
+
+
+def test_captured_graphs_are_retired_when_their_buffers_move(golden_dir):
+    """the trainer and the embedding extractor share the engine's B = 3 storage and fp16 weight caches.  A
+    workspace that grows under one of them, or load_state_dict(), must retire the other's captured graph."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.evaluate import EmbeddingExtractor
+    from modaltune_amd.trainer import TrainStep
+    seed, ngrids = 11, 128
+    sizes = synth.toy_group_sizes()
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)), slide_ngrids=ngrids)
+    eng = Engine(cfg, sizes, "cuda")
+    sd = synth.synth_state_dict(cfg, sizes, seed)
+    eng.load_state_dict(sd)
+    small, big = synth.synth_inputs(37, sizes, seed, grid=ngrids), synth.synth_inputs(900, sizes, seed + 1, grid=ngrids)
+    dev = lambda inp: (torch.from_numpy(inp["x"]).cuda(), inp["coords"], [torch.from_numpy(a).cuda() for a in inp["genes"]])
+    ex = EmbeddingExtractor(eng)
+    ref_small = EmbeddingExtractor(eng, graphed=False)(*dev(small)).clone()
+    outs = [ex(*dev(small)) for _ in range(3)]              # eager, capture, replay
+    assert ex._graph is not None and all(_rel(o.cpu().numpy(), ref_small.cpu().numpy()) < 1e-6 for o in outs)
+    assert outs[1].data_ptr() != outs[2].data_ptr()         # callers get their own tensor, not the static buffer
+    gen0 = eng.generation
+    ts = TrainStep(eng, lr=0.0, weight_decay=0.0)
+    ts.set_projector(synth.projector_state(seed))
+    xb, cb, gb = dev(big)
+    ts.step_graphed(xb, cb, gb, torch.from_numpy(big["text"]).cuda())        # a bigger bag: the shared storage is reallocated
+    assert eng.generation > gen0
+    again = ex(*dev(small))                                  # must NOT replay against the freed buffers
+    assert _rel(again.cpu().numpy(), ref_small.cpu().numpy()) < 1e-6
+    # new weights: the fp16 caches are rebuilt, captured graphs of the old ones are retired
+    for _ in range(3):
+        ex(*dev(small))
+    assert ex._graph is not None
+    sd2 = synth.synth_state_dict(cfg, sizes, seed + 7)
+    eng.load_state_dict(sd2)
+    new = ex(*dev(small))
+    want = EmbeddingExtractor(eng, graphed=False)(*dev(small))
+    assert _rel(new.cpu().numpy(), want.cpu().numpy()) < 1e-6
+    assert _rel(new.cpu().numpy(), ref_small.cpu().numpy()) > 1e-3
+    from modaltune_amd.evaluate import multitask_forward
+
+    class _M:            # task_ids=None means "all tasks" (TM:156-179)
+        is_multi, cfg = True, cfg
+
+        def forward_tasks(self, x, coords, genes, onehots, clinical=None):
+            return onehots
+    assert multitask_forward(_M(), task_ids=None, x=0, coords=0, genes=0).shape == (3, 3)

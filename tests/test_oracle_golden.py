@@ -100,7 +100,8 @@ def _run_model_case(path, dtype):
     sizes = [int(s) for s in g["sizes"]]
     cfg = ModelConfig(depth=depth, interaction_indexes=tuple(tuple(int(i) for i in p) for p in g["inter"]),
                       slide_ngrids=ngrids, clinical=bool(int(g["clinical"])) if "clinical" in g.files else False,
-                      token_agg=str(g["token_agg"]) if "token_agg" in g.files else "sum")
+                      token_agg=str(g["token_agg"]) if "token_agg" in g.files else "sum",
+                      multi_task=int(g["multi_task"]) if "multi_task" in g.files else 3)
     cfg.validate()
     sd = _sd(cfg, sizes, seed, dtype)
     inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
@@ -115,7 +116,8 @@ def _run_model_case(path, dtype):
     return g, cfg, logits, loss, grads
 
 
-@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12", "L37_d3_clin", "L37_d3_clin_cat", "L37_d3_cat"])
+@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12", "L37_d3_clin", "L37_d3_clin_cat", "L37_d3_cat",
+                                  "L37_d3_pan", "L129_d3_pan", "L37_d3_single"])
 def test_full_train_step_f64(golden_dir, name):
     path = os.path.join(golden_dir, f"model_{name}.npz")
     if not os.path.exists(path):
@@ -131,6 +133,38 @@ def test_full_train_step_f64(golden_dir, name):
     for k in g.files:
         if k.startswith("f64_grad/"):
             assert _maxrel(grads[k[len("f64_grad/"):]], g[k]) < 1e-8
+
+
+def test_two_adamw_steps_match_the_reference_trainer(golden_dir):
+    """Post-AdamW weights: the reference trainer's optimiser (torch.optim.AdamW over the requires_grad parameters,
+    TM:139-149) stepped twice on the reference model; the oracle repeats it with its own forward / backward and
+    adamw_update."""
+    path = os.path.join(golden_dir, "model_L37_d3_adamw.npz")
+    g, cfg, logits, loss, grads = _run_model_case(path, F64)
+    lr, steps = float(g["adamw_lr"]), int(g["adamw_steps"])
+    L, seed, ngrids = int(g["L"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    sd = _sd(cfg, sizes, seed, F64)
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    psd = {k: torch.from_numpy(v).to(F64) for k, v in synth.projector_state(seed).items()}
+    args = (torch.from_numpy(inp["x"]).to(F64), torch.from_numpy(inp["coords"]).to(F64), [torch.from_numpy(a).to(F64) for a in inp["genes"]],
+            torch.from_numpy(inp["text"]).to(F64), psd, segment_lengths())
+    trainable = synth.trainable_keys(cfg, sizes)
+    m = {k: torch.zeros_like(sd[k]) for k in trainable}
+    v = {k: torch.zeros_like(sd[k]) for k in trainable}
+    losses = []
+    for step in range(1, steps + 1):
+        _, ls, gr = O.train_step_loss_and_grads(sd, cfg, trainable, *args)
+        losses.append(float(ls))
+        for k in trainable:
+            sd[k], m[k], v[k] = O.adamw_update(sd[k], gr[k], m[k], v[k], step, lr)
+    assert np.allclose(losses, g["f64_adamw_losses"], rtol=1e-9, atol=0)
+    n = 0
+    for k in g.files:
+        if k.startswith("f64_adamw/"):
+            assert _maxrel(sd[k[len("f64_adamw/"):]], g[k]) < 1e-9, k
+            n += 1
+    assert n >= 6
 
 
 def test_full_train_step_f32_matches_reference_f32(golden_dir):
