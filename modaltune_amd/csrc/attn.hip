@@ -55,15 +55,15 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   for (int ks = 0; ks < 3; ++ks)
     qf[ks] = sel8(qvalid, ldg8(hm_ptr(qkv, M, w.h, qrow) + ks * 16 + hh * 8));
 
-  const StageIdx st(tid);
+  const StageRow st(tid);      // conflict-free staging stores (attn_common.h)
   const int ntile = (sq.n + 63) / 64;
   const int nproc = (nv + 63) >> 6;      // tiles holding at least one real key
   // tiles [0, nfull) hold only real rows: loaded with a uniform base + constant 32-bit lane offset, no clamp, no select
   const int nfull = nv >> 6;
   const __amdgpu_buffer_rsrc_t krs = make_rsrc(hm_ptr(qkv, M, H + w.h, sq.row(0)));
   const __amdgpu_buffer_rsrc_t vrs = make_rsrc(hm_ptr(qkv, M, 2 * H + w.h, sq.row(0)));
-  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
-  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
+  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part * 8) * 2u;
+  const uint32_t c1 = (uint32_t)(st.row1 * sq.dr * HD + st.part * 8) * 2u;
   h16x8 rk0, rk1, rv0, rv1;
   bool kok0 = false, kok1 = false, vok0 = false, vok1 = false;
   // ragged tiles: unconditional loads of clamped rows; padded rows are zeroed by a select when the tile goes to LDS
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       rk0 = buf_ldg8(krs, c0, adv); rk1 = buf_ldg8(krs, c1, adv);
     } else {
       const int i0 = kb + st.row0, i1 = kb + st.row1;
-      rk0 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
-      rk1 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
+      rk0 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i0)) + st.part * 8);
+      rk1 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i1)) + st.part * 8);
       kok0 = sq.valid(i0); kok1 = sq.valid(i1);
     }
   };
@@ -86,22 +86,26 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       rv0 = buf_ldg8(vrs, c0, adv); rv1 = buf_ldg8(vrs, c1, adv);
     } else {
       const int i0 = kb + st.row0, i1 = kb + st.row1;
-      rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i0)) + st.part0 * 8);
-      rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i1)) + st.part1 * 8);
+      rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i0)) + st.part * 8);
+      rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i1)) + st.part * 8);
       vok0 = sq.valid(i0); vok1 = sq.valid(i1);
     }
   };
   auto lstore_k = [&](int buf, auto full_tag) {
     h16x8 a = rk0, b = rk1;
     if (!decltype(full_tag)::value) { a = sel8(kok0, a); b = sel8(kok1, b); }
-    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = a;
-    if (st.has1) *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = b;
+    if (st.act) {
+      *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part * 8]) = a;
+      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part * 8]) = b;
+    }
   };
   auto lstore_v = [&](int buf, auto full_tag) {
     h16x8 a = rv0, b = rv1;
     if (!decltype(full_tag)::value) { a = sel8(vok0, a); b = sel8(vok1, b); }
-    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part0 * 8]) = a;
-    if (st.has1) *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part1 * 8]) = b;
+    if (st.act) {
+      *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part * 8]) = a;
+      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part * 8]) = b;
+    }
   };
   auto qk = [&](int buf, f32x16 (&s)[2]) {      // raw scores of one 64-key tile: s[sub][reg] (key = row, query = lane)
 #pragma unroll

@@ -181,13 +181,30 @@ MT_DEVINL Seq make_seq(const Plan& p, const WorkItem& w) {
   return q;
 }
 
-// Per-thread staging slots for a 64-row x 48-col fp16 tile = 384 chunks of 16 B: chunk tid, and (tid < 128) chunk 256+tid.
-struct StageIdx {
+// Per-thread staging slots of a 64-row x 48-col fp16 tile = 384 chunks of 16 B.
+//
+// A ds_write_b128 is served in groups of eight consecutive lanes over 32 banks, so a group is conflict-free when its
+// 16-byte pieces sit on distinct 16-byte slots modulo 128 B.  PACKED form (chunk id = thread id, six lanes per row; 1.5
+// store instructions per wave and image): a group holds pieces of two rows and pays a 2-way conflict in every image used
+// here (tools/lds_bank_check.py; SQ_LDS_BANK_CONFLICT: 23 % of the forward kernel's LDS cycles, 11 % of the dK/dV
+// kernel's).  ROW form (eight lanes per row, two of them idle; 2 store instructions per wave and image): one row per
+// group, consecutive pieces, conflict-free in every image.  Same-box A/B (tools/ab_lib.sh): the forward kernel times
+// the same with either (its LDS array is 39 % busy), the backward kernels run 1 % slower with the ROW form (one more
+// store + load instruction per wave and image in kernels that sit on the issue port), so they keep the packed form.
+struct StageIdx {       // packed
   int row0, part0, row1, part1; bool has1;
   MT_DEVINL StageIdx(int tid) {
     row0 = tid / 6; part0 = tid - row0 * 6;
     const int c = 256 + tid;
     row1 = c / 6; part1 = c - row1 * 6; has1 = tid < 128;
+  }
+};
+struct StageRow {       // eight lanes per row
+  int row0, row1, part; bool act;
+  MT_DEVINL StageRow(int tid) {
+    row0 = tid >> 3; row1 = 32 + row0;
+    act = (tid & 7) < 6;
+    part = min(tid & 7, 5);          // idle lanes re-read chunk 5 (same cache line) and store nothing
   }
 };
 

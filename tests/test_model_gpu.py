@@ -556,8 +556,10 @@ def test_captured_graphs_are_retired_when_their_buffers_move(golden_dir):
     assert _rel(new.cpu().numpy(), ref_small.cpu().numpy()) > 1e-3
     from modaltune_amd.evaluate import multitask_forward
 
+    model_cfg = cfg
+
     class _M:            # task_ids=None means "all tasks" (TM:156-179)
-        is_multi, cfg = True, cfg
+        is_multi, cfg = True, model_cfg
 
         def forward_tasks(self, x, coords, genes, onehots, clinical=None):
             return onehots
