@@ -139,6 +139,7 @@ int mt_layernorm_bwd(const void* dy, long lddy, const MtRowMap* dymap, int dy_dt
 
 /* ------------------------------------------------------- dilated attention ------------------------- */
 #define MT_MAX_BRANCHES 8
+#define MT_QK_SCALE_LOG2 0.20823509396846288f     /* 48^-1/2 * log2(e) */
 typedef struct {
   int nbranch;
   int N;                              /* tokens per pass (L + 1) */
@@ -149,8 +150,11 @@ typedef struct {
   int n[MT_MAX_BRANCHES];             /* sparse length ceil(s / r) incl. zero padding DA:22-37  */
 } MtDilatedPlan;
 
-/* qkv: fp16 HEAD-MAJOR [3][16][B*N][48] (q | k | v; MT_EPI_QKV_HM writes it).  For every branch, every (segment, head):
- * O_b = softmax(Q K^T / sqrt(48)) V over the head's dilated positions, zero-padded rows acting as keys with
+/* qkv: fp16 HEAD-MAJOR [3][16][B*N][48] (q' | k | v; MT_EPI_QKV_HM writes it).  The q slab holds
+ * q' = MT_QK_SCALE_LOG2 * q with MT_QK_SCALE_LOG2 = 48^-1/2 * log2(e): the caller bakes the softmax scale (MHA:109-119
+ * scaling = head_dim^-0.5; in log2 units because the kernels exponentiate with v_exp_f32 = 2^x) into the q rows of the
+ * frozen q_proj weight and bias before rounding them to fp16, so no kernel multiplies by it and q is rounded once.
+ * For every branch, every (segment, head): O_b = softmax(Q K^T / sqrt(48)) V over the head's dilated positions, zero-padded rows acting as keys with
  * logit 0 / value 0 (DA:98-101,24-28).  o_br: fp16 [nbranch][B*N, 768]; lse_br: fp32 [nbranch][B*N, 16]
  * (natural log).  (position, head) pairs a branch does not visit are left untouched.  DA:212-253, MHA:109-119. */
 int mt_dilated_attn_fwd(const mt_half* qkv, const MtDilatedPlan* plan, mt_half* o_br, float* lse_br,
@@ -168,7 +172,8 @@ int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, const float* l
                           const MtDilatedPlan* plan, const float* ln_w, const float* stats, mt_half* dmixed,
                           float* delta_br, mt_stream_t stream);
 
-/* Flash-style backward of all branches: dqkv fp16 [B*N, 2304] (overwritten) from qkv, dmixed, lse_tot, delta_br.
+/* Flash-style backward of all branches: dqkv fp16 [B*N, 2304] (overwritten) from qkv, dmixed, lse_tot, delta_br.  The q
+ * columns of dqkv are the gradient with respect to the PRE-SCALED q' (what the dX GEMM through the scaled q_proj cache needs).
  * P~ = exp(s - lse_tot) (= w_b P_b), dS = P~ (dmixed V^T - delta_b), dQ = dS K, dK = dS^T Q, dV = P~^T dmixed.
  * Two launches cover all branches (a dK/dV kernel with key = lane, a dQ kernel with query = lane); each writes its
  * per-branch result once into `workspace` (fp16, mt_dilated_attn_bwd_workspace_bytes) and a combine kernel sums the

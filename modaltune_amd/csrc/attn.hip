@@ -31,7 +31,6 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
-  const float c = 0.14433756729740643f * LOG2E;   // 48^-1/2 * log2(e)
   // Entries [nv, n) of the sparse sequence are zero padding (segment / sequence end): as QUERIES they produce nothing
   // that is ever read, as KEYS they all have logit 0 and value 0.  A workgroup of padded queries exits; key tiles
   // made only of padding are not computed -- their sum(P) share is added in closed form after the loop.
@@ -50,6 +49,8 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   const int iq = w.qt * 128 + wave * 32 + l31;
   const bool qvalid = sq.valid(iq);
   const long qrow = sq.row_clamped(iq);
+  // q arrives pre-scaled (attn_common.h: QK_SCALE_LOG2): S' = K . Q'^T is the exp2 argument as it leaves the MFMA chain, up
+  // to the running reference m2 -- which rides in as the INITIAL accumulator (below).
   h16x8 qf[3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
@@ -107,15 +108,15 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part * 8]) = b;
     }
   };
-  auto qk = [&](int buf, f32x16 (&s)[2]) {      // raw scores of one 64-key tile: s[sub][reg] (key = row, query = lane)
+  // scores of one 64-key tile relative to the reference: s[sub][reg] = c q.k - m2 (key = row, query = lane); `init` is the
+  // accumulator the chains start from (splat(-m2): the query is the lane, so one value per lane)
+  auto qk = [&](int buf, f32x16 (&s)[2], const f32x16& init) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
-#pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const h16x8 kf = *reinterpret_cast<const h16x8*>(&Ks[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? init : s[sub], 0, 0, 0);
       }
     }
   };
@@ -123,12 +124,33 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   f32x16 o0, o1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-  float m_run = NEG_BIG;      // running row maximum of the RAW logits q.k (scale c folded into the exp2 argument)
 
   // prologue: tile 0 -> LDS
   gload_k(0, std::false_type{}); gload_v(0, std::false_type{});
   lstore_k(0, std::false_type{}); lstore_v(0, std::false_type{});
   __syncthreads();
+  // Running reference m2 of the scaled logits (log2 units), carried as the accumulator initialiser minit = splat(-m2).  It
+  // starts at the row maximum over tile 0's REAL keys (one extra S product per workgroup; tile 0 is then processed by the
+  // loop like every other tile) and moves up only through the deferred rescale below.
+  float m2;
+  f32x16 minit;
+  {
+    f32x16 s0[2], zero;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+    qk(0, s0, zero);
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kidx = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        mx = fmaxf(mx, kidx < sq.n ? s0[sub][i] : NEG_BIG);
+      }
+    m2 = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) minit[i] = -m2;
+  }
 
   // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
     const int kb = t * 64, buf = t & 1;
     if (!LAST) { gload_k(t + 1, next_tag); gload_v(t + 1, next_tag); }
     f32x16 s_cur[2];
-    qk(buf, s_cur);
+    qk(buf, s_cur, minit);
     // keys >= n are tile padding (excluded, last tile only); zero-padded keys keep logit 0 (DA:98-101)
     float mx = NEG_BIG;
 #pragma unroll
@@ -152,16 +174,17 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
         mx = fmaxf(mx, s_cur[sub][i]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // Deferred rescale (exact): the reference point m_run only moves when some row's maximum grew by more than
-    // 2^RESCALE_LOG2; until then P = exp2((s - m_run) c) <= 2^RESCALE_LOG2, which fp16 P / fp32 O hold without loss.
-    if (__any((m_new - m_run) * c > RESCALE_LOG2)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    // Deferred rescale (exact): the reference m2 only moves when some row's maximum grew by more than 2^RESCALE_LOG2 past
+    // it; until then P = exp2(c s - m2) <= 2^RESCALE_LOG2, which fp16 P / fp32 O hold without loss.
+    if (__any(mx > RESCALE_LOG2)) {
+      const float up = fmaxf(mx, 0.f);               // this row's reference moves up by `up`
+      const float alpha = __builtin_amdgcn_exp2f(-up);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-      m_run = m_new;
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; s_cur[0][i] -= up; s_cur[1][i] -= up; }
+      m2 += up;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) minit[i] = -m2;
     }
-    const f32x2 c2 = {c, c}, nmc2 = {-m_run * c, -m_run * c};
     // O^T += V^T . P^T ; A fragment element e of lane half hh = V[key 16 s2 + 8 (e>>2) + 4 hh + (e&3)][d = lane & 31]
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
         h16x8 pf;
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-          const f32x2 a = pk_exp2(pk_fma((f32x2){s_cur[sub][8 * s2 + e], s_cur[sub][8 * s2 + e + 1]}, c2, nmc2));
+          const f32x2 a = pk_exp2((f32x2){s_cur[sub][8 * s2 + e], s_cur[sub][8 * s2 + e + 1]});
           pf[e] = (h16)a[0]; pf[e + 1] = (h16)a[1];
         }
         const h16* vrow = &Vs[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
@@ -191,14 +214,14 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   else tile(nproc - 1, std::true_type{}, std::false_type{}, std::false_type{});
   const int rest = sq.n - nproc * 64;      // padded keys in the tiles not computed: logit 0, value 0
   if (rest > 0) {
-    const float m_new = fmaxf(m_run, 0.f);
-    if (__any((m_new - m_run) * c > RESCALE_LOG2)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    if (__any(-m2 > RESCALE_LOG2)) {             // logit 0 lies more than the threshold above the reference
+      const float up = fmaxf(-m2, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-up);
 #pragma unroll
       for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-      m_run = m_new;
+      m2 += up;
     }
-    o1[8] += (float)rest * __builtin_amdgcn_exp2f(-m_run * c);
+    o1[8] += (float)rest * __builtin_amdgcn_exp2f(-m2);
   }
 
   if (qvalid) {
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
       h16x4 v = {(h16)(o1[4 * gq] * inv), (h16)(o1[4 * gq + 1] * inv), (h16)(o1[4 * gq + 2] * inv), (h16)(o1[4 * gq + 3] * inv)};
       *reinterpret_cast<h16x4*>(orow + 32 + 8 * gq + 4 * hh) = v;
     }
-    if (hh == 0) lse_br[((long)w.br * M + qrow) * H + w.h] = (m_run * c + __log2f(l)) * LN2;
+    if (hh == 0) lse_br[((long)w.br * M + qrow) * H + w.h] = (m2 + __log2f(l)) * LN2;
   }
 }
 
@@ -387,9 +410,9 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // backward, kernel Q: dQ.  Same decomposition as the forward (query = lane).
-//   P'^T = exp2(c S^T - L2[q] + log2(scale))   (L2 = lse_tot * log2e; P' = w_b * P_b / sqrt(48))
+//   P'^T = exp2(S'^T - L2[q] + log2(ln 2))     (S' = K . Q'^T with the pre-scaled q'; L2 = lse_tot * log2e; P' = ln2 w_b P_b)
 //   dP^T[key,q] = V . dO^T                      V rows from LDS, dO^T in registers
-//   dS^T = P'^T (dP^T - delta_b[q])             (the 1/sqrt(48) of dS rides inside P')
+//   dS^T = P'^T (dP^T - delta_b[q])             (= dL/dS': the ln 2 rides inside P')
 //   dQ^T[d,q] += K^T[d,key] . dS^T              K^T via transposed LDS reads
 // The elementwise block is written with packed fp32 ops (v_pk_fma/add/mul_f32): these kernels issue about as many
 // VALU cycles as MFMA cycles, and the two did not overlap (PMC: VALU 49 %, MFMA 37 % busy before this form).
@@ -405,7 +428,6 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
-  const float c = 0.14433756729740643f * LOG2E;
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   // padded queries get no gradient; padded keys have K = 0 and add nothing to dQ: neither is computed
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
@@ -428,9 +450,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   }
   // invalid queries: -L2 = -big -> P' = 0
   const float L2raw = lse_tot[qrow * H + w.h], dlraw = delta_br[((long)w.br * M + qrow) * H + w.h];
-  const float nl2 = qvalid ? fmaf(-L2raw, LOG2E, LOG2_SCALE) : -1.0e30f;
+  const float nl2 = qvalid ? fmaf(-L2raw, LOG2E, LOG2_LN2) : -1.0e30f;
   const float ndl = qvalid ? -dlraw : 0.f;
-  const f32x2 c2 = {c, c}, nl22 = {nl2, nl2}, ndl2 = {ndl, ndl};
+  const f32x2 nl22 = {nl2, nl2}, ndl2 = {ndl, ndl};
 
   const StageIdx st(tid);
   const int ntile = (nv + 63) >> 6;      // tiles holding at least one real key
@@ -496,7 +518,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
       h16x8 dsf[2];
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        f32x2 pt = pk_exp2(pk_fma((f32x2){s[i], s[i + 1]}, c2, nl22));
+        f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]} + nl22);
         if (TAIL) {
           const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
           if (kidx >= sq.n) pt[0] = 0.f;
@@ -543,10 +565,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 // sweeping the queries of the same sparse sequence in tiles of 64.
 //   S[q,key]  = Q . K^T            Q rows from LDS, K^T in registers
 //   dP[q,key] = dO . V^T           dO rows from LDS, V^T in registers
-//   P' = exp2(c S - L2[q] + log2(scale)) ; dS = P' (dP - delta[q])        (P' = P~ / sqrt(48); c rides on K)
-//   dV^T[d,key] += dO^T[d,q] . P'  (rescaled by sqrt(48) once at the end) ; dK^T[d,key] += Q^T[d,q] . dS
-// LDS holds -L2 + log2 scale and -delta per query; they are read straight into the S / dP accumulators before the
-// MFMA chains, and the K fragments carry the softmax scale, so the elementwise block is 1 packed mul, 2 exp and 2 packed
+//   P' = exp2(S' - L2[q] + log2(ln 2)) ; dS = P' (dP - delta[q])          (S' = Q' . K^T, q pre-scaled; P' = ln2 P~)
+//   dV^T[d,key] += dO^T[d,q] . P'  (rescaled by 1 / ln 2 once at the end) ; dK^T[d,key] += Q'^T[d,q] . dS
+// LDS holds -L2 + log2(ln 2) and -delta per query; they are read straight into the S / dP accumulators before the
+// MFMA chains, and q carries the softmax scale, so the elementwise block is 1 packed mul, 2 exp and 2 packed
 // converts per element pair.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
@@ -561,7 +583,6 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
-  const float c = 0.14433756729740643f * LOG2E;
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   // padded keys get no gradient; padded queries have P' = 0: neither is computed
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
@@ -581,10 +602,6 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
   for (int ks = 0; ks < 3; ++ks) {
     kf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, H + w.h, krow) + ks * 16 + hh * 8));
     vf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, 2 * H + w.h, krow) + ks * 16 + hh * 8));
-    // the softmax scale (in log2 units) rides on this lane's K fragment, which is only ever used for S: one multiply
-    // per WORKGROUP instead of one per score element (S' = Q . (c K)^T is the exp2 argument as it leaves the MFMA chain)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) kf[ks][e] = (h16)((float)kf[ks][e] * c);
   }
 
   const StageIdx st(tid);
@@ -629,7 +646,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     }
     if (tid < 64) {      // padded / out-of-range queries contribute nothing: -L2 = -big -> P' = 0
       const bool ok = FULL || ok2;
-      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_SCALE) : -1.0e30f;
+      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_LN2) : -1.0e30f;
       Dls[tid] = ok ? -rdl : 0.f;
     }
   };
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       // row constants ride in as the INITIAL accumulators (rows of the accumulators are queries:
-      // row(i) = (i&3) + 8 (i>>2) + 4 hh): S' = Q.K^T + (-L2 + log2 scale) / c, dP' = dO.V^T - delta
+      // row(i) = (i&3) + 8 (i>>2) + 4 hh): S' - L2 + log2(ln 2), dP' = dO.V^T - delta
       f32x16 s, dp;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -704,16 +721,16 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const h16x4 a = {(h16)dk0[4 * gq], (h16)dk0[4 * gq + 1], (h16)dk0[4 * gq + 2], (h16)dk0[4 * gq + 3]};
-      const h16x4 b = {(h16)(dv0[4 * gq] * INV_SCALE), (h16)(dv0[4 * gq + 1] * INV_SCALE), (h16)(dv0[4 * gq + 2] * INV_SCALE),
-                       (h16)(dv0[4 * gq + 3] * INV_SCALE)};
+      const h16x4 b = {(h16)(dv0[4 * gq] * INV_LN2), (h16)(dv0[4 * gq + 1] * INV_LN2), (h16)(dv0[4 * gq + 2] * INV_LN2),
+                       (h16)(dv0[4 * gq + 3] * INV_LN2)};
       *reinterpret_cast<h16x4*>(outk + 8 * gq + 4 * hh) = a;
       *reinterpret_cast<h16x4*>(outv + 8 * gq + 4 * hh) = b;
     }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
       const h16x4 a = {(h16)dk1[4 * gq], (h16)dk1[4 * gq + 1], (h16)dk1[4 * gq + 2], (h16)dk1[4 * gq + 3]};
-      const h16x4 b = {(h16)(dv1[4 * gq] * INV_SCALE), (h16)(dv1[4 * gq + 1] * INV_SCALE), (h16)(dv1[4 * gq + 2] * INV_SCALE),
-                       (h16)(dv1[4 * gq + 3] * INV_SCALE)};
+      const h16x4 b = {(h16)(dv1[4 * gq] * INV_LN2), (h16)(dv1[4 * gq + 1] * INV_LN2), (h16)(dv1[4 * gq + 2] * INV_LN2),
+                       (h16)(dv1[4 * gq + 3] * INV_LN2)};
       *reinterpret_cast<h16x4*>(outk + 32 + 8 * gq + 4 * hh) = a;
       *reinterpret_cast<h16x4*>(outv + 32 + 8 * gq + 4 * hh) = b;
     }

@@ -14,8 +14,14 @@ constexpr int VSTR = 96;    // halves per V-layout LDS row (192 B: conflict-free
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float RESCALE_LOG2 = 8.0f;
-constexpr float LOG2_SCALE = -2.7924812503605781f;   // log2(48^-1/2)
-constexpr float INV_SCALE = 6.9282032302755092f;     // sqrt(48)
+// The q slab of the head-major q|k|v buffer holds q' = (48^-1/2 log2 e) q: the softmax scale, in log2 units, is baked into
+// the q rows of the frozen projection's fp16 weight cache (engine.py), so s' = q'.k is the exp2 argument as it leaves the
+// MFMA chain and no kernel multiplies by it.  Backward: dL/ds' = ln2 P (dP - delta), so P'' = ln2 P = exp2(s' - L2 + log2 ln2)
+// carries the factor; dq' = dS''.k and dk = dS''^T.q' are the gradients the dX GEMM (which reads the same scaled cache) needs,
+// dv = P^T dO = P''^T dO / ln2.
+constexpr float QK_SCALE_LOG2 = 0.14433756729740643f * 1.4426950408889634f;   // 48^-1/2 * log2(e)
+constexpr float LOG2_LN2 = -0.52876637294489768f;    // log2(ln 2)
+constexpr float INV_LN2 = 1.4426950408889634f;
 
 struct Plan {
   int nbranch, N, B;

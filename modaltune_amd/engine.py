@@ -77,6 +77,17 @@ class ParamStore:
         return Param(self.tensors[k], self.grads.get(k))
 
 
+QK_SCALE_LOG2 = 0.14433756729740643 * 1.4426950408889634      # 48^-1/2 * log2(e) (include/modaltune_hip.h: MT_QK_SCALE_LOG2)
+
+
+def _scaled_copy(t: torch.Tensor, alpha: float) -> torch.Tensor:
+    """alpha * t as a new fp32 tensor (mt_axpy_dev; the scale factor of the attention's q projection)."""
+    out = torch.empty_like(t)
+    a = torch.full((1,), float(alpha), dtype=F32, device=t.device)
+    ops.axpy_dev(None, t.contiguous(), a, out)
+    return out
+
+
 class _W16:
     """fp16 caches of one nn.Linear weight: as stored [N,K] (forward) and transposed [K,N] (dX GEMM)."""
 
@@ -187,13 +198,15 @@ class Engine:
         self._frozen16 = {"patch": _W16([t["patch_embed.proj.weight"]], dev, need_t=False)}
         for l in range(cfg.depth):
             p = f"encoder.layers.{l}."
-            self._frozen16[p + "qkv"] = _W16([t[p + "self_attn.q_proj.weight"], t[p + "self_attn.k_proj.weight"],
-                                              t[p + "self_attn.v_proj.weight"]], dev)
+            # the attention kernels take q pre-multiplied by 48^-1/2 log2(e): baked into the frozen q rows / bias here, in
+            # fp32, so q is still rounded to fp16 exactly once (by the QKV GEMM's epilogue)
+            self._frozen16[p + "qkv"] = _W16([_scaled_copy(t[p + "self_attn.q_proj.weight"], QK_SCALE_LOG2),
+                                              t[p + "self_attn.k_proj.weight"], t[p + "self_attn.v_proj.weight"]], dev)
             self._frozen16[p + "out"] = _W16([t[p + "self_attn.out_proj.weight"]], dev)
             self._frozen16[p + "fc1"] = _W16([t[p + "ffn.fc1.weight"]], dev)
             self._frozen16[p + "fc2"] = _W16([t[p + "ffn.fc2.weight"]], dev)
-            self._frozen16[p + "bqkv"] = torch.cat([t[p + "self_attn.q_proj.bias"], t[p + "self_attn.k_proj.bias"],
-                                                    t[p + "self_attn.v_proj.bias"]]).contiguous()
+            self._frozen16[p + "bqkv"] = torch.cat([_scaled_copy(t[p + "self_attn.q_proj.bias"], QK_SCALE_LOG2),
+                                                    t[p + "self_attn.k_proj.bias"], t[p + "self_attn.v_proj.bias"]]).contiguous()
         self._train16 = {}
         self._pack_table = None
         for pref in self._cross_attn_prefixes():

@@ -80,11 +80,16 @@ def test_dilated_attention_kernels_at_N10001_vs_oracle():
     N, B = N_FULL, 1
     segs, ratios = segment_lengths(), list(DILATED_RATIOS)
     gen = torch.Generator().manual_seed(N)
-    qkv16 = (torch.randn(B, N, 2304, generator=gen) * 0.7).half()
+    QK = 0.14433756729740643 * 1.4426950408889634       # MT_QK_SCALE_LOG2: the kernels take q' = QK q
+    raw = (torch.randn(B, N, 2304, generator=gen) * 0.7).half()
+    qkv16 = raw.clone()
+    qkv16[..., :768] = (raw[..., :768].float() * QK).half()
+    qkv_eff = qkv16.float()
+    qkv_eff[..., :768] /= QK                            # what the kernels see, exactly
     ln_w = 1 + 0.1 * torch.randn(768, generator=gen)
     ln_b = 0.1 * torch.randn(768, generator=gen)
     dy = (torch.randn(B, N, 768, generator=gen) * 0.1).half()
-    qd = qkv16.float().requires_grad_(True)
+    qd = qkv_eff.requires_grad_(True)
     q, k, v = (t.view(B, N, 16, 48) for t in qd.split(768, dim=-1))
     mixed, outs, lses = O.dilated_attention_core(q, k, v, segs, ratios, return_branches=True, impl="flash")
     yref = torch.nn.functional.layer_norm(mixed, (768,), ln_w, ln_b, 1e-5)
@@ -119,6 +124,7 @@ def test_dilated_attention_kernels_at_N10001_vs_oracle():
     assert _rel(y.view(B, N, 768), yref) < 4e-3
     got = dqkv.view(B, N, 2304).double().cpu()
     assert torch.isfinite(got).all()
+    got[..., :768] *= QK                                # the q columns are the gradient w.r.t. q'
     for name, sl in (("dq", slice(0, 768)), ("dk", slice(768, 1536)), ("dv", slice(1536, 2304))):
         r = _rel(got[..., sl], qd.grad[..., sl])
         assert r < 2e-2, (name, r)

@@ -317,6 +317,18 @@ def _hm(qkv_tok):
     return qkv_tok.view(M, 3, 16, 48).permute(1, 2, 0, 3).contiguous()
 
 
+QK = 0.14433756729740643 * 1.4426950408889634      # MT_QK_SCALE_LOG2: the kernels take q pre-multiplied by it
+
+
+def _prescale(qkv16):
+    """fp16 q|k|v [.., 2304] -> (kernel input with q' = fp16(QK q), the exact fp64 q|k|v the kernels then see: q'/QK | k | v)."""
+    k16 = qkv16.clone()
+    k16[..., :768] = (qkv16[..., :768].float() * QK).half()
+    eff = k16.double()
+    eff[..., :768] /= QK
+    return k16, eff
+
+
 def _hm_inv(dm_hm, M):
     """head-major [16][M][48] -> token-major [M, 768]."""
     return dm_hm.view(16, M, 48).permute(1, 0, 2).reshape(M, 768)
@@ -346,7 +358,7 @@ def test_dilated_attention_fwd_mix_vs_reference_golden(ops, golden_dir, case):
     g, N, segs, ratios, qkv = _qkv_for_case(golden_dir, case)
     B = qkv.shape[0]
     M = B * N
-    qkv16 = qkv.half()
+    qkv16, qkv_eff = _prescale(qkv.half())
     bt = branch_table(N, segs, ratios)
     plan = ops.make_plan(bt, N, B)
     nb = len(bt)
@@ -361,7 +373,7 @@ def test_dilated_attention_fwd_mix_vs_reference_golden(ops, golden_dir, case):
     ops.dilated_mix_ln_fwd(o_br, lse_br, plan, ln_w, ln_b, y, stats, lse_tot)
     torch.cuda.synchronize()
     # reference on the SAME fp16-rounded q,k,v (isolates kernel error from input rounding)
-    q, k, v = (t.view(B, N, 16, 48) for t in qkv16.double().split(768, dim=-1))
+    q, k, v = (t.view(B, N, 16, 48) for t in qkv_eff.split(768, dim=-1))
     mixed, outs, lses = O.dilated_attention_core(q, k, v, segs, ratios, return_branches=True)
     for i, b in enumerate(bt):
         cov = lses[i] > -1e7                                  # [B, N, H]
@@ -391,7 +403,7 @@ def test_dilated_attention_deferred_rescale_branch(ops):
     v = torch.randn(B, N, 16, 48, generator=g)
     for pos, key, gain in ((5, 700, 40.0), (1100, 1400, 60.0), (300, 1023, 25.0), (1499, 1300, 80.0)):
         k[0, key] = q[0, pos] * gain          # a huge logit for query `pos` at a late key
-    qkv = torch.cat([q.reshape(B, N, 768), k.reshape(B, N, 768), v.reshape(B, N, 768)], -1).half()
+    qkv, qkv_eff = _prescale(torch.cat([q.reshape(B, N, 768), k.reshape(B, N, 768), v.reshape(B, N, 768)], -1).half())
     bt = branch_table(N, segs, ratios)
     plan = ops.make_plan(bt, N, B)
     M = B * N
@@ -399,7 +411,7 @@ def test_dilated_attention_deferred_rescale_branch(ops):
     lse_br = torch.zeros(5, M, 16, device=DEV)
     ops.dilated_attn_fwd(_hm(qkv.to(DEV).view(M, 2304)), plan, o_br, lse_br)
     torch.cuda.synchronize()
-    qd, kd, vd = (t.view(B, N, 16, 48) for t in qkv.double().split(768, dim=-1))
+    qd, kd, vd = (t.view(B, N, 16, 48) for t in qkv_eff.split(768, dim=-1))
     _, outs, lses = O.dilated_attention_core(qd, kd, vd, segs, ratios, return_branches=True)
     for i in range(5):
         cov = lses[i] > -1e7
@@ -416,7 +428,7 @@ def test_dilated_attention_bwd_vs_oracle_autograd(ops, golden_dir, case):
     g, N, segs, ratios, qkv = _qkv_for_case(golden_dir, case)
     B = qkv.shape[0]
     M = B * N
-    qkv16 = qkv.half()
+    qkv16, qkv_eff = _prescale(qkv.half())
     bt = branch_table(N, segs, ratios)
     plan = ops.make_plan(bt, N, B)
     nb = len(bt)
@@ -425,7 +437,7 @@ def test_dilated_attention_bwd_vs_oracle_autograd(ops, golden_dir, case):
     ln_b = 0.1 * torch.randn(768, generator=gen)
     dy = (torch.randn(B, N, 768, generator=gen) * 0.1).half()
     # oracle: fp64 autograd through dilated attention + inner LN on the fp16-rounded inputs
-    qd = qkv16.double().requires_grad_(True)
+    qd = qkv_eff.requires_grad_(True)
     q, k, v = (t.view(B, N, 16, 48) for t in qd.split(768, dim=-1))
     mixed = O.dilated_attention_core(q, k, v, segs, ratios)
     yref = torch.nn.functional.layer_norm(mixed, (768,), ln_w.double(), ln_b.double(), 1e-5)
@@ -449,6 +461,7 @@ def test_dilated_attention_bwd_vs_oracle_autograd(ops, golden_dir, case):
     assert rel(y.view(B, N, 768), yref) < 4e-3
     got = dqkv.view(B, N, 2304).double().cpu()
     assert torch.isfinite(got).all()
+    got[..., :768] *= QK          # the q columns are the gradient w.r.t. q' = QK q
     for name, sl in (("dq", slice(0, 768)), ("dk", slice(768, 1536)), ("dv", slice(1536, 2304))):
         r = rel(got[..., sl], qd.grad[..., sl])
         assert r < 2e-2, (name, r)
@@ -464,11 +477,11 @@ def test_dilated_attention_padded_segment_tail(ops, N):
     gen = rng(N)
     B = 1
     segs, ratios = [1024, 5792, 32768, 185363, 1048576], [1, 2, 4, 8, 16]
-    qkv16 = (torch.randn(B, N, 2304, generator=gen) * 0.7).half()
+    qkv16, qkv_eff = _prescale((torch.randn(B, N, 2304, generator=gen) * 0.7).half())
     ln_w = (1 + 0.1 * torch.randn(768, generator=gen))
     ln_b = 0.1 * torch.randn(768, generator=gen)
     dy = (torch.randn(B, N, 768, generator=gen) * 0.1).half()
-    qd = qkv16.double().requires_grad_(True)
+    qd = qkv_eff.requires_grad_(True)
     q, k, v = (t.view(B, N, 16, 48) for t in qd.split(768, dim=-1))
     mixed, outs, lses = O.dilated_attention_core(q, k, v, segs, ratios, return_branches=True)
     yref = torch.nn.functional.layer_norm(mixed, (768,), ln_w.double(), ln_b.double(), 1e-5)
@@ -500,6 +513,7 @@ def test_dilated_attention_padded_segment_tail(ops, N):
     assert rel(y.view(B, N, 768), yref.detach()) < 4e-3
     got = dqkv.view(B, N, 2304).double().cpu()
     assert torch.isfinite(got).all()
+    got[..., :768] *= QK          # the q columns are the gradient w.r.t. q' = QK q
     for name, sl in (("dq", slice(0, 768)), ("dk", slice(768, 1536)), ("dv", slice(1536, 2304))):
         r = rel(got[..., sl], qd.grad[..., sl])
         assert r < 2e-2, (name, r)
