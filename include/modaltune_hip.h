@@ -290,6 +290,14 @@ int mt_axpy_dev(const float* a, const float* b, const float* alpha, float* y, lo
  * the host raises when it next looks (the reference would index out of bounds, SE:116-120,237). */
 int mt_coords_to_grid(const float* coords, int L, float tile, int ngrids, int* prow, int* pcol, int* err,
                       mt_stream_t stream);
+/* TITAN feature gridding (titan_adapter.py:295-327, preprocess_features): dst(idx[m], :) (+)= src(src_idx[m], :) for fp32
+ * rows of D (index_add of the patch features into their grid cells; idx computed by the host: floor((coords - min) /
+ * patch_size); src_idx NULL = identity).  The caller launches one pass per occurrence rank of a cell, so the cells of a
+ * pass are distinct and the sums come out in patch order (bitwise reproducible, as index_add_ on the CPU).
+ * mt_row_absmax_f32: out[m] = max_d |x(m, d)| (the background mask is "any feature of the cell != 0", TA:326). */
+int mt_scatter_rows_f32(const float* src, const int* src_idx, const int* idx, float* dst, int M, int D, int accumulate,
+                        mt_stream_t stream);
+int mt_row_absmax_f32(const float* x, float* out, int M, int D, mt_stream_t stream);
 
 #ifdef __cplusplus
 }

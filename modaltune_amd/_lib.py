@@ -87,6 +87,8 @@ SIGNATURES = {
     "mt_absmax_scale": [P, L, F, P, P],
     "mt_axpy_dev": [P, P, P, P, L, P],
     "mt_coords_to_grid": [P, I, F, I, P, P, P, P],
+    "mt_scatter_rows_f32": [P, P, P, P, I, I, I, P],
+    "mt_row_absmax_f32": [P, P, I, I, P],
 }
 _RESTYPE = {"mt_status_string": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long}
 

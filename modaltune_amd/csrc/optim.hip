@@ -147,6 +147,31 @@ __global__ void coords_to_grid_kernel(const float* __restrict__ coords, int L, f
   if (bad && err) atomicOr(err, 1);
 }
 
+// dst(idx[m], :) (+)= src(m, :): rows scattered by index (TITAN feature gridding: index_add of the patch features into
+// their grid cells, titan_adapter.py:318-320); atomics because several patches may fall into one cell
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ src_idx, const int* __restrict__ idx,
+                                    float* __restrict__ dst, int M, int D, int accumulate) {
+  const long n = (long)M * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / D), d = (int)(i - (long)m * D);
+    const float v = src[(long)(src_idx ? src_idx[m] : m) * D + d];
+    float* p = dst + (long)idx[m] * D + d;
+    if (accumulate) atomicAdd(p, v);
+    else *p = v;
+  }
+}
+
+// out[m] = max_d |x(m, d)|: one wave per row
+__global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+    float v = 0.f;
+    for (int d = lane; d < D; d += 64) v = fmaxf(v, fabsf(x[m * D + d]));
+    v = wave_max(v);
+    if (lane == 0) out[m] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int mt_l2norm_rows(const float* x, float* y, int R, int O, mt_stream_t stream) {
@@ -216,6 +241,23 @@ extern "C" int mt_coords_to_grid(const float* coords, int L, float tile, int ngr
   if (!coords || !prow || !pcol || L < 1 || !(tile > 0.f) || ngrids < 1) return MT_ERR_BAD_ARG;
   hipLaunchKernelGGL(coords_to_grid_kernel, dim3((L + 255) / 256), dim3(256), 0, (hipStream_t)stream, coords, L, tile, ngrids, prow,
                      pcol, err);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_scatter_rows_f32(const float* src, const int* src_idx, const int* idx, float* dst, int M, int D, int accumulate,
+                                   mt_stream_t stream) {
+  if (!src || !idx || !dst || M < 1 || D < 1) return MT_ERR_BAD_ARG;
+  const long n = (long)M * D;
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, src_idx, idx, dst, M, D, accumulate);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_row_absmax_f32(const float* x, float* out, int M, int D, mt_stream_t stream) {
+  if (!x || !out || M < 1 || D < 1) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(row_absmax_kernel, dim3((M + 3) / 4 > 4096 ? 4096 : (M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, out, M, D);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -346,10 +346,7 @@ class Engine:
         self._ctx["patch_map"] = patch_map
 
         # ---- patch embedding + positional table + cls (LVA:232-242); shared by the B passes
-        if not staged:
-            self.stage_inputs(x, coords, ws)
-        ops.gemm_nt(ws["x16"], self._frozen16["patch"].w, ws["x0"], L, D, cfg.in_chans, epilogue=ops.EPI_POSEMB,
-                    bias=t["patch_embed.proj.bias"], pos_table=self.pos_table, pos_row=ws["prow"], pos_col=ws["pcol"])
+        self._embed_patches(x, coords, ws, staged, L)
 
         # ---- token side: gene encoder (shared) + task token per pass (LVA:257-266)
         gene = self._gene_encoder(genes)                                   # Var [1, G64, D]
@@ -376,7 +373,7 @@ class Engine:
             hin = ws[f"hin{la}"]
             # cls row of every pass: cls_token (+ pos_embed[0] = 0) for block 0, else carried from the previous block
             if i == 0:
-                ops.copy_rows(t["cls_token"].view(1, D), hin, B, D, smap=rowmap(1, 0, 0), dmap=rowmap(1, N, 0))
+                ops.copy_rows(self._cls_source().view(1, D), hin, B, D, smap=rowmap(1, 0, 0), dmap=rowmap(1, N, 0))
             else:
                 ops.copy_rows(ws[f"hout{i - 1}"], hin, B, D, smap=rowmap(1, N, 0), dmap=rowmap(1, N, 0))
             self._injector(i, c, pe, src, src_map, hin, first=(i == 0))
@@ -399,6 +396,34 @@ class Engine:
         self.last_call = (tape, logits)
         self.tape = self._main_tape
         return logits.data
+
+    # -- overridable pieces of the image side (modaltune_amd/titan.py plugs an external backbone in here)
+    def _embed_patches(self, x, coords, ws, staged: bool, L: int):
+        cfg, t = self.cfg, self.store.tensors
+        if not staged:
+            self.stage_inputs(x, coords, ws)
+        ops.gemm_nt(ws["x16"], self._frozen16["patch"].w, ws["x0"], L, cfg.embed_dim, cfg.in_chans, epilogue=ops.EPI_POSEMB,
+                    bias=t["patch_embed.proj.bias"], pos_table=self.pos_table, pos_row=ws["prow"], pos_col=ws["pcol"])
+
+    def _cls_source(self) -> torch.Tensor:
+        return self.store.tensors["cls_token"]      # (+ pos_embed[0] = zeros)
+
+    def _image_token(self, hout: torch.Tensor) -> Var:
+        """The image-side feature of the fusion head: the cls row of every pass (LVA:309-312).  Records the closure that
+        starts the patch-side backward (zeroes dh, scatters the cls gradient)."""
+        ctx, tape, D = self._ctx, self.tape, self.cfg.embed_dim
+        B, N, ws = ctx["B"], ctx["N"], ctx["ws"]
+        cls = Var(tape.new(B, D))
+        ops.copy_rows(hout, cls.data, B, D, smap=rowmap(1, N, 0))
+
+        def bwd():
+            dh = ws["dh"]
+            dh.zero_()                       # start of the patch-side backward: only the cls rows carry gradient
+            ctx["dh16_valid"] = False
+            if cls.grad is not None:
+                ops.copy_rows(cls.grad, dh, B, D, dmap=rowmap(1, N, 0))
+        tape.record(bwd)
+        return cls
 
     def stage_inputs(self, x: torch.Tensor, coords, ws: Optional[Dict[str, torch.Tensor]] = None, B: Optional[int] = None):
         """Input boundary: grid indices from coords (slide_encoder.py:198-211) and the fp16 copy of the patch embeddings,
@@ -760,8 +785,7 @@ class Engine:
         nt, ncl = int(cfg.is_multi), int(cfg.clinical)
         off = ncl + nt                              # token order: [clinical], [task], genes (LVA:572-580)
         G64 = T - off
-        cls = Var(tape.new(B, D))
-        ops.copy_rows(hout, cls.data, B, D, smap=rowmap(1, N, 0))
+        cls = self._image_token(hout)
         gene = Var(tape.new(B, D))
         # mean over the gene tokens: gene[b, d] = sum_t (1/G64) c[b, off + t, d]
         ops.sgemm(self._mean_w, (0, 1), c.data[:, off:], (1, D), gene.data, (D, 1), 1, D, G64, batch=B, b_bs=T * D, c_bs=D)
@@ -774,11 +798,6 @@ class Engine:
             ops.copy_rows(c.data, clin.data, B, D, smap=rowmap(1, T, 0))
 
         def bwd_gather():
-            dh = ws["dh"]
-            dh.zero_()                       # start of the patch-side backward: only the cls rows carry gradient
-            ctx["dh16_valid"] = False
-            if cls.grad is not None:
-                ops.copy_rows(cls.grad, dh, B, D, dmap=rowmap(1, N, 0))
             cg = c.g()
             if gene.grad is not None:   # dc[b, off + t, :] += dgene[b, :] / G64
                 ops.sgemm(self._mean_w, (1, 0), gene.grad, (1, 0), cg[:, off:], (D, 1), G64, D, 1, accumulate=True, batch=B,

@@ -283,6 +283,15 @@ def axpy_dev(a, b, alpha_dev, y, n=None):
     check(_lib.load().mt_axpy_dev(_p(a), _p(b), _p(alpha_dev), _p(y), n if n is not None else b.numel(), _s()), "axpy_dev")
 
 
+def scatter_rows(src, idx, dst, M, D, accumulate=True, src_idx=None):
+    """dst[idx[m], :] (+)= src[src_idx[m], :] (include/modaltune_hip.h: mt_scatter_rows_f32)."""
+    check(_lib.load().mt_scatter_rows_f32(_p(src), _p(src_idx), _p(idx), _p(dst), M, D, int(accumulate), _s()), "scatter_rows")
+
+
+def row_absmax(x, out, M, D):
+    check(_lib.load().mt_row_absmax_f32(_p(x), _p(out), M, D, _s()), "row_absmax")
+
+
 def coords_to_grid(coords, L, tile, ngrids, prow, pcol, err=None):
     check(_lib.load().mt_coords_to_grid(_p(coords), L, float(tile), ngrids, _p(prow), _p(pcol), _p(err), _s()), "coords_to_grid")
 

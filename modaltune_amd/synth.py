@@ -183,6 +183,23 @@ def synth_inputs(L: int, group_sizes: Sequence[int], seed: int = 0, grid: int = 
     return {"x": x, "coords": coords, "genes": genes, "text": text, "clinical": clinical}
 
 
+def synth_inputs_titan(L: int, group_sizes: Sequence[int], seed: int = 0, grid: int = 24, feat_dim: int = 768,
+                        patch_size_lv0: int = 1024, text_dim: int = 512) -> Dict[str, np.ndarray]:
+    """One synthetic slide for the TITAN configuration (titan_adapter.py:329-353): tile embeddings [1, L, 768], integer
+    level-0 pixel coordinates [1, L, 2] of L patches on a `grid` x `grid` lattice of 1024-px cells (a few patches share a
+    cell: the gridding sums them), offset so that the minimum is not 0."""
+    r = _rng(seed, f"titan_inputs/{L}")
+    x = r.standard_normal((1, L, feat_dim)).astype(np.float32)
+    cells = r.choice(grid * grid, size=L - L // 16, replace=False)
+    cells = np.concatenate([cells, r.choice(cells, size=L // 16)])           # duplicates
+    rows, cols = cells // grid, cells % grid
+    coords = (np.stack([rows, cols], 1) * patch_size_lv0 + r.integers(0, patch_size_lv0, size=(L, 2)) + 3 * patch_size_lv0 + 17).astype(np.int64)[None]
+    genes = [r.standard_normal((1, int(n))).astype(np.float32) for n in group_sizes]
+    text = r.standard_normal((4, text_dim)).astype(np.float32)
+    clinical = r.standard_normal((1, 5)).astype(np.float32)
+    return {"x": x, "coords": coords, "genes": genes, "text": text, "clinical": clinical}
+
+
 def projector_state(seed: int = 0, in_dim: int = 512, out_dim: int = 256) -> Dict[str, np.ndarray]:
     """Frozen random text projector (train_modaltune.py:44-59): Conv1x1 -> LayerNorm([C,1,1]) -> ReLU -> Conv1x1."""
     spec = [("conv1.0.weight", (out_dim, in_dim, 1, 1), "w"), ("conv1.0.bias", (out_dim,), "b"),

@@ -273,6 +273,68 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token
     return _linear(out.squeeze(1), sd, "final_project")
 
 
+# ------------------------------------------------------------------------------------------------
+# TITAN configuration (models/aggregators/titan_adapter.py:249-438; adapter_modules.py:526-558).  The slide encoder itself
+# is not in the reference tree (parity unpinned): `vit` is any object with the surface the reference uses.
+# ------------------------------------------------------------------------------------------------
+def titan_gridding(features, coords, patch_size_lv0):
+    """preprocess_features (TA:295-327): features [L, C], integer coords [L, 2] -> (grid [1, C, H, W], coords grid
+    [1, 2, H, W], bg mask [1, H, W])."""
+    features, coords = features.reshape(-1, features.shape[-1]), coords.reshape(-1, 2)
+    g = torch.div(coords - coords.min(dim=0).values, patch_size_lv0, rounding_mode="floor")
+    g = g - g.min(dim=0).values
+    H, W = (int(v) + 1 for v in g.max(dim=0).values)
+    idx = g[:, 0] * W + g[:, 1]
+    fg = torch.zeros(H * W, features.shape[-1], dtype=features.dtype).index_add_(0, idx, features)
+    cg = torch.zeros(H * W, 2, dtype=torch.int64).index_add_(0, idx, coords.to(torch.int64))
+    return (fg.view(H, W, -1).permute(2, 0, 1).unsqueeze(0), cg.view(H, W, 2).permute(2, 0, 1).unsqueeze(0),
+            (fg != 0).any(dim=1).view(1, H, W))
+
+
+def titan_model_forward(sd, cfg, vit, x, coords, genes, task_token, patch_size_lv0=1024, clinical=None):
+    """TITANGeneAdapter.forward (TA:329-438) / the clinical variant: x [1, L, C], coords [1, L, 2] -> [1, output_dim]."""
+    heads = cfg.num_heads
+    fg, cg, bgm = titan_gridding(x, coords, patch_size_lv0)
+    B, nc, w, h = fg.shape
+    t = fg.flatten(2, 3).transpose(1, 2)                                                  # TA:253-293, B == 1
+    bias = vit.get_alibi(w, h, bgm).to(t.dtype)
+    t = vit.norm_pre(vit._pos_embed(vit.patch_embed(t), cg, w, h))
+    mask = torch.cat((torch.ones((1, 1), dtype=torch.bool), bgm.view(1, -1)), dim=1)
+    t = t[mask].unsqueeze(0)
+    c = gene_encoder(genes, sd, depth=cfg.gene.depth)
+    if cfg.is_multi:
+        tk = _ln(_linear(task_token.unsqueeze(0), sd, "task_weight.0"), sd, "task_weight.1")
+        c = torch.cat((tk.unsqueeze(0), c), dim=1)
+    ncl = int(getattr(cfg, "clinical", False))
+    if ncl:
+        ce = _linear(F.relu(_linear(clinical, sd, "clinical_mlp.0")), sd, "clinical_mlp.2")
+        c = torch.cat((_ln(ce, sd, "clinical_mlp.3").unsqueeze(0), c), dim=1)
+    pe = sd["gene_pe"]
+    cls, xx = t[:, :1], t[:, 1:]
+    for i, (a, b) in enumerate(cfg.interaction_indexes):                                  # TA:376-391, AM:526-558
+        if i > 0 and cfg.use_prompt_sa:
+            c = prompt_self_attention(c, pe, sd, f"prompt_selfattention.{i}", heads)
+        xx = injector(xx, c, pe, sd, f"interactions.{i}.injector", heads)
+        hcat = torch.cat((cls, xx), dim=1)
+        for l in range(a, b + 1):
+            hcat = vit.blocks.modules_list[l](hcat, bias, mask)
+        cls, xx = hcat[:, :1], hcat[:, 1:]
+        c = extractor(c, xx, pe, sd, f"interactions.{i}.extractor", heads)
+        if i == len(cfg.interaction_indexes) - 1 and cfg.use_extra_extractor:
+            for j in range(2):
+                c = extractor(c, xx, pe, sd, f"interactions.{i}.extra_extractors.{j}", heads)
+    img, _ = vit.forward_attn_pool(vit.norm(torch.cat((cls, xx), dim=1)), bg_mask=mask)   # TA:399-402
+    img = img.unsqueeze(0)
+    nt = int(cfg.is_multi)
+    clin_out, task_out = c[:, :ncl], c[:, ncl:ncl + nt]
+    gene_out = c[:, ncl + nt:].mean(dim=1, keepdim=True)
+    if cfg.token_agg == "sum":
+        out = img + gene_out + (task_out if nt else 0) + (clin_out if ncl else 0)
+    else:
+        out = torch.cat([img] + ([task_out] if nt else []) + [gene_out] + ([clin_out] if ncl else []), dim=-1)
+    return _linear(_ln(out, sd, "final_norm").squeeze(1), sd, "final_project")
+
+
 def projector_forward(text, psd):
     """Projection_layer (train_modaltune.py:44-59) on [4,512] + row L2 normalisation (TM:211-213)."""
     h = F.linear(text, psd["conv1.0.weight"].flatten(1), psd["conv1.0.bias"])

@@ -288,6 +288,66 @@ def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32
     np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
 
 
+def titan_case(name, L, seed, clinical=False, grid=24):
+    """The reference's TITAN adapter (titan_gene_adapter / titan_gene_clinical_adapter, titan_adapter.py) run end to end on
+    the stand-in backbone of tests/golden/titan_standin.py (the real snapshot is absent: SURVEY §8c): 3 task passes, loss,
+    backward -- fp64.  Pins the adapter-side flow: feature gridding, background masking, interaction blocks, cat head."""
+    import titan_standin
+    from modaltune_amd.titan import titan_model_config
+    cfg_kw = json.load(open("/root/reference/model_configs/modaltune_titan_config.json"))
+    cfg_kw.update(pretrained=False, drop_path_rate=0.0)
+    sizes = synth.toy_group_sizes(6)
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    dt = torch.float64
+    model = Aggregator.create("titan_gene_clinical_adapter" if clinical else "titan_gene_adapter", gene_group_defination=groups,
+                              **cfg_kw, multi_task=3)
+    titan_standin.init_standin(model, seed)
+    cfg = titan_model_config(cfg_kw, 3, clinical, depth=6)
+    adapter_sd = {k: tt(v, torch.float32) for (k, _, _, train), v in
+                  zip(synth.param_specs(cfg, sizes), synth.synth_state_dict(cfg, sizes, seed).values()) if train}
+    res = model.load_state_dict(adapter_sd, strict=False)
+    backbone_keys = set(titan_standin.VisionTransformer().state_dict().keys())
+    assert not res.unexpected_keys and set(res.missing_keys) <= backbone_keys, (res.unexpected_keys[:5], [k for k in res.missing_keys if k not in backbone_keys][:5])
+    assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == sorted(adapter_sd.keys())
+    model = model.to(dt)
+    ref_shims.zero_dropout(model)
+    model.train()
+    inp = synth.synth_inputs_titan(L, sizes, seed, grid=grid)
+    psd = synth.projector_state(seed)
+    proj = TM.Projection_layer(512, 256)
+    proj.load_state_dict({k: tt(v, torch.float32) for k, v in psd.items()}, strict=True)
+    proj = proj.to(dt)
+    for prm in proj.parameters():
+        prm.requires_grad = False
+    x, coords = tt(inp["x"], dt), torch.from_numpy(inp["coords"])
+    genes = {i: tt(g, dt) for i, g in enumerate(inp["genes"])}
+    text = proj(tt(inp["text"], dt)); text = text / text.norm(dim=-1, keepdim=True)
+    kw = dict(clinical=tt(inp["clinical"], dt)) if clinical else {}
+    torch.set_default_dtype(dt)      # (preprocess_features builds its grid with torch.zeros(...): default dtype)
+    fg, cg, bgm = model.preprocess_features(x, coords, 1024)
+    logits = torch.cat([model(x=x, coords=coords, genes=genes, task_token=torch.eye(3, dtype=dt)[t], **kw) for t in (0, 1, 2)], dim=0)
+    logit = logits / logits.norm(dim=-1, keepdim=True)
+    loss = torch.nn.KLDivLoss(reduction="sum")(torch.nn.functional.log_softmax(logit, dim=1),
+                                              torch.nn.functional.softmax(text[[0, 1, 3], :], dim=1)) * 10
+    loss.backward()
+    torch.set_default_dtype(torch.float32)
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            names.append(k); norms.append(float(p.grad.double().norm()))
+    out = {"L": L, "seed": seed, "grid": grid, "sizes": np.array(sizes), "clinical": int(clinical),
+           "grid_hw": np.array(fg.shape[-2:]), "n_foreground": int(bgm.sum()), "bg_mask": bgm.numpy(),
+           "grid_feature_sum": fg.sum(dim=1).numpy().astype(np.float32), "coords_grid": cg.numpy(),
+           "f64_logits": logits.detach().numpy(), "f64_loss": loss.detach().numpy(), "f64_grad_names": np.array(names),
+           "f64_grad_norms": np.array(norms)}
+    params = dict(model.named_parameters())
+    for k in GRAD_KEYS_FULL:
+        if k in params:
+            out["f64_grad/" + k] = params[k].grad.numpy().copy()
+    print(name, "loss", float(loss), "grid", tuple(fg.shape[-2:]), "foreground", int(bgm.sum()), flush=True)
+    np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["adapter", "layer", "gene", "m37", "m1500", "m512", "clin"]
@@ -295,6 +355,9 @@ if __name__ == "__main__":
         model_case("L37_d3_clin", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=14, clinical=True)
         model_case("L37_d3_clin_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=15, clinical=True, token_agg="cat")
         model_case("L37_d3_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=16, token_agg="cat")
+    if "titan" in which:   # TITAN configuration (BASELINE config 4 family) on the stand-in backbone
+        titan_case("titan_L300", 300, seed=21)
+        titan_case("titan_L170_clin", 170, seed=22, clinical=True, grid=16)
     if "pan" in which:    # pan-cancer trainer shape: one-hot width 4, task ids 0..2 (train_modaltune_pancancer.py:50-134,537-542)
         model_case("L37_d3_pan", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=17, multi_task=4)
         model_case("L129_d3_pan", 129, 3, [[0, 0], [1, 1], [2, 2]], seed=18, multi_task=4, dtypes=(torch.float64,))

@@ -87,16 +87,12 @@ def install():
     pkg.__path__ = []
     vt = types.ModuleType(snap + ".vision_transformer")
 
-    class VisionTransformer(torch.nn.Module):
-        pass
-
-    vt.VisionTransformer = VisionTransformer
+    # (our own stand-in with the surface titan_adapter.py uses -- tests/golden/titan_standin.py -- so that the
+    # reference's TITAN adapter code can be run end to end; the real snapshot is not in the reference tree)
+    import titan_standin
+    vt.VisionTransformer = titan_standin.VisionTransformer
     ct = types.ModuleType(snap + ".configuration_titan")
-
-    class TitanConfig:
-        pass
-
-    ct.TitanConfig = TitanConfig
+    ct.TitanConfig = titan_standin.TitanConfig
     pkg.vision_transformer = vt
     pkg.configuration_titan = ct
     sys.modules.update({snap: pkg, snap + ".vision_transformer": vt, snap + ".configuration_titan": ct})

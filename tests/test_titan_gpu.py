@@ -1,0 +1,110 @@
+"""TITAN configuration on the GPU (BASELINE config 4 family): the HIP adapter path of modaltune_amd.titan with
+the stand-in backbone plugged in, against fixtures produced by the REFERENCE's titan_adapter.py on the same stand-in
+(tests/golden/make_golden.py `titan`).  Backbone parity itself is unpinned (the TITAN snapshot is not in the reference tree)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from modaltune_amd import synth  # noqa: E402
+from test_titan_cpu import TITAN_JSON, _case  # noqa: E402
+
+import titan_standin  # noqa: E402
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def _model(golden_dir, name):
+    from modaltune_amd.aggregators import Aggregator
+    import modaltune_amd.titan  # noqa: F401
+    from oracle import modaltune_oracle as O
+    g, cfg, sizes, inp, seed, clinical = _case(golden_dir, name)
+    vit = titan_standin.VisionTransformer()
+    titan_standin.init_standin(vit, seed)
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("titan_gene_clinical_adapter" if clinical else "titan_gene_adapter", gene_group_defination=groups,
+                              **TITAN_JSON, multi_task=3, backbone=vit)
+    sd = synth.synth_state_dict(model.cfg, sizes, seed)
+    state = {k: torch.from_numpy(v) for k, v in sd.items() if k in dict(model._params)}
+    state.update(vit.state_dict())
+    model.load_state_dict(state, strict=True)
+    assert set(model.state_dict().keys()) == set(state.keys())
+    return g, model, sizes, inp, seed, clinical, O
+
+
+@pytest.mark.parametrize("name", ["titan_L300", "titan_L170_clin"])
+def test_titan_adapter_train_step_matches_reference_golden(golden_dir, name):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    g, model, sizes, inp, seed, clinical, O = _model(golden_dir, name)
+    x = torch.from_numpy(inp["x"]).cuda()
+    coords = torch.from_numpy(inp["coords"]).cuda()
+    genes = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    kw = dict(clinical=torch.from_numpy(inp["clinical"]).cuda()) if clinical else {}
+    model.train()
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    assert len(trainable) == len(g["f64_grad_names"])
+    logits = torch.cat([model(x=x, coords=coords, genes=genes, task_token=torch.eye(3)[t].cuda(), **kw) for t in (0, 1, 2)], dim=0)
+    assert _rel(logits.detach().cpu().numpy(), g["f64_logits"]) < 1e-3
+    psd = {k: torch.from_numpy(v).cuda() for k, v in synth.projector_state(seed).items()}
+    loss = O.distill_loss(logits, O.projector_forward(torch.from_numpy(inp["text"]).cuda(), psd))
+    assert abs(float(loss.detach()) - float(g["f64_loss"])) < 1e-3 * float(g["f64_loss"])
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [str(n) for n in g["f64_grad_names"]]
+    params = dict(model.named_parameters())
+    ours = np.array([float(params[n].grad.double().norm()) for n in names])
+    ref = g["f64_grad_norms"]
+    bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > 2e-2 * r + 1e-6 * ref.max()]
+    assert not bad, bad[:10]
+    for k in g.files:
+        if k.startswith("f64_grad/"):
+            ours_k = params[k[len("f64_grad/"):]].grad.double().cpu().numpy()
+            err = np.linalg.norm(ours_k - g[k]) / (np.linalg.norm(g[k]) + 1e-300)
+            assert err < 4e-2, (k, err)
+
+
+def test_titan_gridding_and_ragged_bags(golden_dir):
+    """preprocess_features on the device vs the reference's grid; bags of different sizes through one model (config 4:
+    "mixed bag lengths"): each forward equals a fresh model's."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.titan import preprocess_features
+    g, model, sizes, inp, seed, clinical, O = _model(golden_dir, "titan_L300")
+    fg, cg, bgm = preprocess_features(torch.from_numpy(inp["x"]).cuda(), inp["coords"], 1024)
+    assert tuple(fg.shape[-2:]) == tuple(g["grid_hw"])
+    assert np.array_equal(bgm.cpu().numpy(), g["bg_mask"]) and np.array_equal(cg.cpu().numpy(), g["coords_grid"])
+    assert np.allclose(fg.sum(dim=1).cpu().numpy(), g["grid_feature_sum"], rtol=1e-5, atol=1e-5)
+    fg2, _, _ = preprocess_features(torch.from_numpy(inp["x"]).cuda(), inp["coords"], 1024)
+    assert torch.equal(fg, fg2)                      # cells shared by several patches: summed in patch order, every time
+    model.eval()
+    outs = {}
+    with torch.no_grad():
+        for rep in range(2):
+            for L in (300, 90, 520, 33):
+                inp_l = synth.synth_inputs_titan(L, sizes, seed + L, grid=24)
+                o = model(x=torch.from_numpy(inp_l["x"]).cuda(), coords=torch.from_numpy(inp_l["coords"]).cuda(),
+                          genes={i: torch.from_numpy(a).cuda() for i, a in enumerate(inp_l["genes"])}, task_token=torch.eye(3)[1].cuda())
+                assert torch.isfinite(o).all()
+                if L in outs:
+                    assert torch.equal(o, outs[L])          # same slide later, other lengths in between: same result
+                outs[L] = o.clone()
+
+
+def test_titan_without_backbone_fails_loudly():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    import modaltune_amd.titan  # noqa: F401
+    sizes = synth.toy_group_sizes()
+    model = Aggregator.create("titan_gene_adapter", gene_group_defination={i: ["g"] * n for i, n in enumerate(sizes)}, **TITAN_JSON, multi_task=3)
+    inp = synth.synth_inputs_titan(40, sizes, 1)
+    with pytest.raises(RuntimeError, match="TITAN slide encoder"):
+        model(x=torch.from_numpy(inp["x"]).cuda(), coords=torch.from_numpy(inp["coords"]).cuda(),
+              genes=[torch.from_numpy(a).cuda() for a in inp["genes"]], task_token=torch.eye(3)[0].cuda())
