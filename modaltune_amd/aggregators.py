@@ -36,6 +36,8 @@ class Aggregator(nn.Module):
 
     @classmethod
     def create(cls, subclass_name: str, **params):
+        if subclass_name not in cls.subclasses and subclass_name.startswith("titan"):
+            from . import titan  # noqa: F401  (registers titan_gene_adapter / titan_gene_clinical_adapter)
         if subclass_name not in cls.subclasses:
             raise ValueError("Unknown subclass name {}".format(subclass_name))
         return cls.subclasses[subclass_name](**params)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# One round's profile set on the GPU box (everything lands under gpurun_out/prof_$1/):
+#   bench line + per-kernel times, rocprofv3 kernel-trace stats of the same command, ragged / eager bench lines,
+#   SQ counters of the attention kernels, HBM counters of the attention backward kernels.
+tag=${1:-r02}
+out=gpurun_out/prof_$tag; mkdir -p $out
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+python bench.py --kernel-times > $out/bench.json 2> $out/kernel_times.txt
+python bench.py --no-cpu-baseline --ragged > $out/bench_ragged.json 2>/dev/null
+python bench.py --no-cpu-baseline --eager > $out/bench_eager.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline > $out/stats.log 2>&1
+bash tools/pmc.sh ${tag}_fwd tools/fwd_microbench.py
+bash tools/pmc.sh ${tag}_bwd tools/kv_microbench.py
+bash tools/pmc_hbm.sh ${tag}_bwd tools/kv_microbench.py
+python tools/pmc_summary.py gpurun_out/pmc_${tag}_fwd > $out/pmc_attn_fwd.txt
+python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd > $out/pmc_attn_bwd.txt
+python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd/f > $out/pmc_hbm_f.txt; python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd/w > $out/pmc_hbm_w.txt
+find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+echo profile set done
