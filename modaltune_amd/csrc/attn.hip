@@ -17,15 +17,15 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// forward.  K and V tiles are double-buffered in LDS, one barrier per tile; the global loads of tile t+1 are issued
-// at the top of tile t and first touched at its end.  (A variant software-pipelined across tiles inside each wave --
-// S^T of tile t+1 in flight during the softmax of tile t -- measured 5 % slower: it needs 185 VGPRs = 2 waves/SIMD
-// against 142 = 3 waves/SIMD here, and these kernels are latency-bound, not pipe-bound.)
+// forward.  K and V tiles live in two LDS-DMA images each (attn_common.h: img_off), one barrier per tile: the DMA of tile
+// t + 1 is issued at the top of tile t and awaited at its end.  No staging registers, stores or per-tile address
+// arithmetic; the only tile variant is the last one of a sequence whose length is not a multiple of 64.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __restrict__ qkv, Plan p, h16* __restrict__ o_br,
                                                                float* __restrict__ lse_br) {
-  __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];
-  __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * VSTR];
+  __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // K0 | K1 | V0 | V1
+  h16* const Ks = smem;
+  h16* const Vs = smem + 2 * IMG_HALVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
   const WorkItem w = decode(p, blockIdx.x);
@@ -37,12 +37,12 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
   if (w.qt * 128 >= nv) return;
 
-  // ones columns (d = 48 and 52) so that O^T row 48 (both lane halves) accumulates sum(P); written once
-  if (tid < 128) {
-    const int buf = tid >> 6, row = tid & 63;
-    h16x8 one = {(h16)1.f, 0, 0, 0, (h16)1.f, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    *reinterpret_cast<h16x8*>(&Vs[buf][row * VSTR + 48]) = one;
-    *reinterpret_cast<h16x8*>(&Vs[buf][row * VSTR + 56]) = zero;
+  // constant chunks of the V images: logical chunk 6 = ones at d = 48 and 52 (O^T row 48 of both lane halves accumulates
+  // sum(P)), chunk 7 = zeros; written once (the DMA never touches them)
+  {
+    const int buf = tid >> 7, row = (tid >> 1) & 63, which = 6 + (tid & 1);
+    const h16x8 one = {(h16)1.f, 0, 0, 0, (h16)1.f, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<h16x8*>(&Vs[buf * IMG_HALVES + img_off(row, which)]) = which == 6 ? one : zero;
   }
 
   // Q^T fragments (B operand): lane = query, element j of k-step ks = Q[q][16 ks + 8 hh + j]
@@ -56,66 +56,36 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   for (int ks = 0; ks < 3; ++ks)
     qf[ks] = sel8(qvalid, ldg8(hm_ptr(qkv, M, w.h, qrow) + ks * 16 + hh * 8));
 
-  const StageRow st(tid);      // conflict-free staging stores (attn_common.h)
   const int ntile = (sq.n + 63) / 64;
   const int nproc = (nv + 63) >> 6;      // tiles holding at least one real key
-  // tiles [0, nfull) hold only real rows: loaded with a uniform base + constant 32-bit lane offset, no clamp, no select
-  const int nfull = nv >> 6;
-  const __amdgpu_buffer_rsrc_t krs = make_rsrc(hm_ptr(qkv, M, H + w.h, sq.row(0)));
-  const __amdgpu_buffer_rsrc_t vrs = make_rsrc(hm_ptr(qkv, M, 2 * H + w.h, sq.row(0)));
-  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part * 8) * 2u;
-  const uint32_t c1 = (uint32_t)(st.row1 * sq.dr * HD + st.part * 8) * 2u;
-  h16x8 rk0, rk1, rv0, rv1;
-  bool kok0 = false, kok1 = false, vok0 = false, vok1 = false;
-  // ragged tiles: unconditional loads of clamped rows; padded rows are zeroed by a select when the tile goes to LDS
-  auto gload_k = [&](int t, auto full_tag) {
-    const int kb = t * 64;
-    if (decltype(full_tag)::value) {
-      const uint32_t adv = (uint32_t)(kb * sq.dr * HD) * 2u;
-      rk0 = buf_ldg8(krs, c0, adv); rk1 = buf_ldg8(krs, c1, adv);
-    } else {
-      const int i0 = kb + st.row0, i1 = kb + st.row1;
-      rk0 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i0)) + st.part * 8);
-      rk1 = ldg8(hm_ptr(qkv, M, H + w.h, sq.row_clamped(i1)) + st.part * 8);
-      kok0 = sq.valid(i0); kok1 = sq.valid(i1);
-    }
+  const int row_bytes = sq.dr * HD * 2;                             // distance of two sparse entries in memory
+  const long valid_bytes = (long)(nv - 1) * row_bytes + HD * 2;     // entries [0, nv) are real rows
+  const long tile_bytes = 64L * row_bytes;
+  const h16* const kseq = hm_ptr(qkv, M, H + w.h, sq.row(0));
+  const h16* const vseq = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
+  const DmaLane dl(tid, row_bytes);
+  auto dma = [&](int t) {
+    dma_tile(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), dl);
+    dma_tile(Vs + (t & 1) * IMG_HALVES, tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl);
   };
-  auto gload_v = [&](int t, auto full_tag) {
-    const int kb = t * 64;
-    if (decltype(full_tag)::value) {
-      const uint32_t adv = (uint32_t)(kb * sq.dr * HD) * 2u;
-      rv0 = buf_ldg8(vrs, c0, adv); rv1 = buf_ldg8(vrs, c1, adv);
-    } else {
-      const int i0 = kb + st.row0, i1 = kb + st.row1;
-      rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i0)) + st.part * 8);
-      rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, sq.row_clamped(i1)) + st.part * 8);
-      vok0 = sq.valid(i0); vok1 = sq.valid(i1);
-    }
-  };
-  auto lstore_k = [&](int buf, auto full_tag) {
-    h16x8 a = rk0, b = rk1;
-    if (!decltype(full_tag)::value) { a = sel8(kok0, a); b = sel8(kok1, b); }
-    if (st.act) {
-      *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part * 8]) = a;
-      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part * 8]) = b;
-    }
-  };
-  auto lstore_v = [&](int buf, auto full_tag) {
-    h16x8 a = rv0, b = rv1;
-    if (!decltype(full_tag)::value) { a = sel8(vok0, a); b = sel8(vok1, b); }
-    if (st.act) {
-      *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * VSTR + st.part * 8]) = a;
-      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * VSTR + st.part * 8]) = b;
-    }
-  };
+  // per-lane read offsets (halves): K rows sub * 32 + l31 at chunk 2 ks + hh; V transposed reads of rows 4 hh + tq (+ 8),
+  // d blocks 0..31 / 32..63 (the sub / s2 row-block offsets are multiples of 16 rows: they do not change img_f)
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  int krd[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) krd[ks] = img_off(l31, 2 * ks + hh);
+  const int vc = 2 * (grp & 1) + (tp >> 1), vo = 4 * (tp & 1);
+  const int va0 = img_off(4 * hh + tq, vc) + vo, va1 = img_off(4 * hh + tq, vc + 4) + vo;
+  const int vb0 = img_off(4 * hh + tq + 8, vc) + vo, vb1 = img_off(4 * hh + tq + 8, vc + 4) + vo;
+
   // scores of one 64-key tile relative to the reference: s[sub][reg] = c q.k - m2 (key = row, query = lane); `init` is the
   // accumulator the chains start from (splat(-m2): the query is the lane, so one value per lane)
-  auto qk = [&](int buf, f32x16 (&s)[2], const f32x16& init) {
+  auto qk = [&](const h16* Kb, f32x16 (&s)[2], const f32x16& init) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Ks[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + krd[ks]]);
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? init : s[sub], 0, 0, 0);
       }
     }
@@ -126,19 +96,19 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
 
   // prologue: tile 0 -> LDS
-  gload_k(0, std::false_type{}); gload_v(0, std::false_type{});
-  lstore_k(0, std::false_type{}); lstore_v(0, std::false_type{});
+  dma(0);
+  dma_wait_all();
   __syncthreads();
   // Running reference m2 of the scaled logits (log2 units), carried as the accumulator initialiser minit = splat(-m2).  It
-  // starts at the row maximum over tile 0's REAL keys (one extra S product per workgroup; tile 0 is then processed by the
-  // loop like every other tile) and moves up only through the deferred rescale below.
+  // starts at the row maximum over tile 0 (one extra S product per workgroup; tile 0 is then processed by the loop like
+  // every other tile) and moves up only through the deferred rescale below.
   float m2;
   f32x16 minit;
   {
     f32x16 s0[2], zero;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero[i] = 0.f;
-    qk(0, s0, zero);
+    qk(Ks, s0, zero);
     float mx = NEG_BIG;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -147,20 +117,19 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
         const int kidx = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
         mx = fmaxf(mx, kidx < sq.n ? s0[sub][i] : NEG_BIG);
       }
-    m2 = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    m2 = max_halves(mx);
 #pragma unroll
     for (int i = 0; i < 16; ++i) minit[i] = -m2;
   }
 
-  // transposed-read lane roles (T10): 16-lane group grp, lane 4*tq+tp supplies row tq, columns 4*tp..4*tp+3
-  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  // next_tag: tile t + 1 is a full tile (fast loads, no selects)
-  auto tile = [&](int t, auto last_tag, auto tail_tag, auto next_tag) {
-    constexpr bool LAST = decltype(last_tag)::value, TAIL = decltype(tail_tag)::value;
-    const int kb = t * 64, buf = t & 1;
-    if (!LAST) { gload_k(t + 1, next_tag); gload_v(t + 1, next_tag); }
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int kb = t * 64;
+    const h16* Kb = Ks + (t & 1) * IMG_HALVES;
+    const h16* Vb = Vs + (t & 1) * IMG_HALVES;
+    if (t + 1 < nproc) dma(t + 1);
     f32x16 s_cur[2];
-    qk(buf, s_cur, minit);
+    qk(Kb, s_cur, minit);
     // keys >= n are tile padding (excluded, last tile only); zero-padded keys keep logit 0 (DA:98-101)
     float mx = NEG_BIG;
 #pragma unroll
@@ -173,7 +142,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
         }
         mx = fmaxf(mx, s_cur[sub][i]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_halves(mx);
     // Deferred rescale (exact): the reference m2 only moves when some row's maximum grew by more than 2^RESCALE_LOG2 past
     // it; until then P = exp2(c s - m2) <= 2^RESCALE_LOG2, which fp16 P / fp32 O hold without loss.
     if (__any(mx > RESCALE_LOG2)) {
@@ -196,22 +165,19 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
           const f32x2 a = pk_exp2((f32x2){s_cur[sub][8 * s2 + e], s_cur[sub][8 * s2 + e + 1]});
           pf[e] = (h16)a[0]; pf[e + 1] = (h16)a[1];
         }
-        const h16* vrow = &Vs[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
-        const h16x8 v0 = cat8(lds_tr4(vrow), lds_tr4(vrow + 8 * VSTR));
-        const h16x8 v1 = cat8(lds_tr4(vrow + 32), lds_tr4(vrow + 8 * VSTR + 32));
+        const h16* vblk = Vb + (sub * 32 + s2 * 16) * IMG_ROW;
+        const h16x8 v0 = cat8(lds_tr4(vblk + va0), lds_tr4(vblk + vb0));
+        const h16x8 v1 = cat8(lds_tr4(vblk + va1), lds_tr4(vblk + vb1));
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf, o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf, o1, 0, 0, 0);
       }
-    if (!LAST) {
-      lstore_k(buf ^ 1, next_tag); lstore_v(buf ^ 1, next_tag);
-      __syncthreads();
-    }
+    dma_wait_all();            // tile t + 1 has landed (this wave's pieces) ...
+    __syncthreads();           // ... everybody's, and everybody is done reading tile t's images
   };
-  int t = 0;
-  for (; t + 1 < nfull; ++t) tile(t, std::false_type{}, std::false_type{}, std::true_type{});
-  for (; t < nproc - 1; ++t) tile(t, std::false_type{}, std::false_type{}, std::false_type{});
-  if (nproc == ntile && (sq.n & 63)) tile(nproc - 1, std::true_type{}, std::true_type{}, std::false_type{});
-  else tile(nproc - 1, std::true_type{}, std::false_type{}, std::false_type{});
+  const bool tail_last = nproc == ntile && (sq.n & 63);
+  const int nplain = tail_last ? nproc - 1 : nproc;
+  for (int t = 0; t < nplain; ++t) tile(t, std::false_type{});
+  if (tail_last) tile(nproc - 1, std::true_type{});
   const int rest = sq.n - nproc * 64;      // padded keys in the tiles not computed: logit 0, value 0
   if (rest > 0) {
     if (__any(-m2 > RESCALE_LOG2)) {             // logit 0 lies more than the threshold above the reference

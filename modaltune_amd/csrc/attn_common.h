@@ -169,6 +169,14 @@ MT_DEVINL float buf_ldf(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) 
 MT_DEVINL f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 MT_DEVINL f32x2 pk_exp2(f32x2 a) { return (f32x2){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])}; }
 
+// max over the two lane halves (lane l and l ^ 32) without the LDS round trip of ds_bpermute: v_permlane32_swap
+// exchanges the upper half of one register with the lower half of another (guide T12)
+MT_DEVINL float max_halves(float x) {
+  float lo = x, hi = x;      // two registers: the instruction rewrites BOTH operands in place (lo <- {x_lo, x_lo}, hi <- {x_hi, x_hi})
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));      // (2 wait states after a VALU write)
+  return fmaxf(lo, hi);
+}
+
 MT_DEVINL h16x8 sel8(bool ok, h16x8 v) {
   const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
   return ok ? v : z;
@@ -186,6 +194,52 @@ MT_DEVINL Seq make_seq(const Plan& p, const WorkItem& w) {
   q.seg_base = w.j * q.s; q.N = p.N; q.row_base = (long)w.b * p.N;
   return q;
 }
+
+// ---- LDS-DMA tile image (forward kernel; tools/lds_bank_check.py) ---------------------------------------------------
+// [64 rows][128 B]: logical 16-byte chunks 0..5 = the 48 halves of a row, 6..7 = constants (ones / zeros columns read as
+// d = 48..63); chunk c of row r sits at chunk position c ^ img_f(r).  With it BOTH the row reads (ds_read_b128, 16-lane
+// groups of rows at one chunk) and the transposed reads (ds_read_b64_tr_b16, four consecutive rows x 64 B) are
+// bank-conflict free, and -- rows being exactly 8 chunks -- a tile is filled by LDS-DMA (buffer_load_dwordx4 ... lds writes
+// lane j's 16 bytes at base + 16 j): piece p of a tile = rows 8p..8p+7, lane j -> row 8p + j / 8, position j % 8, i.e.
+// logical chunk (j % 8) ^ img_f(row); lanes whose logical chunk is 6 or 7 are switched off.  No staging registers, no
+// ds_write pass, no address arithmetic per tile; rows past the end of the sparse sequence come back as zeros from the
+// buffer descriptor's range check (num_records = the sequence's valid bytes), which is what the reference's zero padding
+// is (DA:98-101), so ragged tiles need neither clamps nor selects.
+constexpr int IMG_ROW = 64;                      // halves per image row
+constexpr int IMG_HALVES = 64 * IMG_ROW;         // 8 KB
+MT_DEVINL int img_f(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+MT_DEVINL int img_off(int row, int chunk) { return row * IMG_ROW + ((chunk ^ img_f(row)) << 3); }      // in halves
+
+struct DmaLane {      // this thread's two pieces of a tile image: p = 2 * wave + i
+  uint32_t voff[2]; bool act[2]; int lds_halves[2];
+  MT_DEVINL DmaLane(int tid, int row_stride_bytes) {
+    const int wave = tid >> 6, j = tid & 63;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = 2 * wave + i, row = 8 * piece + (j >> 3);
+      const int c = (j & 7) ^ img_f(row);
+      act[i] = c < 6;
+      voff[i] = (uint32_t)(row * row_stride_bytes + min(c, 5) * 16);
+      lds_halves[i] = piece * 512;               // 1 KiB per piece
+    }
+  }
+};
+// descriptor of the rows [row_first, ...) of one (slab, head) that tile t may touch: base advanced to the tile's first
+// row, num_records = what is left of the sequence's valid bytes (0 when the tile lies past the end)
+MT_DEVINL __amdgpu_buffer_rsrc_t tile_rsrc(const h16* seq_base, long tile_byte_off, long valid_bytes) {
+  const long left = valid_bytes - tile_byte_off;
+  const int rec = (int)__builtin_amdgcn_readfirstlane((int)(left > 0 ? (left < 0x7fffffffL ? left : 0x7fffffffL) : 0));
+  const char* b = reinterpret_cast<const char*>(seq_base) + tile_byte_off;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0, rec, 0x00020000);
+}
+MT_DEVINL void dma_tile(h16* img, __amdgpu_buffer_rsrc_t rs, const DmaLane& d) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (d.act[i])
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + d.lds_halves[i]), 16, d.voff[i], 0, 0, 0);
+}
+MT_DEVINL void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Per-thread staging slots of a 64-row x 48-col fp16 tile = 384 chunks of 16 B.
 //

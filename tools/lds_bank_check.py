@@ -126,3 +126,24 @@ if __name__ == "__main__":
     def l2s_read(sub, g4):
         return lambda l: (sub * 32 + 8 * g4 + 4 * (l >> 5)) * 4
     report("row constants f32x4 read (dK/dV)", read_b128, [l2s_read(s, g) for s in range(2) for g in range(4)])
+
+    # ---- round 2: the LDS-DMA image.  [64 rows][128 B] (logical chunks 0..5 = the 48 halves of a row, 6..7 constants), the
+    # 16-byte chunk c of row r stored at chunk position c ^ f(r), f(r) = ((r >> 1) & 1) << 2 | ((r >> 2) & 3).  Filled by
+    # buffer_load ... lds (lane j of piece p -> row 8 p + j / 8, physical chunk j % 8): no staging stores at all.
+    def f(r):
+        return (((r >> 1) & 1) << 2) | ((r >> 2) & 3)
+
+    def img(row, chunk, byte=0):
+        return row * 128 + ((chunk ^ f(row)) << 4) + byte
+    report("DMA image: row read ds_read_b128", read_b128,
+           [(lambda l, s=s, k=k: img(s * 32 + (l & 31), 2 * k + (l >> 5))) for s in range(2) for k in range(3)])
+
+    def tr(sub, s2, plus8, hi):
+        def g(l):
+            hh, grp, li = l >> 5, l >> 4, l & 15
+            tq, tp = li >> 2, li & 3
+            row = sub * 32 + s2 * 16 + 4 * hh + tq + (8 if plus8 else 0)
+            return img(row, 2 * (grp & 1) + (tp >> 1) + (4 if hi else 0), 8 * (tp & 1))
+        return g
+    report("DMA image: transposed read ds_read_b64_tr_b16", read_tr,
+           [tr(s, s2, a, b) for s in range(2) for s2 in range(2) for a in (0, 1) for b in (0, 1)])
