@@ -45,8 +45,73 @@ constexpr int erows_for(int bm, int cs, int lds_bytes) {
 // .. + 3), i.e. four consecutive output columns of one row per lane -> one 16-byte LDS write per tile instead of four
 // scalar ones.  The tile is staged through LDS (the operand buffers are free now) so that every global access of the
 // epilogue -- the residual read and the C write -- is a full-width row segment (16 B per lane, BN * 4 B per row).
+// fp16 outputs with a plain epilogue (bias, or bias + head-major q|k|v): the tile is converted in registers and staged as
+// fp16 -- half the LDS bytes of the fp32 staging, so a 256 x 256 tile takes two passes instead of four -- and leaves as
+// 16-byte row segments (half the store instructions of the 8-byte form: the store tail is issue-bound, guide T21).
+// Staging rows of BN + 4 halves: the 8-byte writes of a 16-lane group (16 rows, one column quad) land on 16 distinct
+// bank pairs; read back as two ds_read_b64 per thread (rows are only 8-byte aligned).
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int erows_h16(int bm, int csh, int lds_bytes) {
+  int e = bm;
+  while (e * csh * 2 > lds_bytes) e /= 2;
+  return e;
+}
+template <int BM, int BN, int WM, int WN, int EPI, int LDS_BYTES>
+MT_DEVINL void gemm_epilogue_h16(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], h16* smem, int m0, int n0) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int CSH = BN + 4;
+  constexpr int EROWS = erows_h16(BM, CSH, LDS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  h16* C = reinterpret_cast<h16*>(g.C);
+  f32x4 b4[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * TN + j * 16 + fq * 4;
+    b4[j] = (g.bias && n < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int CPR = BN / 8;                                  // 16-byte chunks per tile row
+  constexpr int RPP = NT / CPR;                                // rows per sweep
+  const int cc = (tid % CPR) * 8, r0 = tid / CPR;
+  const int n = n0 + cc;
+#pragma unroll
+  for (int pass = 0; pass < BM / EROWS; ++pass) {
+    const int rbase = pass * EROWS;
+    if (pass > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * TM + i * 16 + fr - rbase;
+      if (row >= 0 && row < EROWS) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const f32x4 v = acc[i][j] + b4[j];
+          *reinterpret_cast<h16x4*>(&smem[row * CSH + wn * TN + j * 16 + fq * 4]) = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = r0; rr < EROWS; rr += RPP) {
+      const int m = m0 + rbase + rr;
+      if (m >= g.m_end || n >= g.N) continue;
+      const h16x4 lo = *reinterpret_cast<const h16x4*>(&smem[rr * CSH + cc]), hi = *reinterpret_cast<const h16x4*>(&smem[rr * CSH + cc + 4]);
+      h16* dst = EPI == MT_EPI_QKV_HM ? C + ((long)(n / 48) * g.M + m) * 48 + (n % 48)      // 8 | 48: chunks never straddle a head
+                                      : C + g.cmap.map(m) * g.ldc + n;
+      *reinterpret_cast<h16x8*>(dst) = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, typename OutT, int LDS_BYTES>
 MT_DEVINL void gemm_epilogue(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], h16* smem, int m0, int n0) {
+  if constexpr (sizeof(OutT) == 2 && (EPI == MT_EPI_BIAS || EPI == MT_EPI_QKV_HM)) {
+    if ((g.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0) {      // 16-byte row segments need aligned rows
+      gemm_epilogue_h16<BM, BN, WM, WN, EPI, LDS_BYTES>(g, acc, smem, m0, n0);
+      return;
+    }
+  }
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
   constexpr int CS = BN + 4;
