@@ -222,10 +222,21 @@ struct MixGeom {
     for (int b = 0; b < MT_MAX_BRANCHES; ++b) grp[b] = b < p.nbranch ? h / (H / p.ratio[b]) : -1;
   }
 };
-// residue of position pos inside its segment, modulo the dilation (wave-uniform)
+// position -> (segment index, offset inside the segment) without an integer division: q = floor(pos / seg) from the
+// float reciprocal, corrected by one step (exact for pos < 2^23)
+MT_DEVINL void seg_split(const Plan& p, int b, int pos, int& j, int& loc) {
+  const int sg = p.seg[b];
+  if (sg >= p.N) { j = 0; loc = pos; return; }
+  j = (int)((float)pos * p.inv_seg[b]);
+  loc = pos - j * sg;
+  if (loc < 0) { loc += sg; --j; }
+  if (loc >= sg) { loc -= sg; ++j; }
+}
+// residue of position pos inside its segment, modulo the dilation
 MT_DEVINL int residue(const Plan& p, int b, int pos) {
-  const int sg = p.seg[b], dr = p.ratio[b];
-  const int loc = sg >= p.N ? pos : pos % sg;
+  int j, loc;
+  seg_split(p, b, pos, j, loc);
+  const int dr = p.ratio[b];
   return (dr & (dr - 1)) == 0 ? (loc & (dr - 1)) : loc % dr;
 }
 MT_DEVINL int dense_branch(const Plan& p) {      // a branch with ratio 1 covers every (position, head)
@@ -234,35 +245,45 @@ MT_DEVINL int dense_branch(const Plan& p) {      // a branch with ratio 1 covers
   for (int b = 0; b < MT_MAX_BRANCHES; ++b) if (b < p.nbranch && p.ratio[b] == 1) d = b;
   return d;
 }
-struct H12 { h16x4 a, b, c; };
-MT_DEVINL H12 ld12(const h16* p) {
-  return H12{*reinterpret_cast<const h16x4*>(p), *reinterpret_cast<const h16x4*>(p + 4), *reinterpret_cast<const h16x4*>(p + 8)};
+// Two token rows per wave: 32 lanes per row, a lane owns 24 consecutive columns = half of one head (three 16-byte loads
+// per branch; the 12-column / 8-byte form ran at 3.6 TB/s, tools: profiles/r02 roofline table).
+constexpr int MIX_CPL = 24;
+struct H24 { h16x8 a, b, c; };
+MT_DEVINL H24 ld24(const h16* p) {
+  return H24{*reinterpret_cast<const h16x8*>(p), *reinterpret_cast<const h16x8*>(p + 8), *reinterpret_cast<const h16x8*>(p + 16)};
 }
-MT_DEVINL float h12(const H12& v, int e) { return (float)(e < 4 ? v.a[e & 3] : e < 8 ? v.b[e & 3] : v.c[e & 3]); }
+MT_DEVINL float h24(const H24& v, int e) { return (float)(e < 8 ? v.a[e & 7] : e < 16 ? v.b[e & 7] : v.c[e & 7]); }
+MT_DEVINL float half_sum(float v) {       // over the 32 lanes of a row
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
 template <int NB>
 __global__ __launch_bounds__(256) void mix_ln_fwd_kernel(const h16* __restrict__ o_br, const float* __restrict__ lse_br, Plan p,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          h16* __restrict__ y, float* __restrict__ stats, float* __restrict__ lse_tot) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 5, l5 = lane & 31;
   const long M = (long)p.B * p.N;
-  const int h = lane >> 2, c0 = lane * 12;
+  const int h = l5 >> 1, c0 = l5 * MIX_CPL;
   const MixGeom geo(p, h);
   const int db = dense_branch(p);
-  float w[12], bb[12];
+  float w[MIX_CPL], bb[MIX_CPL];
 #pragma unroll
-  for (int e = 0; e < 12; ++e) { w[e] = ln_w[c0 + e]; bb[e] = ln_b[c0 + e]; }
-  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+  for (int e = 0; e < MIX_CPL; ++e) { w[e] = ln_w[c0 + e]; bb[e] = ln_b[c0 + e]; }
+  for (long m2 = ((long)blockIdx.x * 4 + wave) * 2; m2 < M; m2 += (long)gridDim.x * 8) {
+    const bool live = m2 + sub < M;
+    const long m = live ? m2 + sub : M - 1;
     const int pos = (int)(m % p.N);
     bool cov[NB];
     float lse[NB];
-    H12 ob[NB];
+    H24 ob[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       cov[b] = b < p.nbranch && geo.grp[b] == residue(p, b, pos);
       const int sb = cov[b] ? b : db;
       lse[b] = lse_br[((long)sb * M + m) * H + h];
-      ob[b] = ld12(o_br + ((long)sb * M + m) * DM + c0);
+      ob[b] = ld24(o_br + ((long)sb * M + m) * DM + c0);
     }
     float mx = NEG_BIG;
 #pragma unroll
@@ -271,33 +292,35 @@ __global__ __launch_bounds__(256) void mix_ln_fwd_kernel(const h16* __restrict__
 #pragma unroll
     for (int b = 0; b < NB; ++b) den += cov[b] ? __expf(lse[b] - mx) : 0.f;
     const float tot = mx + __logf(den);
-    float v[12];
+    float v[MIX_CPL];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) v[e] = 0.f;
+    for (int e = 0; e < MIX_CPL; ++e) v[e] = 0.f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float wgt = cov[b] ? __expf(lse[b] - tot) : 0.f;
 #pragma unroll
-      for (int e = 0; e < 12; ++e) v[e] = fmaf(wgt, cov[b] ? h12(ob[b], e) : 0.f, v[e]);
+      for (int e = 0; e < MIX_CPL; ++e) v[e] = fmaf(wgt, cov[b] ? h24(ob[b], e) : 0.f, v[e]);
     }
     float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 12; ++e) s += v[e];
-    const float mean = wave_sum(s) * (1.0f / DM);
+    for (int e = 0; e < MIX_CPL; ++e) s += v[e];
+    const float mean = half_sum(s) * (1.0f / DM);
     float q = 0.f;
 #pragma unroll
-    for (int e = 0; e < 12; ++e) { const float d = v[e] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / DM) + 1e-5f);
-    h16* dst = y + m * DM + c0;
+    for (int e = 0; e < MIX_CPL; ++e) { const float d = v[e] - mean; q += d * d; }
+    const float rstd = rsqrtf(half_sum(q) * (1.0f / DM) + 1e-5f);
+    if (live) {
+      h16* dst = y + m * DM + c0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      h16x4 o;
+      for (int k = 0; k < 3; ++k) {
+        h16x8 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (h16)((v[4 * k + e] - mean) * rstd * w[4 * k + e] + bb[4 * k + e]);
-      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
+        for (int e = 0; e < 8; ++e) o[e] = (h16)((v[8 * k + e] - mean) * rstd * w[8 * k + e] + bb[8 * k + e]);
+        *reinterpret_cast<h16x8*>(dst + 8 * k) = o;
+      }
+      if (l5 == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+      if ((l5 & 1) == 0) lse_tot[m * H + h] = tot;
     }
-    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
-    if ((lane & 3) == 0) lse_tot[m * H + h] = tot;
   }
 }
 
@@ -308,68 +331,69 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
                                                          const float* __restrict__ lse_br, const float* __restrict__ lse_tot, Plan p,
                                                          const float* __restrict__ ln_w, const float* __restrict__ stats,
                                                          h16* __restrict__ dmixed, float* __restrict__ delta_br) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 5, l5 = lane & 31;
   const long M = (long)p.B * p.N;
-  const int h = lane >> 2, c0 = lane * 12;
+  const int h = l5 >> 1, c0 = l5 * MIX_CPL;
   const MixGeom geo(p, h);
   const int db = dense_branch(p);
-  float w[12];
+  float w[MIX_CPL];
 #pragma unroll
-  for (int e = 0; e < 12; ++e) w[e] = ln_w[c0 + e];
-  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+  for (int e = 0; e < MIX_CPL; ++e) w[e] = ln_w[c0 + e];
+  for (long m2 = ((long)blockIdx.x * 4 + wave) * 2; m2 < M; m2 += (long)gridDim.x * 8) {
+    const bool live = m2 + sub < M;
+    const long m = live ? m2 + sub : M - 1;
     const int pos = (int)(m % p.N);
     const float tot = lse_tot[m * H + h];
     const float mean = stats[2 * m], rstd = stats[2 * m + 1];
-    const H12 dyv = ld12(dy + m * DM + c0);
+    const H24 dyv = ld24(dy + m * DM + c0);
     bool cov[NB];
     float lse[NB];
-    H12 ob[NB];
+    H24 ob[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       cov[b] = b < p.nbranch && geo.grp[b] == residue(p, b, pos);
       const int sb = cov[b] ? b : db;
       lse[b] = lse_br[((long)sb * M + m) * H + h];
-      ob[b] = ld12(o_br + ((long)sb * M + m) * DM + c0);
+      ob[b] = ld24(o_br + ((long)sb * M + m) * DM + c0);
     }
-    float v[12];
+    float v[MIX_CPL];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) v[e] = 0.f;
+    for (int e = 0; e < MIX_CPL; ++e) v[e] = 0.f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float wgt = cov[b] ? __expf(lse[b] - tot) : 0.f;
 #pragma unroll
-      for (int e = 0; e < 12; ++e) v[e] = fmaf(wgt, cov[b] ? h12(ob[b], e) : 0.f, v[e]);
+      for (int e = 0; e < MIX_CPL; ++e) v[e] = fmaf(wgt, cov[b] ? h24(ob[b], e) : 0.f, v[e]);
     }
-    float g[12], xh[12];
+    float g[MIX_CPL], xh[MIX_CPL];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < MIX_CPL; ++i) {
       xh[i] = (v[i] - mean) * rstd;
-      g[i] = h12(dyv, i) * w[i];
+      g[i] = h24(dyv, i) * w[i];
       s1 += g[i]; s2 = fmaf(g[i], xh[i], s2);
     }
-    const float c1 = wave_sum(s1) * (1.0f / DM), c2 = wave_sum(s2) * (1.0f / DM);
-    float dm[12];
+    const float c1 = half_sum(s1) * (1.0f / DM), c2 = half_sum(s2) * (1.0f / DM);
+    float dm[MIX_CPL];
     h16* dst = dmixed + ((long)h * M + m) * HD + (c0 - h * HD);      // head-major [head][B*N][48]
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      h16x4 o;
+      h16x8 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * k + e;
+      for (int e = 0; e < 8; ++e) {
+        const int i = 8 * k + e;
         o[e] = (h16)(rstd * (g[i] - c1 - xh[i] * c2));
         dm[i] = (float)o[e];          // delta must match the fp16 dmixed the attention backward consumes
       }
-      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
+      if (live) *reinterpret_cast<h16x8*>(dst + 8 * k) = o;
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float d = 0.f;
 #pragma unroll
-      for (int e = 0; e < 12; ++e) d = fmaf(dm[e], h12(ob[b], e), d);
+      for (int e = 0; e < MIX_CPL; ++e) d = fmaf(dm[e], h24(ob[b], e), d);
       d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      if ((lane & 3) == 0 && cov[b]) delta_br[((long)b * M + m) * H + h] = d;
+      if (live && (l5 & 1) == 0 && cov[b]) delta_br[((long)b * M + m) * H + h] = d;
     }
   }
 }
@@ -758,7 +782,7 @@ extern "C" int mt_dilated_mix_ln_fwd(const mt_half* o_br, const float* lse_br, c
   if (!o_br || !lse_br || !ln_w || !ln_b || !y || !stats || !lse_tot || !plan_ok(plan)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
   const long M = (long)p.B * p.N;
-  const dim3 grid((int)min((M + 3) / 4, 8192L));
+  const dim3 grid((int)min((M + 7) / 8, 8192L));
   if (p.nbranch <= 5)
     hipLaunchKernelGGL(mix_ln_fwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)o_br, lse_br, p, ln_w, ln_b,
                        (h16*)y, stats, lse_tot);
@@ -775,7 +799,7 @@ extern "C" int mt_dilated_mix_ln_bwd(const mt_half* dy, const mt_half* o_br, con
   if (!dy || !o_br || !lse_br || !lse_tot || !ln_w || !stats || !dmixed || !delta_br || !plan_ok(plan)) return MT_ERR_BAD_ARG;
   const Plan p = make_plan(plan, 128);
   const long M = (long)p.B * p.N;
-  const dim3 grid((int)min((M + 3) / 4, 8192L));
+  const dim3 grid((int)min((M + 7) / 8, 8192L));
   if (p.nbranch <= 5)
     hipLaunchKernelGGL(mix_ln_bwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, (const h16*)dy, (const h16*)o_br, lse_br,
                        lse_tot, p, ln_w, stats, (h16*)dmixed, delta_br);

@@ -28,6 +28,7 @@ struct Plan {
   int seg[MT_MAX_BRANCHES], ratio[MT_MAX_BRANCHES], nseg[MT_MAX_BRANCHES], n[MT_MAX_BRANCHES];
   int order[MT_MAX_BRANCHES], qtiles[MT_MAX_BRANCHES], blk_off[MT_MAX_BRANCHES + 1];
   long ws_off[MT_MAX_BRANCHES + 1];   // backward workspace: per-branch compact [pass][seg][head][i][q|k|v][48] fp16
+  float inv_seg[MT_MAX_BRANCHES];     // 1 / seg (position -> segment index without an integer division per row)
 };
 
 Plan make_plan(const MtDilatedPlan* p, int qtile) {
@@ -37,6 +38,7 @@ Plan make_plan(const MtDilatedPlan* p, int qtile) {
     d.seg[i] = p->seg[i]; d.ratio[i] = p->ratio[i]; d.nseg[i] = p->nseg[i]; d.n[i] = p->n[i];
     d.order[i] = i;
     d.qtiles[i] = cdiv(p->n[i], qtile);
+    d.inv_seg[i] = 1.0f / (float)p->seg[i];
   }
   // longest sparse sequences first (their workgroups run longest)
   for (int i = 0; i < d.nbranch; ++i)
