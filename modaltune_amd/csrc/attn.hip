@@ -410,9 +410,11 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
 __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                  const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
                                                                  Plan p, h16* __restrict__ ws) {
-  __shared__ __attribute__((aligned(16))) h16 Ks[2][64 * KSTR];   // row-read layout
-  __shared__ __attribute__((aligned(16))) h16 Kt[2][64 * VSTR];   // transposed-read layout
-  __shared__ __attribute__((aligned(16))) h16 Vs[2][64 * KSTR];
+  // K and V tiles in LDS-DMA images (attn_common.h: img_off), double-buffered, one barrier per tile; the K image serves
+  // both the row reads (S) and the transposed reads (dQ): one image instead of two, no staging stores
+  __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // K0 | K1 | V0 | V1
+  h16* const Ks = smem;
+  h16* const Vs = smem + 2 * IMG_HALVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
   const WorkItem w = decode(p, blockIdx.x);
@@ -423,10 +425,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
   if (w.qt * 128 >= nv) return;
 
-  if (tid < 128) {   // zero the never-written columns 48..63 of the transposed-layout tile (read as d rows 48..63)
-    const int buf = tid >> 6, row = tid & 63;
-    *reinterpret_cast<h16x8*>(&Kt[buf][row * VSTR + 48]) = zero8;
-    *reinterpret_cast<h16x8*>(&Kt[buf][row * VSTR + 56]) = zero8;
+  {   // constant chunks 6, 7 (zeros, read as d rows 48..63 of K^T) of both K images; written once
+    const int buf = tid >> 7, row = (tid >> 1) & 63, which = 6 + (tid & 1);
+    *reinterpret_cast<h16x8*>(&Ks[buf * IMG_HALVES + img_off(row, which)]) = zero8;
   }
 
   const int iq = w.qt * 128 + wave * 32 + l31;
@@ -444,55 +445,38 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const float ndl = qvalid ? -dlraw : 0.f;
   const f32x2 nl22 = {nl2, nl2}, ndl2 = {ndl, ndl};
 
-  const StageIdx st(tid);
   const int ntile = (nv + 63) >> 6;      // tiles holding at least one real key
-  const int nfull = nv >> 6;             // tiles [0, nfull) hold only real rows
-  const __amdgpu_buffer_rsrc_t krs = make_rsrc(hm_ptr(qkv, M, H + w.h, sq.row(0)));
-  const __amdgpu_buffer_rsrc_t vrs = make_rsrc(hm_ptr(qkv, M, 2 * H + w.h, sq.row(0)));
-  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
-  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
-  h16x8 rk0, rk1, rv0, rv1;
-  bool ok0 = false, ok1 = false;
-  auto gload = [&](int t, auto full_tag) {      // first touched in lstore() (latency hides under the MFMAs)
-    const int kb = t * 64;
-    if (decltype(full_tag)::value) {
-      const uint32_t adv = (uint32_t)(kb * sq.dr * HD) * 2u;
-      rk0 = buf_ldg8(krs, c0, adv); rv0 = buf_ldg8(vrs, c0, adv);
-      rk1 = buf_ldg8(krs, c1, adv); rv1 = buf_ldg8(vrs, c1, adv);
-    } else {      // ragged tile: clamped rows, zeroed by a select in lstore()
-      const int i0 = kb + st.row0, i1 = kb + st.row1;
-      const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1);
-      rk0 = ldg8(hm_ptr(qkv, M, H + w.h, r0) + st.part0 * 8); rv0 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r0) + st.part0 * 8);
-      rk1 = ldg8(hm_ptr(qkv, M, H + w.h, r1) + st.part1 * 8); rv1 = ldg8(hm_ptr(qkv, M, 2 * H + w.h, r1) + st.part1 * 8);
-      ok0 = sq.valid(i0); ok1 = sq.valid(i1);
-    }
+  const int row_bytes = sq.dr * HD * 2;
+  const long valid_bytes = (long)(nv - 1) * row_bytes + HD * 2;     // entries [0, nv) are real rows; the rest read as zeros
+  const long tile_bytes = 64L * row_bytes;
+  const h16* const kseq = hm_ptr(qkv, M, H + w.h, sq.row(0));
+  const h16* const vseq = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
+  const DmaLane dl(tid, row_bytes);
+  auto dma = [&](int t) {
+    dma_tile(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), dl);
+    dma_tile(Vs + (t & 1) * IMG_HALVES, tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl);
   };
-  auto lstore = [&](int buf, auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    const h16x8 k0 = FULL ? rk0 : sel8(ok0, rk0), v0 = FULL ? rv0 : sel8(ok0, rv0);
-    *reinterpret_cast<h16x8*>(&Ks[buf][st.row0 * KSTR + st.part0 * 8]) = k0;
-    *reinterpret_cast<h16x8*>(&Kt[buf][st.row0 * VSTR + st.part0 * 8]) = k0;
-    *reinterpret_cast<h16x8*>(&Vs[buf][st.row0 * KSTR + st.part0 * 8]) = v0;
-    if (st.has1) {
-      const h16x8 k1 = FULL ? rk1 : sel8(ok1, rk1), v1 = FULL ? rv1 : sel8(ok1, rv1);
-      *reinterpret_cast<h16x8*>(&Ks[buf][st.row1 * KSTR + st.part1 * 8]) = k1;
-      *reinterpret_cast<h16x8*>(&Kt[buf][st.row1 * VSTR + st.part1 * 8]) = k1;
-      *reinterpret_cast<h16x8*>(&Vs[buf][st.row1 * KSTR + st.part1 * 8]) = v1;
-    }
-  };
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  int rrd[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) rrd[ks] = img_off(l31, 2 * ks + hh);
+  const int kc = 2 * (grp & 1) + (tp >> 1), ko = 4 * (tp & 1);
+  const int ka0 = img_off(4 * hh + tq, kc) + ko, ka1 = img_off(4 * hh + tq, kc + 4) + ko;
+  const int kb0 = img_off(4 * hh + tq + 8, kc) + ko, kb1 = img_off(4 * hh + tq + 8, kc + 4) + ko;
 
   f32x16 dq0, dq1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq0[i] = 0.f; dq1[i] = 0.f; }
-  gload(0, std::false_type{});
-  lstore(0, std::false_type{});
+  dma(0);
+  dma_wait_all();
   __syncthreads();
-  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  // tail_tag: the tile holds keys >= n (tile padding, excluded); next_tag: tile t + 1 is a full tile
-  auto tile = [&](int t, auto tail_tag, auto next_tag) {
+  // tail_tag: the tile holds keys >= n (tile padding, excluded)
+  auto tile = [&](int t, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    const int buf = t & 1, kb = t * 64;
-    if (t + 1 < ntile) gload(t + 1, next_tag);
+    const int kb = t * 64;
+    const h16* Kb = Ks + (t & 1) * IMG_HALVES;
+    const h16* Vb = Vs + (t & 1) * IMG_HALVES;
+    if (t + 1 < ntile) dma(t + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -500,9 +484,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Ks[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + rrd[ks]]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
-        const h16x8 vf = *reinterpret_cast<const h16x8*>(&Vs[buf][(sub * 32 + l31) * KSTR + ks * 16 + hh * 8]);
+        const h16x8 vf = *reinterpret_cast<const h16x8*>(&Vb[sub * 32 * IMG_ROW + rrd[ks]]);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
       }
       h16x8 dsf[2];
@@ -520,21 +504,20 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const h16* krow = &Kt[buf][(sub * 32 + s2 * 16 + 4 * hh + tq) * VSTR + 16 * (grp & 1) + 4 * tp];
-        const h16x8 k0 = cat8(lds_tr4(krow), lds_tr4(krow + 8 * VSTR));
-        const h16x8 k1 = cat8(lds_tr4(krow + 32), lds_tr4(krow + 8 * VSTR + 32));
+        const h16* kblk = Kb + (sub * 32 + s2 * 16) * IMG_ROW;
+        const h16x8 k0 = cat8(lds_tr4(kblk + ka0), lds_tr4(kblk + kb0));
+        const h16x8 k1 = cat8(lds_tr4(kblk + ka1), lds_tr4(kblk + kb1));
         dq0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, dsf[s2], dq0, 0, 0, 0);
         dq1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, dsf[s2], dq1, 0, 0, 0);
       }
     }
-    if (t + 1 < ntile) lstore(buf ^ 1, next_tag);
+    dma_wait_all();
     __syncthreads();
   };
-  int t = 0;
-  for (; t + 1 < nfull; ++t) tile(t, std::false_type{}, std::true_type{});
-  const int nmask = (ntile * 64 > sq.n) ? ntile - 1 : ntile;  // tiles >= nmask contain keys >= n
-  for (; t < nmask; ++t) tile(t, std::false_type{}, std::false_type{});
-  for (; t < ntile; ++t) tile(t, std::true_type{}, std::false_type{});
+  const bool tail_last = ntile * 64 > sq.n;      // the last processed tile contains keys >= n
+  const int nplain = tail_last ? ntile - 1 : ntile;
+  for (int t = 0; t < nplain; ++t) tile(t, std::false_type{});
+  if (tail_last) tile(ntile - 1, std::true_type{});
   if (qvalid) {
     h16* out = ws + ws_slot(p, w, iq);
 #pragma unroll
