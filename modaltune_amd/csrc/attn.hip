@@ -547,23 +547,27 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
                                                                   Plan p, h16* __restrict__ ws) {
-  __shared__ __attribute__((aligned(16))) h16 Qx[64 * VSTR];      // swizzled images (attn_common.h: swz), each read both ways
-  __shared__ __attribute__((aligned(16))) h16 Dx[64 * VSTR];
-  __shared__ __attribute__((aligned(16))) float L2s[64];
-  __shared__ __attribute__((aligned(16))) float Dls[64];
+  // Q and dO tiles in LDS-DMA images (attn_common.h: img_off: each read both by rows and transposed), double-buffered
+  // together with the per-query constants; one barrier per tile
+  __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // Q0 | Q1 | D0 | D1
+  __shared__ __attribute__((aligned(16))) float L2s[2][64];
+  __shared__ __attribute__((aligned(16))) float Dls[2][64];
+  h16* const Qx = smem;
+  h16* const Dx = smem + 2 * IMG_HALVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
   const WorkItem w = decode(p, blockIdx.x);
   const Seq sq = make_seq(p, w);
   const long M = (long)p.B * p.N;
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  // padded keys get no gradient; padded queries have P' = 0: neither is computed
+  // padded keys get no gradient; padded queries read as Q = dO = 0 (range check of the DMA descriptor) and add nothing
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
   if (w.qt * 128 >= nv) return;
 
-  if (tid < 64) {      // the zero columns d = 48..63 (logical chunks 6, 7), written once
-    *reinterpret_cast<h16x8*>(&Qx[swz(tid, 6)]) = zero8; *reinterpret_cast<h16x8*>(&Qx[swz(tid, 7)]) = zero8;
-    *reinterpret_cast<h16x8*>(&Dx[swz(tid, 6)]) = zero8; *reinterpret_cast<h16x8*>(&Dx[swz(tid, 7)]) = zero8;
+  {   // the zero columns d = 48..63 (logical chunks 6, 7) of all four images, written once: 4 x 64 x 2 chunks, two per thread
+    const int img = tid >> 6, row = tid & 63;
+    *reinterpret_cast<h16x8*>(&smem[img * IMG_HALVES + img_off(row, 6)]) = zero8;
+    *reinterpret_cast<h16x8*>(&smem[img * IMG_HALVES + img_off(row, 7)]) = zero8;
   }
 
   // this lane's key: K^T / V^T fragments (B operands), element j of k-step ks = K[key][16 ks + 8 hh + j]
@@ -577,70 +581,55 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     vf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, 2 * H + w.h, krow) + ks * 16 + hh * 8));
   }
 
-  const StageIdx st(tid);
   const int ntile = (nv + 63) >> 6;      // tiles holding at least one real query
-  const int nfull = nv >> 6;             // tiles [0, nfull) hold only real rows
-  const __amdgpu_buffer_rsrc_t qrs = make_rsrc(hm_ptr(qkv, M, w.h, sq.row(0)));
-  const __amdgpu_buffer_rsrc_t drs = make_rsrc(hm_ptr(dmixed, M, w.h, sq.row(0)));
-  const __amdgpu_buffer_rsrc_t lrs = make_rsrc(lse_tot + sq.row(0) * H + w.h);
-  const __amdgpu_buffer_rsrc_t dlrs = make_rsrc(delta_br + ((long)w.br * M + sq.row(0)) * H + w.h);
-  const uint32_t c0 = (uint32_t)(st.row0 * sq.dr * HD + st.part0 * 8) * 2u;
-  const uint32_t c1 = st.has1 ? (uint32_t)(st.row1 * sq.dr * HD + st.part1 * 8) * 2u : c0;
-  const uint32_t cl = (uint32_t)(lane * sq.dr * H) * 4u;
-  h16x8 rq0, rq1, rd0, rd1;
+  const int row_bytes = sq.dr * HD * 2;
+  const long valid_bytes = (long)(nv - 1) * row_bytes + HD * 2;
+  const long tile_bytes = 64L * row_bytes;
+  const h16* const qseq = hm_ptr(qkv, M, w.h, sq.row(0));
+  const h16* const dseq = hm_ptr(dmixed, M, w.h, sq.row(0));
+  const DmaLane dl(tid, row_bytes);
+  // per-query constants of a tile: wave 0 loads them (one query per lane), neutral values past the end of the sequence
+  const float* const lbase = lse_tot + sq.row(0) * H + w.h;
+  const float* const dbase = delta_br + ((long)w.br * M + sq.row(0)) * H + w.h;
   float rl2 = 0.f, rdl = 0.f;
-  bool ok0 = false, ok1 = false, ok2 = false;
-  auto gload = [&](int t, auto full_tag) {      // first touched in lstore()
-    const int qb = t * 64;
-    if (decltype(full_tag)::value) {
-      const uint32_t adv = (uint32_t)(qb * sq.dr * HD) * 2u, advl = (uint32_t)(qb * sq.dr * H) * 4u;
-      rq0 = buf_ldg8(qrs, c0, adv); rd0 = buf_ldg8(drs, c0, adv);
-      rq1 = buf_ldg8(qrs, c1, adv); rd1 = buf_ldg8(drs, c1, adv);
-      rl2 = buf_ldf(lrs, cl, advl); rdl = buf_ldf(dlrs, cl, advl);
-    } else {      // ragged tile: clamped rows, neutralised in lstore()
-      const int i0 = qb + st.row0, i1 = qb + st.row1, i2 = qb + lane;
-      const long r0 = sq.row_clamped(i0), r1 = sq.row_clamped(i1), r2 = sq.row_clamped(i2);
-      rq0 = ldg8(hm_ptr(qkv, M, w.h, r0) + st.part0 * 8); rd0 = ldg8(hm_ptr(dmixed, M, w.h, r0) + st.part0 * 8);
-      rq1 = ldg8(hm_ptr(qkv, M, w.h, r1) + st.part1 * 8); rd1 = ldg8(hm_ptr(dmixed, M, w.h, r1) + st.part1 * 8);
-      rl2 = lse_tot[r2 * H + w.h]; rdl = delta_br[((long)w.br * M + r2) * H + w.h];
-      ok0 = sq.valid(i0); ok1 = sq.valid(i1); ok2 = sq.valid(i2);
+  auto issue = [&](int t) {
+    dma_tile(Qx + (t & 1) * IMG_HALVES, tile_rsrc(qseq, t * tile_bytes, valid_bytes), dl);
+    dma_tile(Dx + (t & 1) * IMG_HALVES, tile_rsrc(dseq, t * tile_bytes, valid_bytes), dl);
+    if (tid < 64) {
+      const int i = t * 64 + lane;
+      const long off = (long)min(i, nv - 1) * sq.dr * H;
+      const bool ok = i < nv;
+      rl2 = ok ? fmaf(-lbase[off], LOG2E, LOG2_LN2) : 0.f;      // (Q = dO = 0 there: P' is multiplied by zeros)
+      rdl = ok ? -dbase[off] : 0.f;
     }
   };
-  const int sw0 = swz(st.row0, st.part0), sw1 = swz(st.row1, st.part1);      // staging slots in the swizzled images
-  auto lstore = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    const h16x8 q0 = FULL ? rq0 : sel8(ok0, rq0), d0 = FULL ? rd0 : sel8(ok0, rd0);
-    *reinterpret_cast<h16x8*>(&Qx[sw0]) = q0;
-    *reinterpret_cast<h16x8*>(&Dx[sw0]) = d0;
-    if (st.has1) {
-      const h16x8 q1 = FULL ? rq1 : sel8(ok1, rq1), d1 = FULL ? rd1 : sel8(ok1, rd1);
-      *reinterpret_cast<h16x8*>(&Qx[sw1]) = q1;
-      *reinterpret_cast<h16x8*>(&Dx[sw1]) = d1;
-    }
-    if (tid < 64) {      // padded / out-of-range queries contribute nothing: -L2 = -big -> P' = 0
-      const bool ok = FULL || ok2;
-      L2s[tid] = ok ? fmaf(-rl2, LOG2E, LOG2_LN2) : -1.0e30f;
-      Dls[tid] = ok ? -rdl : 0.f;
-    }
+  auto publish = [&](int t) {      // constants of tile t into their buffer (written by wave 0, read after the barrier)
+    if (tid < 64) { L2s[t & 1][tid] = rl2; Dls[t & 1][tid] = rdl; }
   };
 
   f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  // per-lane offsets into the swizzled images (the sub / s2 row-block offsets are multiples of 4 rows x 4: they leave the
-  // swizzle term unchanged and stay immediate): row reads of chunk 2 ks + hh, transposed reads of rows 4 hh + tq (a) and
-  // + 8 (b), column blocks d 0..31 (0) and 32..63 (1)
-  const int rrd[3] = {swz(l31, hh), swz(l31, 2 + hh), swz(l31, 4 + hh)};
+  // per-lane offsets into the images: row reads of chunk 2 ks + hh, transposed reads of rows 4 hh + tq (a) and + 8 (b),
+  // column blocks d 0..31 (0) and 32..63 (1); the sub / s2 row-block offsets are multiples of 16 rows (img_f unchanged)
+  int rrd[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) rrd[ks] = img_off(l31, 2 * ks + hh);
   const int trc = 2 * (grp & 1) + (tp >> 1), tro = 4 * (tp & 1);
-  const int tr_a0 = swz(4 * hh + tq, trc) + tro, tr_a1 = swz(4 * hh + tq, trc + 4) + tro;
-  const int tr_b0 = swz(4 * hh + tq + 8, trc) + tro, tr_b1 = swz(4 * hh + tq + 8, trc + 4) + tro;
-  // cur_tag: tile t (in registers) is a full tile; next_tag: tile t + 1 is
-  auto tile = [&](int t, auto cur_tag, auto next_tag) {
-    __syncthreads();            // previous tile fully consumed
-    lstore(cur_tag);
-    __syncthreads();
-    if (t + 1 < ntile) gload(t + 1, next_tag);
+  const int tr_a0 = img_off(4 * hh + tq, trc) + tro, tr_a1 = img_off(4 * hh + tq, trc + 4) + tro;
+  const int tr_b0 = img_off(4 * hh + tq + 8, trc) + tro, tr_b1 = img_off(4 * hh + tq + 8, trc + 4) + tro;
+
+  issue(0);
+  publish(0);
+  dma_wait_all();
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const h16* Qb = Qx + (t & 1) * IMG_HALVES;
+    const h16* Db = Dx + (t & 1) * IMG_HALVES;
+    const float* L2b = L2s[t & 1];
+    const float* Dlb = Dls[t & 1];
+    if (t + 1 < ntile) issue(t + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       // row constants ride in as the INITIAL accumulators (rows of the accumulators are queries:
@@ -648,16 +637,16 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
       f32x16 s, dp;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&L2s[sub * 32 + 8 * g4 + 4 * hh]);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&Dls[sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&L2b[sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Dlb[sub * 32 + 8 * g4 + 4 * hh]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a[e]; dp[4 * g4 + e] = b[e]; }
       }
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qx[sub * 32 * VSTR + rrd[ks]]);
+        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qb[sub * 32 * IMG_ROW + rrd[ks]]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s, 0, 0, 0);
-        const h16x8 da = *reinterpret_cast<const h16x8*>(&Dx[sub * 32 * VSTR + rrd[ks]]);
+        const h16x8 da = *reinterpret_cast<const h16x8*>(&Db[sub * 32 * IMG_ROW + rrd[ks]]);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp, 0, 0, 0);
       }
       h16x8 pf[2], dsf[2];
@@ -670,24 +659,21 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int rb = (sub * 32 + s2 * 16) * VSTR;      // rows rb + 4 hh + tq and + 8; cols d 0..31 / 32..63
-        const h16x8 d0 = cat8(lds_tr4(&Dx[rb + tr_a0]), lds_tr4(&Dx[rb + tr_b0]));
-        const h16x8 d1 = cat8(lds_tr4(&Dx[rb + tr_a1]), lds_tr4(&Dx[rb + tr_b1]));
+        const int rb = (sub * 32 + s2 * 16) * IMG_ROW;      // rows rb + 4 hh + tq and + 8; cols d 0..31 / 32..63
+        const h16x8 d0 = cat8(lds_tr4(&Db[rb + tr_a0]), lds_tr4(&Db[rb + tr_b0]));
+        const h16x8 d1 = cat8(lds_tr4(&Db[rb + tr_a1]), lds_tr4(&Db[rb + tr_b1]));
         dv0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, pf[s2], dv0, 0, 0, 0);
         dv1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, pf[s2], dv1, 0, 0, 0);
-        const h16x8 q0 = cat8(lds_tr4(&Qx[rb + tr_a0]), lds_tr4(&Qx[rb + tr_b0]));
-        const h16x8 q1 = cat8(lds_tr4(&Qx[rb + tr_a1]), lds_tr4(&Qx[rb + tr_b1]));
+        const h16x8 q0 = cat8(lds_tr4(&Qb[rb + tr_a0]), lds_tr4(&Qb[rb + tr_b0]));
+        const h16x8 q1 = cat8(lds_tr4(&Qb[rb + tr_a1]), lds_tr4(&Qb[rb + tr_b1]));
         dk0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, dsf[s2], dk0, 0, 0, 0);
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, dsf[s2], dk1, 0, 0, 0);
       }
     }
-  };
-  if (nfull > 0) gload(0, std::true_type{});
-  else gload(0, std::false_type{});
-  int t = 0;
-  for (; t + 1 < nfull; ++t) tile(t, std::true_type{}, std::true_type{});
-  if (t < nfull) { tile(t, std::true_type{}, std::false_type{}); ++t; }     // last full tile, ragged successor
-  for (; t < ntile; ++t) tile(t, std::false_type{}, std::false_type{});
+    if (t + 1 < ntile) publish(t + 1);
+    dma_wait_all();            // tile t + 1 has landed ...
+    __syncthreads();           // ... for everybody, and everybody has left tile t
+  }
   if (kvalid) {
     h16* outk = ws + ws_slot(p, w, ik) + HD;
     h16* outv = outk + HD;
