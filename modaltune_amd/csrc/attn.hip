@@ -443,7 +443,9 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const float L2raw = lse_tot[qrow * H + w.h], dlraw = delta_br[((long)w.br * M + qrow) * H + w.h];
   const float nl2 = qvalid ? fmaf(-L2raw, LOG2E, LOG2_LN2) : -1.0e30f;
   const float ndl = qvalid ? -dlraw : 0.f;
-  const f32x2 nl22 = {nl2, nl2}, ndl2 = {ndl, ndl};
+  f32x16 nl2i, ndli;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { nl2i[i] = nl2; ndli[i] = ndl; }
 
   const int ntile = (nv + 63) >> 6;      // tiles holding at least one real key
   const int row_bytes = sq.dr * HD * 2;
@@ -479,26 +481,26 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
     if (t + 1 < ntile) dma(t + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      // the per-query constants (query = lane: one value per lane) ride in as the INITIAL accumulators:
+      // S' - L2 + log2(ln 2) and dP - delta leave the chains ready
       f32x16 s, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const h16x8 kf = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + rrd[ks]]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? nl2i : s, 0, 0, 0);
         const h16x8 vf = *reinterpret_cast<const h16x8*>(&Vb[sub * 32 * IMG_ROW + rrd[ks]]);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], ks == 0 ? ndli : dp, 0, 0, 0);
       }
       h16x8 dsf[2];
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]} + nl22);
+        f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]});
         if (TAIL) {
           const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
           if (kidx >= sq.n) pt[0] = 0.f;
           if (kidx + 1 >= sq.n) pt[1] = 0.f;
         }
-        const f32x2 d = pt * ((f32x2){dp[i], dp[i + 1]} + ndl2);
+        const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
         dsf[i >> 3][i & 7] = (h16)d[0];
         dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
       }
