@@ -111,6 +111,31 @@ int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B
                    const float* bias, int bias_on_m, float* C, long cs0, long cs1, long c_bs, int M, int N, int K,
                    int batch, int act, int accumulate, float* rowsum, mt_stream_t stream);
 
+/* Up to MT_SGEMM_MAX independent small products in ONE launch, each with the nn.Linear forward / backward fused around it
+ * (the token side is a chain of ~5 us launches; what it costs is their number):
+ *   forward   C = resid + drop_c(act(A B^T + bias)) [+ C];  pre_out (or NULL) receives A B^T + bias, the value the
+ *             backward differentiates -- nn.Linear + activation + nn.Dropout + residual add of GE:184-192, AM:284-287;
+ *   backward  A'(m,k) = drop_a(A(m,k)) * act'(a_aux(m,k)) is formed as the dy operand is loaded (a_aux = the saved
+ *             pre_out, a_drop = the forward's c_drop): dX = A' W and dW = A'^T x (+ rowsum = db) of one nn.Linear share a launch.
+ * pre_out / resid are addressed like C, a_aux like A.  The masks are element dropout of a DENSE tensor: the mask index
+ * is the element offset from C / from A (path_p must be 0).  Products of one launch must not write what another reads or
+ * writes.  mt_sgemm_small is the one-product, no-fusion form of this entry. */
+#define MT_SGEMM_MAX 3
+typedef struct {
+  const float* A; long as0, as1, a_bs;
+  const float* B; long bs0, bs1, b_bs;
+  const float* bias; int bias_on_m;
+  float* C; long cs0, cs1, c_bs;
+  int M, N, K, batch, act, accumulate;
+  float* rowsum;
+  float* pre_out;
+  const float* resid;
+  MtDropout c_drop;
+  const float* a_aux; int a_act;
+  MtDropout a_drop;
+} MtSgemm;
+int mt_sgemm_multi(const MtSgemm* probs, int n, mt_stream_t stream);
+
 /* ------------------------------------------------------------- LayerNorm --------------------------- */
 /* y = LN(f(x)) * w + b over the last dim D (eps 1e-5), one wave per row; stats (mean, rstd) saved per row.
  * f = identity or erf-GELU computed in fp32 (FFN:136 forces the activation to fp32, then FFN:138 ffn_layernorm).

@@ -29,6 +29,17 @@ class MtGemmEpilogue(C.Structure):
                 ("pos_table", P), ("pos_row", P), ("pos_col", P), ("drop", MtDropout)]
 
 
+MT_SGEMM_MAX = 3
+
+
+class MtSgemm(C.Structure):
+    _fields_ = [("A", P), ("as0", L), ("as1", L), ("a_bs", L), ("B", P), ("bs0", L), ("bs1", L), ("b_bs", L),
+                ("bias", P), ("bias_on_m", I), ("C", P), ("cs0", L), ("cs1", L), ("c_bs", L),
+                ("M", I), ("N", I), ("K", I), ("batch", I), ("act", I), ("accumulate", I),
+                ("rowsum", P), ("pre_out", P), ("resid", P), ("c_drop", MtDropout),
+                ("a_aux", P), ("a_act", I), ("a_drop", MtDropout)]
+
+
 MT_MAX_BRANCHES = 8
 
 
@@ -50,6 +61,7 @@ SIGNATURES = {
     "mt_gemm_tn_f16": [P, L, RM, P, L, RM, I, I, I, P, L, P],
     "mt_colsum_f16": [P, L, RM, I, I, P, P],
     "mt_sgemm_small": [P, L, L, L, P, L, L, L, P, I, P, L, L, L, I, I, I, I, I, I, P, P],
+    "mt_sgemm_multi": [C.POINTER(MtSgemm), I, P],
     "mt_layernorm_fwd": [P, L, RM, I, I, P, P, P, I, P, L, RM, I, P, I, I, P],
     "mt_add_layernorm_fwd": [P, P, DR, P, P, P, P, P, I, I, P],
     "mt_layernorm_bwd": [P, L, RM, I, P, L, RM, I, I, P, P, P, L, RM, I, I, P, P, P, DR, I, I, P],

@@ -603,6 +603,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const h16* A, long lda, Row
 
 // ------------------------------------------------------------------------------------------------
 // Small strided fp32 GEMM (token side): fp32 MFMA, operands straight from global memory.
+// The token side is a chain of ~5 us launches, so what counts is how few there are: one launch carries up to
+// MT_SGEMM_MAX independent products (the dX and dW products of one nn.Linear backward; sibling projections of one input),
+// the nn.Linear forward's activation / dropout / residual ride on the epilogue, and the backward's dropout mask and
+// activation derivative are applied to the dy operand as it is loaded (no dpre tensor, no elementwise launches).
 // ------------------------------------------------------------------------------------------------
 struct SgemmArgs {
   const float* A; long as0, as1, a_bs;
@@ -610,8 +614,16 @@ struct SgemmArgs {
   const float* bias; int bias_on_m;
   float* C; long cs0, cs1, c_bs;
   int M, N, K, act, accumulate;
-  float* rowsum;      // optional: rowsum[m] += sum_k A(m,k) (the bias gradient riding on a dW = dy^T x product)
+  float* rowsum;      // optional: rowsum[m] += sum_k A'(m,k) (the bias gradient riding on a dW = dy^T x product)
+  float* pre_out;     // optional: the value before the activation, addressed like C (what the backward differentiates)
+  const float* resid; // optional: added after activation and dropout, addressed like C
+  DropArgs cdrop;     // element dropout of the activation output; mask index = element offset in C (a dense tensor)
+  const float* a_aux; int a_act;    // A'(m,k) = drop(A(m,k)) * act'(a_aux(m,k)), a_aux addressed like A
+  DropArgs adrop;     // mask index = element offset in A (the dense dy tensor whose forward drew the same mask)
+  int ak, bk;         // operand rows k-contiguous and 16-byte aligned
+  int nx, ny, nblk;   // 16 x 16 tiles along n / m; workgroups of this product (nx * ny * batch)
 };
+struct SgemmMulti { SgemmArgs p[MT_SGEMM_MAX]; int n; };
 
 MT_DEVINL float apply_act(float v, int act) {
   switch (act) {
@@ -620,6 +632,40 @@ MT_DEVINL float apply_act(float v, int act) {
     case MT_ACT_ELU: return v > 0.f ? v : expm1f(v);
     default: return v;
   }
+}
+MT_DEVINL float act_grad(float v, int act) {
+  switch (act) {
+    case MT_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+    case MT_ACT_GELU: return gelu_erf_grad(v);
+    case MT_ACT_ELU: return v > 0.f ? 1.f : __expf(v);
+    default: return 1.f;
+  }
+}
+// scale factors of 4 consecutive elements (offset off, off % 4 == 0) / of one element of an element-dropout site
+MT_DEVINL f32x4 sg_drop4(const DropArgs& d, long off) { return drop_elem4(d, (uint64_t)off >> 2, 1.f); }
+MT_DEVINL float sg_drop1(const DropArgs& d, long off) { return drop_keep1(d, d.site, (uint64_t)off) ? 1.f / (1.f - d.p) : 0.f; }
+
+// 4 consecutive k of operand row `p` (k-contiguous: one 16-byte load; strided: 4 scalar loads)
+template <bool KC>
+MT_DEVINL f32x4 sg_load4(const float* p, long k, long s1) {
+  if (KC) return *reinterpret_cast<const f32x4*>(p + k);
+  return (f32x4){p[k * s1], p[(k + 1) * s1], p[(k + 2) * s1], p[(k + 3) * s1]};
+}
+// A' = drop(A) * act'(aux) on 4 consecutive k; off0 = element offset of (row, k) from the tensor base
+template <bool KC>
+MT_DEVINL f32x4 sg_xform4(const SgemmArgs& g, f32x4 a, f32x4 aux, long off0) {
+  if (g.adrop.rng) {
+    if (KC) a *= sg_drop4(g.adrop, off0);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= sg_drop1(g.adrop, off0 + e * g.as1);
+    }
+  }
+  if (g.a_aux) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] *= act_grad(aux[e], g.a_act);
+  }
+  return a;
 }
 
 // One workgroup = one 16x16 output tile; its four waves split K and each runs v_mfma_f32_16x16x4_f32 (fp32 operands,
@@ -630,32 +676,35 @@ MT_DEVINL float apply_act(float v, int act) {
 // (The previous form -- one output per thread, both operands re-read from LDS for every FMA -- was LDS-bound at
 // 17 us for 195 x 192 x 768; these GEMMs are latency chains, so what matters is one deep batch of independent loads.)
 template <bool AK, bool BK_>
-__global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
-  __shared__ float part[4][16][17];
-  __shared__ float rsum[4][16];
+MT_DEVINL void sgemm_tile(const SgemmArgs& g, int bx, int by, int bz, float (*part)[16][17], float (*rsum)[16]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, bz = blockIdx.z;
-  const float* ap = g.A + (long)bz * g.a_bs + (long)min(m0 + r, g.M - 1) * g.as0;
+  const int m0 = by * 16, n0 = bx * 16;
+  const long arow = (long)bz * g.a_bs + (long)min(m0 + r, g.M - 1) * g.as0;     // element offset of this lane's A row
+  const float* ap = g.A + arow;
+  const float* xp = g.a_aux ? g.a_aux + arow : nullptr;
   const float* bp = g.B + (long)bz * g.b_bs + (long)min(n0 + r, g.N - 1) * g.bs0;
-  float* C = g.C + (long)bz * g.c_bs;
+  const bool xf = g.a_aux != nullptr || g.adrop.rng != nullptr;
   // this wave's k range: a multiple of 16 per wave
   const int kper = ((g.K + 63) / 64) * 16;
   const int kb = wave * kper, ke = min(g.K, kb + kper);
-  const bool want_rs = g.rowsum != nullptr && blockIdx.x == 0;
+  const bool want_rs = g.rowsum != nullptr && bx == 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float rs = 0.f;
   int k0 = kb;
-  // full 64-wide blocks: 4 (x 2 operands) independent loads per lane in flight, then 16 MFMAs
+  // full 64-wide blocks: 4 (x 2 or 3 operands) independent loads per lane in flight, then 16 MFMAs
   for (; k0 + 64 <= ke; k0 += 64) {
-    f32x4 a[4], b[4];
+    f32x4 a[4], b[4], x[4] = {};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + 16 * j + 4 * kq;
-      if (AK) a[j] = *reinterpret_cast<const f32x4*>(ap + k);
-      else a[j] = (f32x4){ap[(long)k * g.as1], ap[(long)(k + 1) * g.as1], ap[(long)(k + 2) * g.as1], ap[(long)(k + 3) * g.as1]};
-      if (BK_) b[j] = *reinterpret_cast<const f32x4*>(bp + k);
-      else b[j] = (f32x4){bp[(long)k * g.bs1], bp[(long)(k + 1) * g.bs1], bp[(long)(k + 2) * g.bs1], bp[(long)(k + 3) * g.bs1]};
+      a[j] = sg_load4<AK>(ap, k, g.as1);
+      b[j] = sg_load4<BK_>(bp, k, g.bs1);
+      if (xp) x[j] = sg_load4<AK>(xp, k, g.as1);
+    }
+    if (xf) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = sg_xform4<AK>(g, a[j], x[j], arow + (long)(k0 + 16 * j + 4 * kq) * g.as1);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -667,11 +716,10 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
   // full 16-wide blocks (a wave's share of a short K is below 64)
   for (; k0 + 16 <= ke; k0 += 16) {
     const int k = k0 + 4 * kq;
-    f32x4 a, b;
-    if (AK) a = *reinterpret_cast<const f32x4*>(ap + k);
-    else a = (f32x4){ap[(long)k * g.as1], ap[(long)(k + 1) * g.as1], ap[(long)(k + 2) * g.as1], ap[(long)(k + 3) * g.as1]};
-    if (BK_) b = *reinterpret_cast<const f32x4*>(bp + k);
-    else b = (f32x4){bp[(long)k * g.bs1], bp[(long)(k + 1) * g.bs1], bp[(long)(k + 2) * g.bs1], bp[(long)(k + 3) * g.bs1]};
+    f32x4 a = sg_load4<AK>(ap, k, g.as1), x = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 b = sg_load4<BK_>(bp, k, g.bs1);
+    if (xp) x = sg_load4<AK>(xp, k, g.as1);
+    if (xf) a = sg_xform4<AK>(g, a, x, arow + (long)k * g.as1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
     if (want_rs) rs += (a[0] + a[1]) + (a[2] + a[3]);
@@ -684,7 +732,10 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
       const int k = k0 + 4 * kq + e;
       const bool ok = k < ke;
       const int kc = ok ? k : kb;
-      const float av = ap[(long)kc * g.as1], bv = bp[(long)kc * g.bs1];
+      float av = ap[(long)kc * g.as1];
+      const float bv = bp[(long)kc * g.bs1];
+      if (g.adrop.rng) av *= sg_drop1(g.adrop, arow + (long)kc * g.as1);
+      if (xp) av *= act_grad(xp[(long)kc * g.as1], g.a_act);
       a[e] = ok ? av : 0.f; b[e] = ok ? bv : 0.f;
     }
 #pragma unroll
@@ -707,10 +758,29 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs g) {
   if (m < g.M && n < g.N) {
     float v = (part[0][tm][tn] + part[1][tm][tn]) + (part[2][tm][tn] + part[3][tm][tn]);
     if (g.bias) v += g.bias[g.bias_on_m ? m : n];
+    const long off = (long)bz * g.c_bs + m * g.cs0 + n * g.cs1;
+    if (g.pre_out) g.pre_out[off] = v;
     v = apply_act(v, g.act);
-    float* c = &C[m * g.cs0 + n * g.cs1];
+    if (g.cdrop.rng) v *= sg_drop1(g.cdrop, off);
+    if (g.resid) v += g.resid[off];
+    float* c = &g.C[off];
     *c = g.accumulate ? *c + v : v;
   }
+}
+
+__global__ __launch_bounds__(256) void sgemm_multi_kernel(SgemmMulti mm) {
+  __shared__ float part[4][16][17];
+  __shared__ float rsum[4][16];
+  int blk = blockIdx.x, pi = 0;
+#pragma unroll
+  for (int i = 0; i + 1 < MT_SGEMM_MAX; ++i)
+    if (pi == i && i + 1 < mm.n && blk >= mm.p[i].nblk) { blk -= mm.p[i].nblk; pi = i + 1; }
+  const SgemmArgs& g = mm.p[pi];
+  const int bx = blk % g.nx, by = (blk / g.nx) % g.ny, bz = blk / (g.nx * g.ny);
+  if (g.ak && g.bk) sgemm_tile<true, true>(g, bx, by, bz, part, rsum);
+  else if (g.ak) sgemm_tile<true, false>(g, bx, by, bz, part, rsum);
+  else if (g.bk) sgemm_tile<false, true>(g, bx, by, bz, part, rsum);
+  else sgemm_tile<false, false>(g, bx, by, bz, part, rsum);
 }
 
 }  // namespace
@@ -783,21 +853,49 @@ extern "C" int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, i
   return MT_OK;
 }
 
+static int sgemm_fill(const MtSgemm& q, SgemmArgs& g) {
+  if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.batch <= 0 || (q.rowsum && q.batch != 1)) return MT_ERR_BAD_ARG;
+  g.A = q.A; g.as0 = q.as0; g.as1 = q.as1; g.a_bs = q.a_bs;
+  g.B = q.B; g.bs0 = q.bs0; g.bs1 = q.bs1; g.b_bs = q.b_bs;
+  g.bias = q.bias; g.bias_on_m = q.bias_on_m;
+  g.C = q.C; g.cs0 = q.cs0; g.cs1 = q.cs1; g.c_bs = q.c_bs;
+  g.M = q.M; g.N = q.N; g.K = q.K; g.act = q.act; g.accumulate = q.accumulate;
+  g.rowsum = q.rowsum; g.pre_out = q.pre_out; g.resid = q.resid;
+  g.cdrop = make_drop(&q.c_drop); g.a_aux = q.a_aux; g.a_act = q.a_act; g.adrop = make_drop(&q.a_drop);
+  // the fused masks are element dropout only (DropPath is a row factor: mt_droppath_rows_f32)
+  if (g.cdrop.path_p > 0.f || g.adrop.path_p > 0.f) return MT_ERR_UNSUPPORTED;
+  if (!(g.cdrop.p > 0.f)) g.cdrop.rng = nullptr;
+  if (!(g.adrop.p > 0.f)) g.adrop.rng = nullptr;
+  // 16-byte loads along k need k-contiguous, 16-byte aligned rows (of the auxiliary operand too)
+  g.ak = q.as1 == 1 && (q.as0 % 4) == 0 && (q.a_bs % 4) == 0 && ((uintptr_t)q.A & 15) == 0 && ((uintptr_t)q.a_aux & 15) == 0;
+  g.bk = q.bs1 == 1 && (q.bs0 % 4) == 0 && (q.b_bs % 4) == 0 && ((uintptr_t)q.B & 15) == 0;
+  g.nx = cdiv(q.N, 16); g.ny = cdiv(q.M, 16); g.nblk = g.nx * g.ny * q.batch;
+  return MT_OK;
+}
+
+extern "C" int mt_sgemm_multi(const MtSgemm* probs, int n, mt_stream_t stream) {
+  if (!probs || n < 1 || n > MT_SGEMM_MAX) return MT_ERR_BAD_ARG;
+  SgemmMulti mm;
+  mm.n = n;
+  long blocks = 0;
+  for (int i = 0; i < MT_SGEMM_MAX; ++i) {
+    const int rc = sgemm_fill(probs[i < n ? i : 0], mm.p[i]);
+    if (rc != MT_OK) return rc;
+    if (i < n) blocks += mm.p[i].nblk;
+  }
+  if (blocks > 0x7fffffffL) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sgemm_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mm);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
 extern "C" int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B, long bs0, long bs1,
                               long b_bs, const float* bias, int bias_on_m, float* C, long cs0, long cs1, long c_bs,
                               int M, int N, int K, int batch, int act, int accumulate, float* rowsum,
                               mt_stream_t stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || (rowsum && batch != 1)) return MT_ERR_BAD_ARG;
-  SgemmArgs g{A, as0, as1, a_bs, B, bs0, bs1, b_bs, bias, bias_on_m, C, cs0, cs1, c_bs, M, N, K, act, accumulate, rowsum};
-  // 16-byte loads along k need k-contiguous, 16-byte aligned rows
-  const bool ak = as1 == 1 && (as0 % 4) == 0 && (a_bs % 4) == 0 && ((uintptr_t)A & 15) == 0;
-  const bool bk = bs1 == 1 && (bs0 % 4) == 0 && (b_bs % 4) == 0 && ((uintptr_t)B & 15) == 0;
-  const dim3 grid(cdiv(N, 16), cdiv(M, 16), batch);
-  hipStream_t s = (hipStream_t)stream;
-  if (ak && bk) hipLaunchKernelGGL((sgemm_small_kernel<true, true>), grid, dim3(256), 0, s, g);
-  else if (ak) hipLaunchKernelGGL((sgemm_small_kernel<true, false>), grid, dim3(256), 0, s, g);
-  else if (bk) hipLaunchKernelGGL((sgemm_small_kernel<false, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((sgemm_small_kernel<false, false>), grid, dim3(256), 0, s, g);
-  MT_CHECK_LAUNCH();
-  return MT_OK;
+  MtSgemm q = {};
+  q.A = A; q.as0 = as0; q.as1 = as1; q.a_bs = a_bs; q.B = B; q.bs0 = bs0; q.bs1 = bs1; q.b_bs = b_bs;
+  q.bias = bias; q.bias_on_m = bias_on_m; q.C = C; q.cs0 = cs0; q.cs1 = cs1; q.c_bs = c_bs;
+  q.M = M; q.N = N; q.K = K; q.batch = batch; q.act = act; q.accumulate = accumulate; q.rowsum = rowsum;
+  return mt_sgemm_multi(&q, 1, stream);
 }

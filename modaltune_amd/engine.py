@@ -513,15 +513,12 @@ class Engine:
             p = f"gene_encoder.mlp_mixer.{k}."
             n1 = tape.layernorm(z, P(p + "0.norm.weight"), P(p + "0.norm.bias"))
             # FeedForward = dense, GELU, Dropout, dense, Dropout (GE:184-192)
-            m1 = tape.dropout(tape.axis_linear(n1, P(p + "0.fn.0.weight"), P(p + "0.fn.0.bias"), act=ops.ACT_GELU),
-                              self._drop(310 + 4 * k, gp))
-            m2 = tape.dropout(tape.axis_linear(m1, P(p + "0.fn.3.weight"), P(p + "0.fn.3.bias")), self._drop(311 + 4 * k, gp))
-            z = tape.add(z, m2)
+            # (activation, Dropout and the residual add ride on each product's epilogue: 4 launches per mixer block)
+            m1 = tape.axis_linear(n1, P(p + "0.fn.0.weight"), P(p + "0.fn.0.bias"), act=ops.ACT_GELU, drop=self._drop(310 + 4 * k, gp))
+            z = tape.axis_linear(m1, P(p + "0.fn.3.weight"), P(p + "0.fn.3.bias"), drop=self._drop(311 + 4 * k, gp), resid=z)
             n2 = tape.layernorm(z, P(p + "1.norm.weight"), P(p + "1.norm.bias"))
-            f1 = tape.dropout(tape.linear(n2, P(p + "1.fn.0.weight"), P(p + "1.fn.0.bias"), act=ops.ACT_GELU),
-                              self._drop(312 + 4 * k, gp))
-            f2 = tape.dropout(tape.linear(f1, P(p + "1.fn.3.weight"), P(p + "1.fn.3.bias")), self._drop(313 + 4 * k, gp))
-            z = tape.add(z, f2)
+            f1 = tape.linear(n2, P(p + "1.fn.0.weight"), P(p + "1.fn.0.bias"), act=ops.ACT_GELU, drop=self._drop(312 + 4 * k, gp))
+            z = tape.linear(f1, P(p + "1.fn.3.weight"), P(p + "1.fn.3.bias"), drop=self._drop(313 + 4 * k, gp), resid=z)
         p = "gene_encoder.mlp_mixer."
         z = tape.layernorm(z, P(p + f"{g.depth}.weight"), P(p + f"{g.depth}.bias"))
         z = tape.linear(z, P(p + f"{g.depth + 1}.weight"), P(p + f"{g.depth + 1}.bias"))          # [1, G, D]
@@ -577,15 +574,12 @@ class Engine:
         tape, P = self.tape, self.store.param
         tn = tape.layernorm(c, P(pref + "norm.weight"), P(pref + "norm.bias"))
         kin = tape.add_rows_param(tn, pe)
-        q1 = tape.linear(kin, P(pref + "q_proj.weight"), P(pref + "q_proj.bias"))
         Wq, Wk, Wv, bq, bk, bv = self._mha_in(pref + "self_attn.")
+        q1, k, v = tape.linear_group([(kin, P(pref + "q_proj.weight"), P(pref + "q_proj.bias")), (kin, Wk, bk), (tn, Wv, bv)])
         q = tape.linear(q1, Wq, bq)
-        k = tape.linear(kin, Wk, bk)
-        v = tape.linear(tn, Wv, bv)
         a = tape.token_mha(q, k, v, self.cfg.num_heads)
         o = tape.linear(a, P(pref + "self_attn.out_proj.weight"), P(pref + "self_attn.out_proj.bias"))
-        o = tape.linear(o, P(pref + "output_proj.weight"), P(pref + "output_proj.bias"))
-        return tape.add(c, o)
+        return tape.linear(o, P(pref + "output_proj.weight"), P(pref + "output_proj.bias"), resid=c)
 
     # ------------------------------------------------------------------ injector (A.1)
     def _injector(self, i: int, c: Var, pe: Param, src: torch.Tensor, src_map, hin: torch.Tensor, first: bool):
@@ -599,8 +593,7 @@ class Engine:
         # token side: k, v from LN_kq(c) + pe (AM:218,227)
         chat = tape.layernorm(c, P(ap + "norm_kq.weight"), P(ap + "norm_kq.bias"), add_rows=pe)
         _, Wk, Wv, _, bk, bv = self._mha_in(ap + "multihead_attn.")
-        k = tape.linear(chat, Wk, bk)
-        v = tape.linear(chat, Wv, bv)
+        k, v = tape.linear_group([(chat, Wk, bk), (chat, Wv, bv)])
         # patch side
         xhat = torch.empty(Mp, D, dtype=H16, device=dev)
         st = torch.empty(Mp, 2, dtype=F32, device=dev)
@@ -760,8 +753,8 @@ class Engine:
                               dw=g[ap + "norm_kq.weight"], db=g[ap + "norm_kq.bias"])
         tape.record(bwd_core)
         o = tape.linear(out, P(ap + "multihead_attn.out_proj.weight"), P(ap + "multihead_attn.out_proj.bias"))
-        attn_out = tape.linear(o, P(ap + "output_proj.weight"), P(ap + "output_proj.bias"))
-        c1 = tape.add(c, tape.add(c, attn_out))         # query + (tgt + output_proj(.)) (AM:231,324)
+        attn_out = tape.linear(o, P(ap + "output_proj.weight"), P(ap + "output_proj.bias"), resid=c)   # tgt + output_proj(.)
+        c1 = tape.add(c, attn_out)                      # query + (tgt + output_proj(.)) (AM:231,324)
         fp = pref + "ffn."
         tn = tape.layernorm(c1, P(fp + "norm.weight"), P(fp + "norm.bias"))
         f = tape.linear(tape.linear(tn, P(fp + "linear1.weight"), P(fp + "linear1.bias"), act=ops.ACT_RELU),

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import MtDilatedPlan, MtDropout, MtGemmEpilogue, MtRowMap, check, rowmap
+from ._lib import MT_SGEMM_MAX, MtDilatedPlan, MtDropout, MtGemmEpilogue, MtRowMap, MtSgemm, check, rowmap
 
 F16, F32 = 0, 1
 EPI_BIAS, EPI_BIAS_RESID, EPI_INJECT, EPI_POSEMB, EPI_QKV_HM = 0, 1, 2, 3, 4
@@ -92,12 +92,37 @@ def colsum(A, out, M, N, *, lda=None, amap=None):
     check(_lib.load().mt_colsum_f16(_p(A), lda if lda is not None else N, _rm(amap), M, N, _p(out), _s()), "colsum")
 
 
-def sgemm(A, a_str, B, b_str, Cm, c_str, M, N, K, *, bias=None, bias_on_m=False, act=ACT_NONE, accumulate=False,
-          batch=1, a_bs=0, b_bs=0, c_bs=0, rowsum=None):
-    """C(m,n) = act(sum_k A(m,k) B(n,k) + bias) with explicit (row, col) element strides; rowsum[m] += sum_k A(m,k)."""
-    check(_lib.load().mt_sgemm_small(_p(A), a_str[0], a_str[1], a_bs, _p(B), b_str[0], b_str[1], b_bs, _p(bias),
-                                     int(bias_on_m), _p(Cm), c_str[0], c_str[1], c_bs, M, N, K, batch, act,
-                                     int(accumulate), _p(rowsum), _s()), "sgemm_small")
+def sgemm_problem(A, a_str, B, b_str, Cm, c_str, M, N, K, *, bias=None, bias_on_m=False, act=ACT_NONE, accumulate=False,
+                  batch=1, a_bs=0, b_bs=0, c_bs=0, rowsum=None, pre_out=None, resid=None, c_drop=None, a_aux=None,
+                  a_act=ACT_NONE, a_drop=None) -> MtSgemm:
+    """One product of an mt_sgemm_multi launch (include/modaltune_hip.h: MtSgemm).  The tensors must outlive the launch."""
+    q = MtSgemm()
+    q.A, q.as0, q.as1, q.a_bs = _p(A), a_str[0], a_str[1], a_bs
+    q.B, q.bs0, q.bs1, q.b_bs = _p(B), b_str[0], b_str[1], b_bs
+    q.bias, q.bias_on_m = _p(bias), int(bias_on_m)
+    q.C, q.cs0, q.cs1, q.c_bs = _p(Cm), c_str[0], c_str[1], c_bs
+    q.M, q.N, q.K, q.batch, q.act, q.accumulate = M, N, K, batch, act, int(accumulate)
+    q.rowsum, q.pre_out, q.resid = _p(rowsum), _p(pre_out), _p(resid)
+    if c_drop is not None:
+        q.c_drop = c_drop
+    q.a_aux, q.a_act = _p(a_aux), a_act
+    if a_drop is not None:
+        q.a_drop = a_drop
+    return q
+
+
+def sgemm_multi(problems):
+    """Up to MT_SGEMM_MAX independent small products in one launch (more are split over launches, in order)."""
+    for i in range(0, len(problems), MT_SGEMM_MAX):
+        chunk = problems[i:i + MT_SGEMM_MAX]
+        arr = (MtSgemm * len(chunk))(*chunk)
+        check(_lib.load().mt_sgemm_multi(arr, len(chunk), _s()), "sgemm_multi")
+
+
+def sgemm(A, a_str, B, b_str, Cm, c_str, M, N, K, **k):
+    """C(m,n) = act(sum_k A(m,k) B(n,k) + bias) with explicit (row, col) element strides; rowsum[m] += sum_k A(m,k).
+    Keyword arguments as in sgemm_problem (the fused nn.Linear forward / backward forms included)."""
+    sgemm_multi([sgemm_problem(A, a_str, B, b_str, Cm, c_str, M, N, K, **k)])
 
 
 def layernorm_fwd(x, w, b, y, stats, M, D, *, ldx=None, xmap=None, ldy=None, ymap=None, gelu_in=False, add_rows=None,
@@ -345,7 +370,7 @@ extract_attn_bwd = _timed(lambda *a, **k: "extract_attn_bwd")(extract_attn_bwd)
 inject_resid_bwd = _timed(lambda *a, **k: "inject_resid_bwd")(inject_resid_bwd)
 colsum = _timed(lambda *a, **k: "colsum")(colsum)
 _DETAIL = bool(os.environ.get("MT_TIMER_DETAIL"))
-sgemm = _timed(lambda A, a_str, B, b_str, Cm, c_str, M, N, K, **k: (f"sgemm[{M}x{N}x{K} b{k.get('batch', 1)}]" if _DETAIL else "token_side"))(sgemm)
+sgemm_multi = _timed(lambda problems: ("sgemm[" + "+".join(f"{q.M}x{q.N}x{q.K}b{q.batch}" for q in problems) + "]" if _DETAIL else "token_side"))(sgemm_multi)
 adamw_step = _timed(lambda *a, **k: "adamw")(adamw_step)
 
 

@@ -109,35 +109,55 @@ class Tape:
         return torch.empty(*shape, device=self.device, dtype=torch.float32)
 
     # ------------------------------------------------------------------ ops
-    def linear(self, x: Var, W: Param, b: Optional[Param], act: int = ops.ACT_NONE) -> Var:
-        """y = act(x @ W^T + b) over the last dim (nn.Linear)."""
+    def _take_residual_grad(self, resid: Optional[Var], y: Var):
+        """d resid += dy of y = resid + f(.): dy is dead after the closure that calls this, so the first contribution
+        simply becomes resid's gradient (the launches that read dy are already queued ahead of any later writer)."""
+        if resid is not None and resid.needs_grad:
+            resid.acc(y.grad)
+
+    def linear(self, x: Var, W: Param, b: Optional[Param], act: int = ops.ACT_NONE, drop=None, resid: Optional[Var] = None) -> Var:
+        """y = [resid +] Dropout(act(x @ W^T + b)) over the last dim: nn.Linear with the activation, the nn.Dropout that
+        follows it and the residual add on the GEMM's epilogue (one launch); the backward applies the mask and act' to dy
+        as the dX and dW products load it, and both products share a launch (mt_sgemm_multi)."""
+        return self.linear_group([(x, W, b)], act=act, drop=drop, resid=resid)[0]
+
+    def linear_group(self, items, act: int = ops.ACT_NONE, drop=None, resid: Optional[Var] = None) -> List[Var]:
+        """Independent nn.Linear modules [(x, W, b), ...] (sibling projections: q | k | v of one normed input) whose forward
+        products share launches; each keeps its own backward closure."""
+        probs, outs = [], []
+        for x, W, b in items:
+            K, N, R = x.cols, W.data.shape[0], x.rows
+            y = Var(self.new(*x.data.shape[:-1], N))
+            pre = self.new(*y.data.shape) if act != ops.ACT_NONE else None
+            probs.append(ops.sgemm_problem(x.data, (K, 1), W.data, (K, 1), y.data, (N, 1), R, N, K, bias=None if b is None else b.data,
+                                           act=act, pre_out=pre, c_drop=drop, resid=None if resid is None else resid.data))
+            self.record(self._linear_bwd(x, W, b, y, pre, act, drop, resid))
+            outs.append(y)
+        ops.sgemm_multi(probs)
+        return outs
+
+    def _linear_bwd(self, x: Var, W: Param, b: Optional[Param], y: Var, pre, act: int, drop, resid: Optional[Var]):
         K, N, R = x.cols, W.data.shape[0], x.rows
-        pre = self.new(*x.data.shape[:-1], N)
-        ops.sgemm(x.data, (K, 1), W.data, (K, 1), pre, (N, 1), R, N, K, bias=None if b is None else b.data)
-        if act != ops.ACT_NONE:
-            y = Var(self.new(*pre.shape))
-            ops.act_fwd(pre, y.data, act)
-        else:
-            y = Var(pre)
 
         def bwd():
             if y.grad is None:
                 return
             dy = y.grad
-            if act != ops.ACT_NONE:
-                dpre = self.new(*pre.shape)
-                ops.act_bwd(pre, dy, dpre, act)
-                dy = dpre
-            if x.needs_grad:   # dx += dy @ W
-                ops.sgemm(dy, (N, 1), W.data, (1, K), x.g(), (K, 1), R, K, N, accumulate=True)
+            fuse = dict(a_aux=pre, a_act=act, a_drop=drop)       # dpre = mask(dy) * act'(pre), formed at the operand load
+            probs = []
+            if x.needs_grad:   # dx += dpre @ W
+                probs.append(ops.sgemm_problem(dy, (N, 1), W.data, (1, K), x.g(), (K, 1), R, K, N, accumulate=True, **fuse))
             want_db = b is not None and b.grad is not None
-            if W.grad is not None:   # dW += dy^T @ x ; the bias gradient (row sums of dy^T) rides on the same launch
-                ops.sgemm(dy, (1, N), x.data, (1, K), W.grad, (K, 1), N, K, R, accumulate=True,
-                          rowsum=b.grad if want_db else None)
+            if W.grad is not None:   # dW += dpre^T @ x ; the bias gradient (row sums of dpre^T) rides on the same product
+                probs.append(ops.sgemm_problem(dy, (1, N), x.data, (1, K), W.grad, (K, 1), N, K, R, accumulate=True,
+                                               rowsum=b.grad if want_db else None, **fuse))
             elif want_db:
-                self._colsum(dy, R, N, b.grad)
-        self.record(bwd)
-        return y
+                assert R <= self._ones.numel()
+                probs.append(ops.sgemm_problem(dy, (1, N), self._ones, (0, 1), b.grad, (1, 1), N, 1, R, accumulate=True, **fuse))
+            if probs:
+                ops.sgemm_multi(probs)
+            self._take_residual_grad(resid, y)
+        return bwd
 
     def dropout(self, x: Var, spec) -> Var:
         """y = Dropout(x) with a counter-based mask (ops.dropout_spec); spec None = identity.  x dense [..., D], D % 4 == 0."""
@@ -156,42 +176,34 @@ class Tape:
         self.record(bwd)
         return y
 
-    def _colsum(self, dy, R, N, out):
-        assert R <= self._ones.numel()
-        ops.sgemm(dy, (1, N), self._ones, (0, 1), out, (1, 1), N, 1, R, accumulate=True)
-
-    def axis_linear(self, x: Var, W: Param, b: Param, act: int = ops.ACT_NONE) -> Var:
-        """y[b, go, c] = act(sum_g W[go, g] x[b, g, c] + bias[go]): Conv1d(kernel 1) over the group axis
-        (gene_encoder.py:140-158) and pathway_compression (gene_encoder.py:212)."""
+    def axis_linear(self, x: Var, W: Param, b: Param, act: int = ops.ACT_NONE, drop=None, resid: Optional[Var] = None) -> Var:
+        """y[b, go, c] = [resid +] Dropout(act(sum_g W[go, g] x[b, g, c] + bias[go])): Conv1d(kernel 1) over the group axis
+        (gene_encoder.py:140-158) and pathway_compression (gene_encoder.py:212); fused like `linear`."""
         Bb, G, Cc = x.data.shape
         assert Bb == 1, "the gene encoder runs once per slide (shared by the task passes)"
         Go = W.data.shape[0]
         Wm = W.data.view(Go, G)
-        pre = self.new(Bb, Go, Cc)
-        ops.sgemm(Wm, (G, 1), x.data, (1, Cc), pre, (Cc, 1), Go, Cc, G, bias=b.data, bias_on_m=True, batch=Bb,
-                  b_bs=G * Cc, c_bs=Go * Cc)
-        if act != ops.ACT_NONE:
-            y = Var(self.new(Bb, Go, Cc))
-            ops.act_fwd(pre, y.data, act)
-        else:
-            y = Var(pre)
+        y = Var(self.new(Bb, Go, Cc))
+        pre = self.new(Bb, Go, Cc) if act != ops.ACT_NONE else None
+        ops.sgemm(Wm, (G, 1), x.data, (1, Cc), y.data, (Cc, 1), Go, Cc, G, bias=b.data, bias_on_m=True, act=act, pre_out=pre,
+                  c_drop=drop, resid=None if resid is None else resid.data)
 
         def bwd():
             if y.grad is None:
                 return
-            dy = y.grad
-            if act != ops.ACT_NONE:
-                dpre = self.new(Bb, Go, Cc)
-                ops.act_bwd(pre, dy, dpre, act)
-                dy = dpre
-            if x.needs_grad:   # dx[b,g,c] += sum_go W[go,g] dy[b,go,c]
-                ops.sgemm(Wm, (1, G), dy, (1, Cc), x.g(), (Cc, 1), G, Cc, Go, accumulate=True, batch=Bb,
-                          b_bs=Go * Cc, c_bs=G * Cc)
-            if W.grad is not None:   # dW[go,g] += sum_{b,c} dy[b,go,c] x[b,g,c]
-                for bi in range(Bb):
-                    ops.sgemm(dy[bi], (Cc, 1), x.data[bi], (Cc, 1), W.grad.view(Go, G), (G, 1), Go, G, Cc, accumulate=True)
-            if b.grad is not None:   # db[go] += sum_{b,c} dy
-                ops.sgemm(dy.view(Go, Cc), (Cc, 1), self._ones, (0, 1), b.grad, (1, 1), Go, 1, Cc, accumulate=True)
+            dy = y.grad.view(Go, Cc)
+            fuse = dict(a_aux=pre, a_act=act, a_drop=drop)
+            probs = []
+            if x.needs_grad:   # dx[g, c] += sum_go dpre[go, c] W[go, g], written as (dpre^T W)[c, g] so that dy is the A operand
+                probs.append(ops.sgemm_problem(dy, (1, Cc), Wm, (1, G), x.g(), (1, Cc), Cc, G, Go, accumulate=True, **fuse))
+            if W.grad is not None:   # dW[go, g] += sum_c dpre[go, c] x[g, c];  db[go] += sum_c dpre[go, c] on the same product
+                probs.append(ops.sgemm_problem(dy, (Cc, 1), x.data.view(G, Cc), (Cc, 1), W.grad.view(Go, G), (G, 1), Go, G, Cc,
+                                               accumulate=True, rowsum=b.grad, **fuse))
+            elif b.grad is not None:
+                probs.append(ops.sgemm_problem(dy, (Cc, 1), self._ones, (0, 1), b.grad, (1, 1), Go, 1, Cc, accumulate=True, **fuse))
+            if probs:
+                ops.sgemm_multi(probs)
+            self._take_residual_grad(resid, y)
         self.record(bwd)
         return y
 

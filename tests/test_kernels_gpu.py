@@ -179,6 +179,89 @@ def test_sgemm_small(ops):
     assert rel(db, db0.double() + dy.double().sum(0)) < 1e-5
 
 
+def _mask(ops, spec, shape):
+    """The element-dropout scale factors of a dense tensor, read back from the standalone dropout kernel."""
+    ones = torch.ones(shape, device=DEV)
+    m = torch.empty_like(ones)
+    R, D = int(np.prod(shape[:-1])), shape[-1]
+    ops.dropout_f32(ones, m, R, D, spec)
+    return m
+
+
+@pytest.mark.parametrize("act", ["none", "gelu", "relu", "elu"])
+@pytest.mark.parametrize("R,N,K", [(195, 192, 768), (66, 768, 192), (6, 256, 128), (33, 52, 76)])
+def test_sgemm_fused_linear_forward_and_backward(ops, act, R, N, K):
+    """nn.Linear + activation + Dropout + residual on one launch, and its backward (mask and act' applied to dy at the operand
+    load, dX and dW (+ db) products in ONE mt_sgemm_multi launch) against fp64 torch autograd with the same mask."""
+    code = {"none": ops.ACT_NONE, "gelu": ops.ACT_GELU, "relu": ops.ACT_RELU, "elu": ops.ACT_ELU}[act]
+    g = rng(R * 7 + N + K + code)
+    x, W, b = torch.randn(R, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    res, dy = torch.randn(R, N, generator=g), torch.randn(R, N, generator=g)
+    rngbuf = torch.tensor([11, 0, 5, 0], dtype=torch.int32, device=DEV)
+    spec = ops.dropout_spec(rngbuf, site=321, p=0.25) if N % 4 == 0 else None     # (the standalone mask kernel wants D % 4 == 0)
+    mask = _mask(ops, spec, (R, N)).double().cpu() if spec is not None else torch.ones(R, N, dtype=torch.float64)
+    xd, Wd, bd, resd, dyd = (t.to(DEV) for t in (x, W, b, res, dy))
+    y = torch.full((R, N), float("nan"), device=DEV)
+    pre = torch.full((R, N), float("nan"), device=DEV)
+    ops.sgemm(xd, (K, 1), Wd, (K, 1), y, (N, 1), R, N, K, bias=bd, act=code, pre_out=pre, c_drop=spec, resid=resd)
+    x64, W64, b64 = (t.double().requires_grad_(True) for t in (x, W, b))
+    pre64 = x64 @ W64.t() + b64
+    f = {"none": lambda t: t, "gelu": torch.nn.functional.gelu, "relu": torch.relu, "elu": torch.nn.functional.elu}[act]
+    y64 = res.double() + f(pre64) * mask
+    torch.cuda.synchronize()
+    assert rel(pre, pre64) < 1e-5 and rel(y, y64) < 1e-5
+    y64.backward(dy.double())
+    dx = torch.randn(R, K, generator=g)
+    dW0, db0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    dxd, dWd, dbd = dx.to(DEV).clone(), dW0.to(DEV).clone(), db0.to(DEV).clone()
+    fuse = dict(a_aux=pre if code != ops.ACT_NONE else None, a_act=code, a_drop=spec)
+    ops.sgemm_multi([ops.sgemm_problem(dyd, (N, 1), Wd, (1, K), dxd, (K, 1), R, K, N, accumulate=True, **fuse),
+                     ops.sgemm_problem(dyd, (1, N), xd, (1, K), dWd, (K, 1), N, K, R, accumulate=True, rowsum=dbd, **fuse)])
+    torch.cuda.synchronize()
+    assert rel(dxd, dx.double() + x64.grad) < 1e-5
+    assert rel(dWd, dW0.double() + W64.grad) < 1e-5
+    assert rel(dbd, db0.double() + b64.grad) < 1e-5
+
+
+def test_sgemm_multi_three_products_and_group_axis_form(ops):
+    """Three unrelated products (different shapes, layouts, batch) in one launch land where three launches put them; the
+    group-axis (Conv1d kernel 1) backward with dy as the strided A operand keeps the mask / act' indexing of the dense dy."""
+    g = rng(77)
+    shapes = [(65, 50, 77, 1), (16, 256, 6, 1), (20, 33, 40, 3)]
+    probs, refs, outs = [], [], []
+    keep = []
+    for M, N, K, Bt in shapes:
+        A, Bm = torch.randn(Bt, M, K, generator=g), torch.randn(Bt, N, K, generator=g)
+        out = torch.full((Bt, M, N), float("nan"), device=DEV)
+        Ad, Bd = A.to(DEV), Bm.to(DEV)
+        keep += [Ad, Bd]
+        probs.append(ops.sgemm_problem(Ad, (K, 1), Bd, (K, 1), out, (N, 1), M, N, K, batch=Bt, a_bs=M * K, b_bs=N * K, c_bs=M * N))
+        refs.append(A.double() @ Bm.double().transpose(1, 2)); outs.append(out)
+    ops.sgemm_multi(probs)
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert rel(o, r) < 1e-5
+    # y[go, c] = drop(gelu(sum_g W[go, g] x[g, c] + b[go]));  dx[g, c] = sum_go dpre[go, c] W[go, g] with A = dy^T (strides (1, Cc))
+    Go, G, Cc = 12, 6, 256
+    W, x, b, dy = (torch.randn(*sh, generator=g) for sh in ((Go, G), (G, Cc), (Go,), (Go, Cc)))
+    rngbuf = torch.tensor([3, 0, 9, 0], dtype=torch.int32, device=DEV)
+    spec = ops.dropout_spec(rngbuf, site=77, p=0.3)
+    mask = _mask(ops, spec, (Go, Cc)).double().cpu()
+    Wd, xd, bd, dyd = (t.to(DEV) for t in (W, x, b, dy))
+    y, pre = torch.empty(Go, Cc, device=DEV), torch.empty(Go, Cc, device=DEV)
+    ops.sgemm(Wd, (G, 1), xd, (1, Cc), y, (Cc, 1), Go, Cc, G, bias=bd, bias_on_m=True, act=ops.ACT_GELU, pre_out=pre, c_drop=spec)
+    W64, x64, b64 = (t.double().requires_grad_(True) for t in (W, x, b))
+    y64 = torch.nn.functional.gelu(W64 @ x64 + b64[:, None]) * mask
+    y64.backward(dy.double())
+    dxd, dWd, dbd = torch.zeros(G, Cc, device=DEV), torch.zeros(Go, G, device=DEV), torch.zeros(Go, device=DEV)
+    fuse = dict(a_aux=pre, a_act=ops.ACT_GELU, a_drop=spec)
+    ops.sgemm_multi([ops.sgemm_problem(dyd, (1, Cc), Wd, (1, G), dxd, (1, Cc), Cc, G, Go, accumulate=True, **fuse),
+                     ops.sgemm_problem(dyd, (Cc, 1), xd, (Cc, 1), dWd, (G, 1), Go, G, Cc, accumulate=True, rowsum=dbd, **fuse)])
+    torch.cuda.synchronize()
+    assert rel(y, y64) < 1e-5
+    assert rel(dxd, x64.grad) < 1e-5 and rel(dWd, W64.grad) < 1e-5 and rel(dbd, b64.grad) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(195, 192, 768), (195, 768, 192), (192, 768, 195), (6, 3, 256), (3, 256, 6), (1, 4992, 3),
                                    (17, 33, 1), (64, 64, 64), (16, 16, 1024), (195, 192, 200)])
 @pytest.mark.parametrize("layout", ["nt", "tn", "nn"])
