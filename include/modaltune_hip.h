@@ -93,9 +93,10 @@ int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_ha
                    mt_stream_t stream);
 
 /* C[N1,N2] (fp32) += sum_m A[m,N1] * B[m,N2] over M rows (split over workgroups, fp32 atomics): the weight
- * gradient of a big-M nn.Linear (autograd of AM:154-164 etc.).  N1 % 64 == 0, N2 % 64 == 0. */
+ * gradient of a big-M nn.Linear (autograd of AM:154-164 etc.).  N1 % 64 == 0, N2 % 64 == 0.
+ * colsum (fp32 [N1], or NULL): colsum[n] += sum_m A[m,n] on the same pass -- the bias gradient of that nn.Linear. */
 int mt_gemm_tn_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* B, long ldb, const MtRowMap* bmap,
-                   int M, int N1, int N2, float* C, long ldc, mt_stream_t stream);
+                   int M, int N1, int N2, float* C, long ldc, float* colsum, mt_stream_t stream);
 
 /* out[n] (fp32) += sum_m A[m,n]: bias gradient of a big-M nn.Linear.  N % 8 == 0, lda % 8 == 0 (16-byte loads). */
 int mt_colsum_f16(const mt_half* A, long lda, const MtRowMap* amap, int M, int N, float* out, mt_stream_t stream);

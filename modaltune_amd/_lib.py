@@ -58,7 +58,7 @@ SIGNATURES = {
     "mt_version": [],
     "mt_status_string": [I],
     "mt_gemm_nt_f16": [P, L, RM, P, I, I, I, I, EP, P, L, RM, I, P],
-    "mt_gemm_tn_f16": [P, L, RM, P, L, RM, I, I, I, P, L, P],
+    "mt_gemm_tn_f16": [P, L, RM, P, L, RM, I, I, I, P, L, P, P],
     "mt_colsum_f16": [P, L, RM, I, I, P, P],
     "mt_sgemm_small": [P, L, L, L, P, L, L, L, P, I, P, L, L, L, I, I, I, I, I, I, P, P],
     "mt_sgemm_multi": [C.POINTER(MtSgemm), I, P],

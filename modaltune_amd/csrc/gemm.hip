@@ -483,12 +483,15 @@ int launch_nt_bn(const GemmNtArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_tn: C[N1,N2] += sum_m A[m,n1] B[m,n2].  64x64 output tile per workgroup, 32 rows of m per step,
-// split over M (grid.z) with fp32 atomics.  Both operands are "k-strided" in memory, so the tiles are staged
-// as they lie ([m][n]) and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transposed read).
+// gemm_tn: C[N1,N2] += sum_m A[m,n1] B[m,n2]  (+ colsum[n1] += sum_m A[m,n1], the bias gradient, on the same pass).
+// TM x TN output tile per workgroup (64 / 128 / 192 on each side: the adapter's 192 / 384 / 768 divide exactly), 32 rows of m
+// per step, split over M with fp32 atomics.  Both operands are "k-strided" in memory, so the tiles are staged as they lie
+// ([m][n]) and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transposed read).
+// What bounds it at M = 30 000 is traffic, not the 9-18 GFLOP: the M-split's atomics (split x N1 x N2 x 4 bytes at the
+// ~1.3 TB/s memory-side atomic rate), the operand re-reads (A: N2 / TN times, B: N1 / TM times) and how many DISTINCT bytes
+// are in flight (tools/experiments/README.md, round 2).  Workgroup id -> (XCD = id % 8, slot = id / 8): the tiles of one row
+// range run on one XCD and share its L2, which is worth 20-30 % over the tile-major order at every shape of the step.
 // ------------------------------------------------------------------------------------------------
-constexpr int TN_STRIDE = 72;   // halves per LDS row: 64 + 8 (144 B; 8-byte aligned tr reads, 16-B aligned writes)
-
 MT_DEVINL h16x4 lds_tr4(const h16* p) {
   s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)p);
@@ -500,40 +503,76 @@ struct GemmTnArgs {
   const h16* B; long ldb; RowMap bmap;
   int M, N1, N2, rows_per_split;
   float* C; long ldc;
+  float* colsum;      // optional [N1]
 };
 
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
-  __shared__ __attribute__((aligned(16))) h16 As[2][32 * TN_STRIDE];
-  __shared__ __attribute__((aligned(16))) h16 Bs[2][32 * TN_STRIDE];
+  constexpr int SA = TM + 8, SB = TN + 8;       // halves per LDS row (+16 B: 8-byte aligned tr reads, 16-B aligned writes)
+  constexpr int CA = TM / 64, CB = TN / 64;     // 16-byte chunks per thread per step (32 rows x T/8 chunks over 256 threads)
+  constexpr int MI = TM / 32, NI = TN / 32;     // 16 x 16 MFMA tiles per wave (wave tile TM/2 x TN/2)
+  __shared__ __attribute__((aligned(16))) h16 As[2][32 * SA];
+  __shared__ __attribute__((aligned(16))) h16 Bs[2][32 * SB];
+  __shared__ float csum[TM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;      // wave tile 32(n1) x 32(n2)
-  const int n1_0 = blockIdx.x * 64, n2_0 = blockIdx.y * 64;
-  const int mbeg = blockIdx.z * g.rows_per_split;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_x = g.N1 / TM, tiles = tiles_x * (g.N2 / TN);
+  const int slot = blockIdx.x >> 3, tile = slot % tiles, split_id = (slot / tiles) * 8 + (blockIdx.x & 7);
+  const int n1_0 = (tile % tiles_x) * TM, n2_0 = (tile / tiles_x) * TN;
+  const int mbeg = split_id * g.rows_per_split;
   const int mend = min(g.M, mbeg + g.rows_per_split);
   if (mbeg >= mend) return;
-  // staging: tile 32 rows x 64 cols = 256 chunks of 16 B: one chunk per thread per operand
-  const int srow = tid >> 3, skc = tid & 7;
-  h16x8 ra, rb;
+  const bool want_cs = g.colsum != nullptr && n2_0 == 0;
+  // staging: chunk c = i * 256 + tid of a 32-row tile: row c / (T / 8), chunk column c % (T / 8)
+  h16x8 ra[CA], rb[CB];
+  float cs[CA][8];
+#pragma unroll
+  for (int i = 0; i < CA; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[i][e] = 0.f;
   const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   auto gload = [&](int mt) {      // branch-free: clamp the row, select zero past the end of the split
-    const int m = mt + srow, mc = min(m, mend - 1);
-    const h16x8 a = ldg8(g.A + g.amap.map(mc) * g.lda + n1_0 + skc * 8);
-    const h16x8 b = ldg8(g.B + g.bmap.map(mc) * g.ldb + n2_0 + skc * 8);
-    ra = m < mend ? a : zero; rb = m < mend ? b : zero;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int c = i * 256 + tid, row = c / (TM / 8), kc = c % (TM / 8);
+      const int m = mt + row, mc = min(m, mend - 1);
+      const h16x8 a = ldg8(g.A + g.amap.map(mc) * g.lda + n1_0 + kc * 8);
+      ra[i] = m < mend ? a : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int c = i * 256 + tid, row = c / (TN / 8), kc = c % (TN / 8);
+      const int m = mt + row, mc = min(m, mend - 1);
+      const h16x8 b = ldg8(g.B + g.bmap.map(mc) * g.ldb + n2_0 + kc * 8);
+      rb[i] = m < mend ? b : zero;
+    }
   };
   auto lstore = [&](int buf) {
-    *reinterpret_cast<h16x8*>(&As[buf][srow * TN_STRIDE + skc * 8]) = ra;
-    *reinterpret_cast<h16x8*>(&Bs[buf][srow * TN_STRIDE + skc * 8]) = rb;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int c = i * 256 + tid, row = c / (TM / 8), kc = c % (TM / 8);
+      *reinterpret_cast<h16x8*>(&As[buf][row * SA + kc * 8]) = ra[i];
+      if (want_cs) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[i][e] += (float)ra[i][e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int c = i * 256 + tid, row = c / (TN / 8), kc = c % (TN / 8);
+      *reinterpret_cast<h16x8*>(&Bs[buf][row * SB + kc * 8]) = rb[i];
+    }
   };
-  f32x4 acc[2][2];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nt = (mend - mbeg + 31) / 32;
   gload(mbeg);
   lstore(0);
+  if (tid < TM) csum[tid] = 0.f;
   __syncthreads();
   // transposed-read addressing (T10): 16-lane group grp covers k rows 8*grp + {0..3} (+4 for the second read);
   // lane 4q+p of the group supplies the address of row q, columns 4p..4p+3 of the 16-column block.
@@ -541,36 +580,49 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) gload(mbeg + (t + 1) * 32);
-    h16x8 af[2], bf[2];
+    h16x8 af[MI], bf[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const h16* pa = &As[buf][(8 * grp + tq) * TN_STRIDE + wm * 32 + i * 16 + 4 * tp];
-      h16x4 lo = lds_tr4(pa), hi = lds_tr4(pa + 4 * TN_STRIDE);
+    for (int i = 0; i < MI; ++i) {
+      const h16* pa = &As[buf][(8 * grp + tq) * SA + wm * (TM / 2) + i * 16 + 4 * tp];
+      const h16x4 lo = lds_tr4(pa), hi = lds_tr4(pa + 4 * SA);
       af[i] = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      const h16* pb = &Bs[buf][(8 * grp + tq) * TN_STRIDE + wn * 32 + i * 16 + 4 * tp];
-      lo = lds_tr4(pb); hi = lds_tr4(pb + 4 * TN_STRIDE);
-      bf[i] = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NI; ++j) {
+      const h16* pb = &Bs[buf][(8 * grp + tq) * SB + wn * (TN / 2) + j * 16 + 4 * tp];
+      const h16x4 lo = lds_tr4(pb), hi = lds_tr4(pb + 4 * SB);
+      bf[j] = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     if (t + 1 < nt) lstore(buf ^ 1);
     __syncthreads();
   }
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n1 = n1_0 + wm * 32 + i * 16 + fq * 4 + r;
+      const int n1 = n1_0 + wm * (TM / 2) + i * 16 + fq * 4 + r;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n2 = n2_0 + wn * 32 + j * 16 + fr;
+      for (int j = 0; j < NI; ++j) {
+        const int n2 = n2_0 + wn * (TN / 2) + j * 16 + fr;
         atomicAdd(&g.C[(long)n1 * g.ldc + n2], acc[i][j][r]);
       }
     }
+  if (want_cs) {      // the threads of one chunk column hold partial sums over their rows: meet in LDS, one global atomic per column
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int kc = (i * 256 + tid) % (TM / 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&csum[kc * 8 + e], cs[i][e]);
+    }
+    __syncthreads();
+    if (tid < TM) atomicAdd(&g.colsum[n1_0 + tid], csum[tid]);
+  }
 }
 
 // block = 32 column groups of 8 (16-byte loads) x 8 row lanes over a slab of rows; one atomic per column per block
@@ -828,17 +880,21 @@ extern "C" int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, 
 }
 
 extern "C" int mt_gemm_tn_f16(const mt_half* A, long lda, const MtRowMap* amap, const mt_half* B, long ldb,
-                              const MtRowMap* bmap, int M, int N1, int N2, float* C, long ldc, mt_stream_t stream) {
+                              const MtRowMap* bmap, int M, int N1, int N2, float* C, long ldc, float* colsum,
+                              mt_stream_t stream) {
   if (!A || !B || !C || M <= 0 || N1 % 64 || N2 % 64 || lda % 8 || ldb % 8) return MT_ERR_BAD_ARG;
   GemmTnArgs g;
   g.A = (const h16*)A; g.lda = lda; g.amap = make_rowmap(amap);
   g.B = (const h16*)B; g.ldb = ldb; g.bmap = make_rowmap(bmap);
-  g.M = M; g.N1 = N1; g.N2 = N2; g.C = C; g.ldc = ldc;
+  g.M = M; g.N1 = N1; g.N2 = N2; g.C = C; g.ldc = ldc; g.colsum = colsum;
+  // 64 x 64 tiles and ~1024 workgroups (512 for the small products) measured best at M = 30 000 once the tiles of a row range
+  // share an XCD (tools/experiments/tn_sweep.sh: 63 / 39 / 39 / 19 us for 384x768 / 192x768 / 768x192 / 192x192; the larger
+  // tiles the kernel template allows re-read less but need more splits -- more atomics -- for the same number of workgroups)
   const int tiles = (N1 / 64) * (N2 / 64);
-  int split = max(1, min(cdiv(M, 256), cdiv(2048, tiles)));   // ~2k workgroups, >= 256 rows each
+  int split = max(1, min(cdiv(M, 256), cdiv(tiles >= 16 ? 1024 : 512, tiles)));
+  split = cdiv(split, 8) * 8;                                   // a multiple of the 8 XCDs
   g.rows_per_split = cdiv(cdiv(M, split), 32) * 32;
-  split = cdiv(M, g.rows_per_split);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(N1 / 64, N2 / 64, split), dim3(256), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), dim3(tiles * split), dim3(256), 0, (hipStream_t)stream, g);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -621,22 +621,18 @@ class Engine:
             # residual path: dh_patch <- (1+gamma) dh_patch (in place; block 0's input x0 needs no gradient)
             ops.inject_resid_bwd(dh, src, proj, t[pref + "gamma"], dh if not first else ws["scratch32"], dproj,
                                  g[pref + "gamma"], Mp, D, dymap=pm, xmap=src_map, dxmap=pm if not first else None)
-            ops.gemm_tn(dproj, o1, g[ap + "output_proj.weight"], Mp, D, E)
-            ops.colsum(dproj, g[ap + "output_proj.bias"], Mp, D)
+            ops.gemm_tn(dproj, o1, g[ap + "output_proj.weight"], Mp, D, E, colsum=g[ap + "output_proj.bias"])
             do1 = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.gemm_nt(dproj, w16[ap + "output_proj"].wt, do1, Mp, E, D)
-            ops.gemm_tn(do1, a, g[ap + "multihead_attn.out_proj.weight"], Mp, E, E)
-            ops.colsum(do1, g[ap + "multihead_attn.out_proj.bias"], Mp, E)
+            ops.gemm_tn(do1, a, g[ap + "multihead_attn.out_proj.weight"], Mp, E, E, colsum=g[ap + "multihead_attn.out_proj.bias"])
             da = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.gemm_nt(do1, w16[ap + "out_in"].wt, da, Mp, E, E)
             dq2 = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.inject_attn_bwd(q2, a, alse, da, k.data, v.data, dq2, k.g(), v.g(), Mp, L, T)
-            ops.gemm_tn(dq2, q1, g[ap + "multihead_attn.q_proj_weight"], Mp, E, E)
-            ops.colsum(dq2, g[ap + "multihead_attn.in_proj_bias"][:E], Mp, E)
+            ops.gemm_tn(dq2, q1, g[ap + "multihead_attn.q_proj_weight"], Mp, E, E, colsum=g[ap + "multihead_attn.in_proj_bias"][:E])
             dq1 = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.gemm_nt(dq2, w16[ap + "q_in"].wt, dq1, Mp, E, E)
-            ops.gemm_tn(dq1, xhat, g[ap + "q_proj.weight"], Mp, E, D)
-            ops.colsum(dq1, g[ap + "q_proj.bias"], Mp, E)
+            ops.gemm_tn(dq1, xhat, g[ap + "q_proj.weight"], Mp, E, D, colsum=g[ap + "q_proj.bias"])
             dxhat = torch.empty(Mp, D, dtype=H16, device=dev)
             ops.gemm_nt(dq1, w16[ap + "q_proj"].wt, dxhat, Mp, D, E)
             if first:
@@ -745,8 +741,8 @@ class Engine:
                 return
             dkv = torch.empty(Mp, 2 * E, dtype=H16, device=dev)
             ops.extract_attn_bwd(q2.data, kv, out.data, lse, out.grad, q2.g(), dkv, B, T, L)
-            ops.gemm_tn(dkv, xk, g[ap + "multihead_attn.k_proj_weight"], Mp, 2 * E, D)       # k | v weights are adjacent
-            ops.colsum(dkv, g[ap + "multihead_attn.in_proj_bias"][E:], Mp, 2 * E)
+            ops.gemm_tn(dkv, xk, g[ap + "multihead_attn.k_proj_weight"], Mp, 2 * E, D,       # k | v weights are adjacent
+                        colsum=g[ap + "multihead_attn.in_proj_bias"][E:])
             dxk = torch.empty(Mp, D, dtype=H16, device=dev)
             ops.gemm_nt(dkv, w16[ap + "kv"].wt, dxk, Mp, D, 2 * E)
             ops.layernorm_bwd(dxk, hout, t[ap + "norm_kq.weight"], st, ws["dh"], Mp, D, xmap=pm, dxmap=pm, accumulate=True,

@@ -82,10 +82,10 @@ def gemm_nt(A, W, out, M, N, K, *, lda=None, amap=None, ldc=None, cmap=None, epi
           "gemm_nt")
 
 
-def gemm_tn(A, B, out, M, N1, N2, *, lda=None, amap=None, ldb=None, bmap=None, ldc=None):
-    """out[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics)."""
+def gemm_tn(A, B, out, M, N1, N2, *, lda=None, amap=None, ldb=None, bmap=None, ldc=None, colsum=None):
+    """out[N1,N2] += A^T B over M rows (weight gradient); colsum[N1] += column sums of A (the bias gradient) on the same pass."""
     check(_lib.load().mt_gemm_tn_f16(_p(A), lda if lda is not None else N1, _rm(amap), _p(B), ldb if ldb is not None else N2,
-                                     _rm(bmap), M, N1, N2, _p(out), ldc if ldc is not None else N2, _s()), "gemm_tn")
+                                     _rm(bmap), M, N1, N2, _p(out), ldc if ldc is not None else N2, _p(colsum), _s()), "gemm_tn")
 
 
 def colsum(A, out, M, N, *, lda=None, amap=None):

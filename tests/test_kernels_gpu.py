@@ -131,17 +131,26 @@ def test_gemm_nt_head_major_qkv_epilogue(ops, M):
     assert rel(out.view(3, 16, M, 48), ref) < 2e-3
 
 
-@pytest.mark.parametrize("M,N1,N2", [(1000, 192, 768), (4097, 64, 64), (333, 384, 768), (9000, 768, 192)])
+@pytest.mark.parametrize("M,N1,N2", [(1000, 192, 768), (4097, 64, 64), (333, 384, 768), (9000, 768, 192), (30003, 192, 192),
+                                     (2050, 384, 192), (700, 64, 192), (515, 320, 448), (31, 128, 64)])
 def test_gemm_tn_and_colsum(ops, M, N1, N2):
+    """Weight gradient A^T B over every tile form (64 / 128 / 192 on each side), accumulating into C, with the bias gradient
+    (column sums of A) riding on the same pass, and the standalone column-sum kernel."""
     g = rng(M)
     A = torch.randn(M, N1, generator=g).half()
     B = torch.randn(M, N2, generator=g).half()
-    out = torch.zeros(N1, N2, device=DEV)
-    ops.gemm_tn(A.to(DEV), B.to(DEV), out, M, N1, N2)
+    C0 = torch.randn(N1, N2, generator=g)
+    b0 = torch.randn(N1, generator=g)
+    out, bsum = C0.to(DEV).clone(), b0.to(DEV).clone()
+    ops.gemm_tn(A.to(DEV), B.to(DEV), out, M, N1, N2, colsum=bsum)
+    out2 = torch.zeros(N1, N2, device=DEV)
+    ops.gemm_tn(A.to(DEV), B.to(DEV), out2, M, N1, N2)
     cs = torch.zeros(N1, device=DEV)
     ops.colsum(A.to(DEV), cs, M, N1)
     torch.cuda.synchronize()
-    assert rel(out, A.double().t() @ B.double()) < 1e-4
+    ref = A.double().t() @ B.double()
+    assert rel(out, C0.double() + ref) < 1e-4 and rel(out2, ref) < 1e-4
+    assert rel(bsum, b0.double() + A.double().sum(0)) < 1e-4
     assert rel(cs, A.double().sum(0)) < 1e-4
 
 
