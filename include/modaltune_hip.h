@@ -174,6 +174,9 @@ typedef struct {
   int ratio[MT_MAX_BRANCHES];         /* dilation r                                  DA:213     */
   int nseg[MT_MAX_BRANCHES];          /* ceil(N / s)                                            */
   int n[MT_MAX_BRANCHES];             /* sparse length ceil(s / r) incl. zero padding DA:22-37  */
+  int qlimit[MT_MAX_BRANCHES];        /* 0, or: only the first qlimit sparse entries of every (segment, head) act as QUERIES
+                                       * (all n act as keys) -- the sequence-parallel form of DA:61-111, where a rank's
+                                       * queries attend over the keys gathered from the ranks of its segment            */
 } MtDilatedPlan;
 
 /* qkv: fp16 HEAD-MAJOR [3][16][B*N][48] (q' | k | v; MT_EPI_QKV_HM writes it).  The q slab holds

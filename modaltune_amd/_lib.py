@@ -45,7 +45,7 @@ MT_MAX_BRANCHES = 8
 
 class MtDilatedPlan(C.Structure):
     _fields_ = [("nbranch", I), ("N", I), ("B", I), ("seg", I * MT_MAX_BRANCHES), ("ratio", I * MT_MAX_BRANCHES),
-                ("nseg", I * MT_MAX_BRANCHES), ("n", I * MT_MAX_BRANCHES)]
+                ("nseg", I * MT_MAX_BRANCHES), ("n", I * MT_MAX_BRANCHES), ("qlimit", I * MT_MAX_BRANCHES)]
 
 
 RM = C.POINTER(MtRowMap)

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
   // that is ever read, as KEYS they all have logit 0 and value 0.  A workgroup of padded queries exits; key tiles
   // made only of padding are not computed -- their sum(P) share is added in closed form after the loop.
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
-  if (w.qt * 128 >= nv) return;
+  const int nvq = min(nv, p.qlimit[w.br]);                 // entries that act as queries (sequence-parallel plans: a prefix)
+  if (w.qt * 128 >= nvq) return;
 
   // constant chunks of the V images: logical chunk 6 = ones at d = 48 and 52 (O^T row 48 of both lane halves accumulates
   // sum(P)), chunk 7 = zeros; written once (the DMA never touches them)
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void dilated_attn_fwd_kernel(const h16* __rest
 
   // Q^T fragments (B operand): lane = query, element j of k-step ks = Q[q][16 ks + 8 hh + j]
   const int iq = w.qt * 128 + wave * 32 + l31;
-  const bool qvalid = sq.valid(iq);
+  const bool qvalid = sq.valid(iq) && iq < nvq;
   const long qrow = sq.row_clamped(iq);
   // q arrives pre-scaled (attn_common.h: QK_SCALE_LOG2): S' = K . Q'^T is the exp2 argument as it leaves the MFMA chain, up
   // to the running reference m2 -- which rides in as the INITIAL accumulator (below).
@@ -423,7 +424,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   // padded queries get no gradient; padded keys have K = 0 and add nothing to dQ: neither is computed
   const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
-  if (w.qt * 128 >= nv) return;
+  const int nvq = min(nv, p.qlimit[w.br]);
+  if (w.qt * 128 >= nvq) return;
 
   {   // constant chunks 6, 7 (zeros, read as d rows 48..63 of K^T) of both K images; written once
     const int buf = tid >> 7, row = (tid >> 1) & 63, which = 6 + (tid & 1);
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   }
 
   const int iq = w.qt * 128 + wave * 32 + l31;
-  const bool qvalid = sq.valid(iq);
+  const bool qvalid = sq.valid(iq) && iq < nvq;
   const long qrow = sq.row_clamped(iq);
   h16x8 qf[3], dof[3];
 #pragma unroll
@@ -583,9 +585,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     vf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, 2 * H + w.h, krow) + ks * 16 + hh * 8));
   }
 
-  const int ntile = (nv + 63) >> 6;      // tiles holding at least one real query
+  const int nvq = min(nv, p.qlimit[w.br]);   // entries that act as queries (sequence-parallel plans: a prefix)
+  const int ntile = (nvq + 63) >> 6;     // tiles holding at least one real query
   const int row_bytes = sq.dr * HD * 2;
-  const long valid_bytes = (long)(nv - 1) * row_bytes + HD * 2;
+  const long valid_bytes = (long)(nvq - 1) * row_bytes + HD * 2;
   const long tile_bytes = 64L * row_bytes;
   const h16* const qseq = hm_ptr(qkv, M, w.h, sq.row(0));
   const h16* const dseq = hm_ptr(dmixed, M, w.h, sq.row(0));
@@ -599,8 +602,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
     dma_tile(Dx + (t & 1) * IMG_HALVES, tile_rsrc(dseq, t * tile_bytes, valid_bytes), dl);
     if (tid < 64) {
       const int i = t * 64 + lane;
-      const long off = (long)min(i, nv - 1) * sq.dr * H;
-      const bool ok = i < nv;
+      const long off = (long)min(i, nvq - 1) * sq.dr * H;
+      const bool ok = i < nvq;
       rl2 = ok ? fmaf(-lbase[off], LOG2E, LOG2_LN2) : 0.f;      // (Q = dO = 0 there: P' is multiplied by zeros)
       rdl = ok ? -dbase[off] : 0.f;
     }

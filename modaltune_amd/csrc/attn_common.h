@@ -29,6 +29,7 @@ struct Plan {
   int order[MT_MAX_BRANCHES], qtiles[MT_MAX_BRANCHES], blk_off[MT_MAX_BRANCHES + 1];
   long ws_off[MT_MAX_BRANCHES + 1];   // backward workspace: per-branch compact [pass][seg][head][i][q|k|v][48] fp16
   float inv_seg[MT_MAX_BRANCHES];     // 1 / seg (position -> segment index without an integer division per row)
+  int qlimit[MT_MAX_BRANCHES];        // sparse entries [0, qlimit) act as queries (= n unless sequence-parallel)
 };
 
 Plan make_plan(const MtDilatedPlan* p, int qtile) {
@@ -39,6 +40,7 @@ Plan make_plan(const MtDilatedPlan* p, int qtile) {
     d.order[i] = i;
     d.qtiles[i] = cdiv(p->n[i], qtile);
     d.inv_seg[i] = 1.0f / (float)p->seg[i];
+    d.qlimit[i] = p->qlimit[i] > 0 ? p->qlimit[i] : p->n[i];
   }
   // longest sparse sequences first (their workgroups run longest)
   for (int i = 0; i < d.nbranch; ++i)
@@ -60,6 +62,7 @@ bool plan_ok(const MtDilatedPlan* p) {
     const int r = p->ratio[i], s = p->seg[i];
     if (r < 1 || r > H || (H % r) != 0 || s < 1 || s > p->N) return false;
     if (p->nseg[i] != cdiv(p->N, s) || p->n[i] != cdiv(s, r)) return false;
+    if (p->qlimit[i] < 0 || p->qlimit[i] > p->n[i]) return false;
   }
   return true;
 }

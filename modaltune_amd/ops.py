@@ -44,11 +44,14 @@ def _need(t, dtype, name):
         raise TypeError(f"{name}: expected contiguous cuda {dtype}, got {t.dtype} cuda={t.is_cuda} contig={t.is_contiguous()}")
 
 
-def make_plan(branches, N: int, B: int) -> MtDilatedPlan:
+def make_plan(branches, N: int, B: int, qlimit=None) -> MtDilatedPlan:
+    """Plan of the dilated-attention launches; qlimit[i] (optional): only the first qlimit[i] sparse entries of branch i's
+    sequences act as queries (sequence parallelism: local queries over gathered keys)."""
     p = MtDilatedPlan()
     p.nbranch, p.N, p.B = len(branches), N, B
     for i, b in enumerate(branches):
         p.seg[i], p.ratio[i], p.nseg[i], p.n[i] = b.seg, b.ratio, b.nseg, b.n
+        p.qlimit[i] = 0 if qlimit is None else int(qlimit[i])
     return p
 
 
@@ -173,6 +176,12 @@ ATTN_BWD_KV, ATTN_BWD_Q, ATTN_BWD_COMBINE, ATTN_BWD_ALL = 1, 2, 4, 7
 def _dilated_attn_bwd_phase(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16, phases):
     check(_lib.load().mt_dilated_attn_bwd(_p(qkv), _p(dmixed), _p(lse_tot), _p(delta_br), C.byref(plan), _p(workspace),
                                           _p(dqkv16), phases, _s()), "dilated_attn_bwd")
+
+
+def dilated_attn_bwd_phases(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16, phases):
+    """Selected phases (ATTN_BWD_KV | ATTN_BWD_Q | ATTN_BWD_COMBINE) of the backward: the sequence-parallel path fills parts of
+    the workspace from another plan's launches before the combine."""
+    _dilated_attn_bwd_phase(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16, phases)
 
 
 def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):

@@ -159,6 +159,71 @@ def dilated_attention_core(q, k, v, seg_lengths: Sequence[int], ratios: Sequence
     return out
 
 
+def dilated_attention_core_sp(qs, ks, vs, seg_lengths: Sequence[int], ratios: Sequence[int], return_branches: bool = False):
+    """Sequence-parallel DilatedAttention (dilated_attention.py:61-111,212-255 with args.seq_parallel = True).
+
+    qs / ks / vs: one [B, Lloc, H, d] tensor per rank (rank r holds chunk r of the sequence).  Per branch (sl, dr):
+      * sl <= Lloc: the rank works on its chunk alone -- segments of sl tokens counted from the chunk's first row
+        (gathering() sees only the local tensor, DA:96-104);
+      * sl > Lloc (requires sl % Lloc == 0, DA:63): the chunk is ONE segment (sl = min(sl, Lloc), DA:97); every rank
+        sparsifies its chunk on its own (zero rows up to a multiple of dr included), the sparse K / V of the
+        num_rank_per_segment = sl // Lloc ranks of its group [rank // nrps * nrps, +nrps) are concatenated along the
+        length (all-gather over all ranks, then the slice of DA:76-79), and the rank's own sparse queries attend over them
+        (non-causal).  The all-gather's backward is a reduce-scatter (TS/component/utils.py:43-82): a rank's dK / dV is the
+        sum over the ranks of its group -- here simply autograd through the concatenation.
+    Returns the mixed output [B, Lloc, H*d] per rank (and, optionally, the per-branch outputs / LSEs per rank)."""
+    W = len(qs)
+    B, L, H, d = qs[0].shape
+    scale = d ** -0.5
+    outs = [[] for _ in range(W)]
+    lses = [[] for _ in range(W)]
+    for sl, dr in zip(seg_lengths, ratios):
+        sl, dr = int(sl), int(dr)
+        gathered = W > 1 and sl > L
+        s = min(sl, L)
+        nseg = -(-L // s)
+        n = -(-s // dr)
+        g = H // dr
+        padN = nseg * s - L
+
+        def sparse(t):
+            t = F.pad(t, (0, 0, 0, 0, 0, padN))
+            t = t.view(B, nseg, s, H, d)
+            t = F.pad(t, (0, 0, 0, 0, 0, n * dr - s))
+            t = t.view(B, nseg, n, dr, dr, g, d)
+            return torch.diagonal(t, dim1=3, dim2=4)                 # [B, nseg, n, g, d, r]
+
+        sq = [sparse(t) for t in qs]
+        sk = [sparse(t) for t in ks]
+        sv = [sparse(t) for t in vs]
+        if gathered:
+            assert sl % L == 0, "segment length must be a multiple of the local sequence length (DA:63)"
+            nrps = sl // L
+        for r in range(W):
+            if gathered:
+                first = r // nrps * nrps
+                grp = range(first, min(W, first + nrps))
+                kk, vv = torch.cat([sk[i] for i in grp], dim=2), torch.cat([sv[i] for i in grp], dim=2)
+            else:
+                kk, vv = sk[r], sv[r]
+            o, lse = _softmax_attention(sq[r], kk, vv, scale, "explicit")
+            od = qs[r].new_zeros(B, nseg, n, dr, dr, g, d)
+            ld = torch.full((B, nseg, n, dr, dr, g), -1e8, dtype=lse.dtype)
+            idx = torch.arange(dr)
+            od[:, :, :, idx, idx] = o.permute(0, 1, 2, 5, 3, 4)
+            ld[:, :, :, idx, idx] = lse.permute(0, 1, 4, 2, 3)
+            outs[r].append(od.reshape(B, nseg, n * dr, H, d)[:, :, :s].reshape(B, nseg * s, H, d)[:, :L])
+            lses[r].append(ld.reshape(B, nseg, n * dr, H)[:, :, :s].reshape(B, nseg * s, H)[:, :L])
+    mixed = []
+    for r in range(W):
+        with torch.no_grad():
+            w = torch.softmax(torch.stack(lses[r], 0), dim=0)
+        mixed.append(sum(o * w[i].unsqueeze(-1).to(o.dtype) for i, o in enumerate(outs[r])).reshape(B, L, H * d))
+    if return_branches:
+        return mixed, outs, lses
+    return mixed
+
+
 def encoder_layer(x, sd, prefix, seg_lengths, ratios, heads=16, attn_impl="auto"):
     """EncoderLayer.forward (torchscale/architecture/encoder.py:121-175) with DilatedAttention.forward
     (dilated_attention.py:146-262) and FeedForwardNetwork.forward (feedforward_network.py:132-143);

@@ -102,6 +102,73 @@ def unit_layer(seed=2):
     np.savez_compressed(os.path.join(HERE, "unit_layer.npz"), seed=seed, **out)
 
 
+def unit_seqpar(seed=23):
+    """The reference's DilatedAttention with args.seq_parallel (DA:61-111) on W simulated ranks: one thread per rank runs the
+    reference's own gathering / attention_ops / scattering on its chunk; the module-level hooks of the reference's
+    dilated_attention module (world size, rank, all_gather_func) are pointed at an in-process exchange that concatenates the
+    ranks' LIVE tensors along dim 0 -- exactly what Allgather.forward returns -- so one backward over the joint graph gives
+    every rank the sum over ranks of its chunk's gradient, which is Allgather.backward's reduce-scatter
+    (TS/component/utils.py:43-82).  Records per rank: the mixed attention output and dq, dk, dv for a fixed cotangent."""
+    import threading
+    out = {}
+    dt = torch.float64
+    DA = saved = None
+    for name, (W, B, L, segs, ratios) in unit_inputs.SEQPAR_CASES.items():
+        enc = make_longnet_from_name("LongNet_3_layers_768_dim", dilated_ratio=str(ratios), segment_length=str(segs),
+                                     drop_path_rate=0.0, dropout=0.0).double()
+        at = enc.layers[0].self_attn
+        if DA is None:       # the module object the class was defined in (LongNet.py imports it as torchscale.component...)
+            DA = sys.modules[type(at).__module__]
+            saved = DA.get_data_parallel_world_size, DA.get_data_parallel_rank, DA.all_gather_func
+        q, k, v, dy = (tt(a, dt) for a in unit_inputs.seqpar_inputs(seed, name))
+        tl = threading.local()
+        barrier = threading.Barrier(W)
+        slots = [None] * W
+
+        def exchange(x):
+            slots[tl.rank] = x
+            barrier.wait()
+            res = torch.cat(list(slots), 0)
+            barrier.wait()
+            return res
+
+        DA.get_data_parallel_world_size = lambda: W
+        DA.get_data_parallel_rank = lambda: tl.rank
+        DA.all_gather_func = exchange
+        leaves, attns, errs = [None] * W, [None] * W, []
+
+        def run(r):
+            try:
+                tl.rank = r
+                qr, kr, vr = (t[r].clone().requires_grad_(True) for t in (q, k, v))
+                outs, lses = [], []
+                for sl, dr in zip(segs, ratios):
+                    ki = at.gathering(kr, dr, sl, is_causal=False, offset=0, is_kv=True, seq_parall=True)
+                    vi = at.gathering(vr, dr, sl, is_causal=False, offset=0, is_kv=True, seq_parall=True)
+                    qi = at.gathering(qr, dr, sl, is_causal=False, offset=0, is_kv=False, seq_parall=True)
+                    o, lse = at.attention_ops(qi, ki, vi)
+                    outs.append(o); lses.append(lse)
+                leaves[r], attns[r] = (qr, kr, vr), at.scattering(outs, lses, L, B, offset=0)
+            except Exception as e:      # a failed rank must not leave the others at the barrier
+                errs.append(e)
+                barrier.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        sum((attns[r] * dy[r]).sum() for r in range(W)).backward()
+        for r in range(W):
+            out[f"{name}_attn{r}"] = attns[r].detach().numpy().astype(np.float32)      # (fp32 storage keeps the fixture small)
+            for nm, leaf in zip("qkv", leaves[r]):
+                out[f"{name}_d{nm}{r}"] = leaf.grad.numpy().astype(np.float32)
+    DA.get_data_parallel_world_size, DA.get_data_parallel_rank, DA.all_gather_func = saved
+    np.savez_compressed(os.path.join(HERE, "unit_seqpar.npz"), seed=seed, **out)
+
+
 def unit_gene(seed=3):
     cfg = ModelConfig.from_json(REF_CFG, depth=3, interaction_indexes=[[0, 0], [1, 1], [2, 2]])
     out = {}
@@ -371,6 +438,8 @@ if __name__ == "__main__":
         unit_layer()
     if "gene" in which:
         unit_gene()
+    if "seqpar" in which:   # LongNet sequence parallelism
+        unit_seqpar()
     if "gene331" in which:
         unit_gene331()
     if "dataset" in which:
