@@ -238,13 +238,17 @@ int mt_extract_attn_bwd(const float* q, const mt_half* kv, const float* out, con
  *   z[i] = ELU(W2_i ELU(W1_i g_i + b1_i) + b2_i).
  * params / grads: the flat fp32 parameter / gradient buffers; offs [G][4] = element offsets of (W1_i [latent, n_i],
  * b1_i, W2_i [latent, latent], b2_i) (W2 offsets multiples of 4); sizes [G] = n_i; goff [G] = offset of g_i in the
- * concatenated `genes` vector; a1, a2 [G, latent] pre-activations saved for the backward; latent must be 256.
- * alpha_drop (or NULL): train-mode nn.AlphaDropout(p) after each ELU, sites alpha_drop->site and site + 1. */
+ * concatenated `genes` vector; latent must be 256.  passes P (1..4): the reference calls the model once per task, so in
+ * train mode every task pass draws its own AlphaDropout masks; the weights are streamed once for all passes.
+ * z, a2 (second pre-activation, saved) are [G, P, latent] (pathway-major: the mixer's group axis stays outermost); a1 (first
+ * pre-activation: the same in every pass) [G, latent].  alpha_drop (or NULL): train-mode nn.AlphaDropout(p) after each ELU, sites
+ * alpha_drop->site and site + 1; the mask index of pathway i, pass p, unit j is (i P + p) latent + j. */
 int mt_gene_snn_fwd(const float* params, const long* offs, const int* sizes, const long* goff, const float* genes, int G,
-                    int latent, float* a1, float* a2, float* z, const MtDropout* alpha_drop, mt_stream_t stream);
-/* backward: grads (+)= dW1, db1, dW2, db2 for every pathway given dz [G, latent] (no input gradient: genes are data) */
+                    int latent, int passes, float* a1, float* a2, float* z, const MtDropout* alpha_drop, mt_stream_t stream);
+/* backward: grads (+)= dW1, db1, dW2, db2 for every pathway, summed over the passes, given dz [G, P, latent] (no input
+ * gradient: genes are data) */
 int mt_gene_snn_bwd(const float* params, float* grads, const long* offs, const int* sizes, const long* goff,
-                    const float* genes, int G, int latent, const float* a1, const float* a2, const float* dz,
+                    const float* genes, int G, int latent, int passes, const float* a1, const float* a2, const float* dz,
                     const MtDropout* alpha_drop, mt_stream_t stream);
 
 /* Small dense multi-head attention over tokens (prompt self-attention AM:87): q,k,v fp32 [B,T,E], heads h. */

@@ -70,8 +70,8 @@ SIGNATURES = {
     "mt_dilated_mix_ln_bwd": [P, P, P, P, PL, P, P, P, P, P],
     "mt_dilated_attn_bwd_workspace_bytes": [PL],
     "mt_dilated_attn_bwd": [P, P, P, P, PL, P, P, I, P],
-    "mt_gene_snn_fwd": [P, P, P, P, P, I, I, P, P, P, DR, P],
-    "mt_gene_snn_bwd": [P, P, P, P, P, P, I, I, P, P, P, DR, P],
+    "mt_gene_snn_fwd": [P, P, P, P, P, I, I, I, P, P, P, DR, P],
+    "mt_gene_snn_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, DR, P],
     "mt_inject_attn_fwd": [P, I, I, P, P, I, P, P, P],
     "mt_inject_attn_bwd": [P, P, P, P, I, I, P, P, I, P, P, P, P],
     "mt_extract_attn_fwd": [P, P, I, I, I, P, P, P, P, I, P],

@@ -21,11 +21,13 @@ struct GeneArgs {
   const int* sizes;      // [G]
   const long* goff;      // [G] offset of g_i in `genes`
   const float* genes;
-  float* a1; float* a2;  // [G][latent] pre-activations (saved)
-  float* z;              // [G][latent] forward output
-  const float* dz;       // [G][latent]
+  float* a1; float* a2;  // pre-activations (saved): a1 [G][latent] (the same in every pass), a2 [G][P][latent]
+  float* z;              // [G][P][latent] forward output (pathway-major: the mixer's group axis stays outermost)
+  const float* dz;       // [G][P][latent]
   DropArgs adrop;        // nn.AlphaDropout after each ELU (gene_encoder.py:178-181): sites adrop.site, adrop.site + 1
+  int G, P;              // P task passes: one forward call of the reference each, so each draws its own masks
 };
+constexpr int GP_MAX = 4;
 
 // AlphaDropout(p): kept values pass, dropped ones become alpha' = -selu_scale * selu_alpha; then the affine (a, b) that
 // restores zero mean / unit variance (torch.nn.functional.alpha_dropout)
@@ -36,8 +38,10 @@ MT_DEVINL AlphaAff alpha_affine(float p) {
   return AlphaAff{a, -a * ALPHA_P * p};
 }
 
-// y[j] = bias[j] + sum_k W[j][k] x[k]  (thread j), W row-major [GL][n] streamed through LDS, x in LDS
-MT_DEVINL float gemv_rows(const float* __restrict__ W, int n, const float* xs, float (*Ws)[GC + 1], float acc) {
+// y_p[j] = bias[j] + sum_k W[j][k] x_p[k]  (thread j) for P input vectors at once: W row-major [GL][n] is streamed through
+// LDS ONCE for all passes, x_p in LDS
+template <int P>
+MT_DEVINL void gemv_rows(const float* __restrict__ W, int n, const float (*xs)[GL], float (*Ws)[GC + 1], float (&acc)[P]) {
   const int j = threadIdx.x;
   for (int k0 = 0; k0 < n; k0 += GC) {
     const int kc = min(GC, n - k0);
@@ -48,24 +52,28 @@ MT_DEVINL float gemv_rows(const float* __restrict__ W, int n, const float* xs, f
     }
     __syncthreads();
 #pragma unroll 8
-    for (int c = 0; c < GC; ++c) acc = fmaf(Ws[j][c], (k0 + c < n) ? xs[k0 + c] : 0.f, acc);
+    for (int c = 0; c < GC; ++c) {
+      const float w = Ws[j][c];
+#pragma unroll
+      for (int p = 0; p < P; ++p) acc[p] = fmaf(w, (k0 + c < n) ? xs[p][k0 + c] : 0.f, acc[p]);
+    }
   }
-  return acc;
 }
 
+template <int P>
 __global__ __launch_bounds__(GL) void gene_snn_fwd_kernel(GeneArgs a) {
   __shared__ float Ws[GL][GC + 1];
-  __shared__ float xs[GL];
+  __shared__ float xs[P][GL];
   const int i = blockIdx.x, j = threadIdx.x;
   const int n = a.sizes[i];
   const long* o = a.offs + 4L * i;
   const float* g = a.genes + a.goff[i];
   float acc = a.params[o[1] + j];
-  // first layer: n can exceed the LDS vector; walk it in pieces of GL
+  // first layer (the same in every pass: the input is data): n can exceed the LDS vector; walk it in pieces of GL
   for (int p0 = 0; p0 < n; p0 += GL) {
     const int pn = min(GL, n - p0);
     __syncthreads();
-    if (j < pn) xs[j] = g[p0 + j];
+    if (j < pn) xs[0][j] = g[p0 + j];
     __syncthreads();
     // rows of W1 restricted to columns [p0, p0 + pn): row stride n
     for (int k0 = 0; k0 < pn; k0 += GC) {
@@ -77,51 +85,75 @@ __global__ __launch_bounds__(GL) void gene_snn_fwd_kernel(GeneArgs a) {
       }
       __syncthreads();
 #pragma unroll 8
-      for (int c = 0; c < GC; ++c) acc = fmaf(Ws[j][c], (k0 + c < pn) ? xs[k0 + c] : 0.f, acc);
+      for (int c = 0; c < GC; ++c) acc = fmaf(Ws[j][c], (k0 + c < pn) ? xs[0][k0 + c] : 0.f, acc);
     }
   }
   a.a1[(long)i * GL + j] = acc;
   __syncthreads();
   const bool ad = a.adrop.active() && a.adrop.p > 0.f;
   const AlphaAff af = alpha_affine(a.adrop.p);
-  float h1 = elu(acc);
-  if (ad) h1 = fmaf(af.a, drop_keep1(a.adrop, a.adrop.site, (uint64_t)i * GL + j) ? h1 : ALPHA_P, af.b);
-  xs[j] = h1;
-  float acc2 = gemv_rows(a.params + o[2], GL, xs, Ws, a.params[o[3] + j]);
-  a.a2[(long)i * GL + j] = acc2;
-  float zz = elu(acc2);
-  if (ad) zz = fmaf(af.a, drop_keep1(a.adrop, a.adrop.site + 1, (uint64_t)i * GL + j) ? zz : ALPHA_P, af.b);
-  a.z[(long)i * GL + j] = zz;
+  const float e1 = elu(acc);
+  float acc2[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {         // pass p draws its own masks: element index (i P + p) 256 + j
+    float h1 = e1;
+    if (ad) h1 = fmaf(af.a, drop_keep1(a.adrop, a.adrop.site, ((uint64_t)i * P + p) * GL + j) ? h1 : ALPHA_P, af.b);
+    xs[p][j] = h1;
+    acc2[p] = a.params[o[3] + j];
+  }
+  gemv_rows<P>(a.params + o[2], GL, xs, Ws, acc2);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const long e = ((long)i * P + p) * GL + j;
+    a.a2[e] = acc2[p];
+    float zz = elu(acc2[p]);
+    if (ad) zz = fmaf(af.a, drop_keep1(a.adrop, a.adrop.site + 1, (uint64_t)e) ? zz : ALPHA_P, af.b);
+    a.z[e] = zz;
+  }
 }
 
+template <int P>
 __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
   __shared__ float Ws[GC][GL + 1];   // 32 rows x 256 columns of W2
-  __shared__ float da2s[GL], h1s[GL], da1s[GL];
+  __shared__ float da2s[P][GL], h1s[P][GL], da1s[GL];
   const int i = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const int n = a.sizes[i];
   const long* o = a.offs + 4L * i;
-  const float pre1 = a.a1[(long)i * GL + j], pre2 = a.a2[(long)i * GL + j];
+  const float pre1 = a.a1[(long)i * GL + j];
   const bool ad = a.adrop.active() && a.adrop.p > 0.f;
   const AlphaAff af = alpha_affine(a.adrop.p);
-  const bool keep1 = !ad || drop_keep1(a.adrop, a.adrop.site, (uint64_t)i * GL + j);
-  const bool keep2 = !ad || drop_keep1(a.adrop, a.adrop.site + 1, (uint64_t)i * GL + j);
-  const float g2 = ad ? (keep2 ? af.a : 0.f) : 1.f, g1 = ad ? (keep1 ? af.a : 0.f) : 1.f;
-  const float da2 = a.dz[(long)i * GL + j] * g2 * elu_grad(pre2);
-  da2s[j] = da2;
-  h1s[j] = ad ? fmaf(af.a, keep1 ? elu(pre1) : ALPHA_P, af.b) : elu(pre1);
-  a.grads[o[3] + j] += da2;
+  float g1[P], db2 = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const long e = ((long)i * P + p) * GL + j;
+    const float pre2 = a.a2[e];
+    const bool keep1 = !ad || drop_keep1(a.adrop, a.adrop.site, (uint64_t)e);
+    const bool keep2 = !ad || drop_keep1(a.adrop, a.adrop.site + 1, (uint64_t)e);
+    const float g2 = ad ? (keep2 ? af.a : 0.f) : 1.f;
+    g1[p] = ad ? (keep1 ? af.a : 0.f) : 1.f;
+    const float da2 = a.dz[e] * g2 * elu_grad(pre2);
+    da2s[p][j] = da2;
+    h1s[p][j] = ad ? fmaf(af.a, keep1 ? elu(pre1) : ALPHA_P, af.b) : elu(pre1);
+    db2 += da2;
+  }
+  a.grads[o[3] + j] += db2;
   __syncthreads();
-  // dW2[r][c] += da2[r] h1[c]: one wave per row, 16-byte accesses
+  // dW2[r][c] += sum_p da2_p[r] h1_p[c]: one wave per row, 16-byte accesses
   for (int r = wave; r < GL; r += 4) {
     float* dst = a.grads + o[2] + (long)r * GL + lane * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(dst);
-    const float d = da2s[r];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = fmaf(d, h1s[lane * 4 + e], v[e]);
+    for (int p = 0; p < P; ++p) {
+      const float d = da2s[p][r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(d, h1s[p][lane * 4 + e], v[e]);
+    }
     *reinterpret_cast<f32x4*>(dst) = v;
   }
-  // dh1[k] = sum_r W2[r][k] da2[r] (thread k): W2 streamed 32 rows at a time, coalesced
-  float dh1 = 0.f;
+  // dh1_p[k] = sum_r W2[r][k] da2_p[r] (thread k): W2 streamed ONCE, 32 rows at a time, coalesced
+  float dh1[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) dh1[p] = 0.f;
   for (int r0 = 0; r0 < GL; r0 += GC) {
     __syncthreads();
     for (int t = j; t < GC * GL; t += GL) {
@@ -130,9 +162,17 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
     }
     __syncthreads();
 #pragma unroll 8
-    for (int r = 0; r < GC; ++r) dh1 = fmaf(Ws[r][j], da2s[r0 + r], dh1);
+    for (int r = 0; r < GC; ++r) {
+      const float w = Ws[r][j];
+#pragma unroll
+      for (int p = 0; p < P; ++p) dh1[p] = fmaf(w, da2s[p][r0 + r], dh1[p]);
+    }
   }
-  const float da1 = dh1 * g1 * elu_grad(pre1);
+  // the first layer's input is the same in every pass: da1 = sum_p dh1_p * mask_p * elu'(pre1)
+  float da1 = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) da1 += dh1[p] * g1[p];
+  da1 *= elu_grad(pre1);
   a.grads[o[1] + j] += da1;
   da1s[j] = da1;
   __syncthreads();
@@ -147,23 +187,36 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
 }  // namespace
 
 extern "C" int mt_gene_snn_fwd(const float* params, const long* offs, const int* sizes, const long* goff, const float* genes,
-                               int G, int latent, float* a1, float* a2, float* z, const MtDropout* alpha_drop, mt_stream_t stream) {
-  if (!params || !offs || !sizes || !goff || !genes || !a1 || !a2 || !z || G < 1) return MT_ERR_BAD_ARG;
-  if (latent != GL) return MT_ERR_UNSUPPORTED;
-  GeneArgs a{params, nullptr, offs, sizes, goff, genes, a1, a2, z, nullptr, make_drop(alpha_drop)};
-  hipLaunchKernelGGL(gene_snn_fwd_kernel, dim3(G), dim3(GL), 0, (hipStream_t)stream, a);
+                               int G, int latent, int passes, float* a1, float* a2, float* z, const MtDropout* alpha_drop,
+                               mt_stream_t stream) {
+  if (!params || !offs || !sizes || !goff || !genes || !a1 || !a2 || !z || G < 1 || passes < 1) return MT_ERR_BAD_ARG;
+  if (latent != GL || passes > GP_MAX) return MT_ERR_UNSUPPORTED;
+  GeneArgs a{params, nullptr, offs, sizes, goff, genes, a1, a2, z, nullptr, make_drop(alpha_drop), G, passes};
+  hipStream_t s = (hipStream_t)stream;
+  switch (passes) {
+    case 1: hipLaunchKernelGGL(gene_snn_fwd_kernel<1>, dim3(G), dim3(GL), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(gene_snn_fwd_kernel<2>, dim3(G), dim3(GL), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(gene_snn_fwd_kernel<3>, dim3(G), dim3(GL), 0, s, a); break;
+    default: hipLaunchKernelGGL(gene_snn_fwd_kernel<4>, dim3(G), dim3(GL), 0, s, a); break;
+  }
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
 
 extern "C" int mt_gene_snn_bwd(const float* params, float* grads, const long* offs, const int* sizes, const long* goff,
-                               const float* genes, int G, int latent, const float* a1, const float* a2, const float* dz,
-                               const MtDropout* alpha_drop, mt_stream_t stream) {
-  if (!params || !grads || !offs || !sizes || !goff || !genes || !a1 || !a2 || !dz || G < 1) return MT_ERR_BAD_ARG;
-  if (latent != GL) return MT_ERR_UNSUPPORTED;
+                               const float* genes, int G, int latent, int passes, const float* a1, const float* a2,
+                               const float* dz, const MtDropout* alpha_drop, mt_stream_t stream) {
+  if (!params || !grads || !offs || !sizes || !goff || !genes || !a1 || !a2 || !dz || G < 1 || passes < 1) return MT_ERR_BAD_ARG;
+  if (latent != GL || passes > GP_MAX) return MT_ERR_UNSUPPORTED;
   GeneArgs a{params, grads, offs, sizes, goff, genes, const_cast<float*>(a1), const_cast<float*>(a2), nullptr, dz,
-             make_drop(alpha_drop)};
-  hipLaunchKernelGGL(gene_snn_bwd_kernel, dim3(G), dim3(GL), 0, (hipStream_t)stream, a);
+             make_drop(alpha_drop), G, passes};
+  hipStream_t s = (hipStream_t)stream;
+  switch (passes) {
+    case 1: hipLaunchKernelGGL(gene_snn_bwd_kernel<1>, dim3(G), dim3(GL), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(gene_snn_bwd_kernel<2>, dim3(G), dim3(GL), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(gene_snn_bwd_kernel<3>, dim3(G), dim3(GL), 0, s, a); break;
+    default: hipLaunchKernelGGL(gene_snn_bwd_kernel<4>, dim3(G), dim3(GL), 0, s, a); break;
+  }
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -348,8 +348,9 @@ class Engine:
         # ---- patch embedding + positional table + cls (LVA:232-242); shared by the B passes
         self._embed_patches(x, coords, ws, staged, L)
 
-        # ---- token side: gene encoder (shared) + task token per pass (LVA:257-266)
-        gene = self._gene_encoder(genes)                                   # Var [1, G64, D]
+        # ---- token side: gene encoder (one pass when dropout is off, own masks per task pass otherwise) + task token per pass
+        # (LVA:257-266)
+        gene = self._gene_encoder(genes, passes=int(task_onehots.shape[0]))  # Var [1, G64, P, D]
         c = self._assemble_tokens(gene, task_onehots, clinical)            # Var [B, T, D]
         pe = P("gene_pe")
 
@@ -479,8 +480,9 @@ class Engine:
             raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid")
 
     # ------------------------------------------------------------------ token-side pieces
-    def _gene_encoder(self, genes: Sequence[torch.Tensor]) -> Var:
-        """GeneEncoder_Group.gene_encode (gene_encoder.py:194-215), batch 1."""
+    def _gene_encoder(self, genes: Sequence[torch.Tensor], passes: int = 1) -> Var:
+        """GeneEncoder_Group.gene_encode (gene_encoder.py:194-215) of one slide for `passes` task passes: returns the gene tokens
+        [1, G64, P, D] with P = passes in train mode with dropout (own masks per pass), else 1 (shared)."""
         tape, P, g = self.tape, self.store.param, self.cfg.gene
         G = len(self.group_sizes)
         if not torch.is_tensor(genes) and len(genes) != G:
@@ -492,22 +494,25 @@ class Engine:
             gflat = torch.cat([gi.reshape(-1) for gi in genes]).to(self.device, F32)
         if gflat.numel() != self._gene_total:
             raise ValueError(f"expected {self._gene_total} gene values in {G} groups, got {gflat.numel()}")
-        z = Var(tape.new(1, G, g.latent_dim))
-        a1, a2 = tape.new(G, g.latent_dim), tape.new(G, g.latent_dim)
-        st = self.store
-        # train mode: AlphaDropout after each ELU (GE:178-181).  The gene encoder runs once per slide here and is shared by the
-        # task passes, so its masks are shared too (the reference redraws them in each of its three forward calls).
+        # train mode: AlphaDropout after each ELU (GE:178-181) and Dropout in the mixer.  The reference calls the model once per
+        # task, so every task pass draws its own masks: with dropout on the encoder carries a pass axis [1, G, P, C] behind the
+        # group axis (weights streamed once for all passes; the counter-based masks differ because the element offsets do);
+        # with dropout off the passes are identical and ONE is computed and broadcast.
         gp = float(g.dropout)
         adrop = self._drop(300, gp)
+        Pn = passes if adrop is not None else 1
+        z = Var(tape.new(1, G, Pn, g.latent_dim))
+        a1, a2 = tape.new(G, g.latent_dim), tape.new(G, Pn, g.latent_dim)
+        st = self.store
         ops.gene_snn_fwd(st.flat, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim, a1, a2, z.data,
-                         alpha_drop=adrop)
+                         alpha_drop=adrop, passes=Pn)
         z0 = z          # (closures bind late: `z` is rebound by the mixer loop below)
 
         def bwd_networks():
             if z0.grad is None:
                 return
             ops.gene_snn_bwd(st.flat, st.flat_grad, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim,
-                             a1, a2, z0.grad, alpha_drop=adrop)
+                             a1, a2, z0.grad, alpha_drop=adrop, passes=Pn)
         tape.record(bwd_networks)
         for k in range(g.depth):
             p = f"gene_encoder.mlp_mixer.{k}."
@@ -521,7 +526,7 @@ class Engine:
             z = tape.linear(f1, P(p + "1.fn.3.weight"), P(p + "1.fn.3.bias"), drop=self._drop(313 + 4 * k, gp), resid=z)
         p = "gene_encoder.mlp_mixer."
         z = tape.layernorm(z, P(p + f"{g.depth}.weight"), P(p + f"{g.depth}.bias"))
-        z = tape.linear(z, P(p + f"{g.depth + 1}.weight"), P(p + f"{g.depth + 1}.bias"))          # [1, G, D]
+        z = tape.linear(z, P(p + f"{g.depth + 1}.weight"), P(p + f"{g.depth + 1}.bias"))          # [1, G, P, D]
         return tape.axis_linear(z, P("gene_encoder.pathway_compression.weight"), P("gene_encoder.pathway_compression.bias"))
 
     def _assemble_tokens(self, gene: Var, onehots: torch.Tensor, clinical: Optional[torch.Tensor] = None) -> Var:
@@ -546,16 +551,21 @@ class Engine:
             task = tape.layernorm(tape.linear(oh, P("task_weight.0.weight"), P("task_weight.0.bias")),
                                   P("task_weight.1.weight"), P("task_weight.1.bias"))                  # [B, D]
             ops.copy_rows(task.data, c.data, B, D, dmap=rowmap(1, T, ncl))
-        ops.copy_rows(gene.data.view(G64, D), c.data, B * G64, D, smap=rowmap(G64, 0, 0), dmap=rowmap(G64, T, ncl + nt))
+        Pg = gene.data.shape[2]              # 1 (one encoder pass shared by the task passes) or B (own dropout masks per pass)
+        assert Pg in (1, B)
+        gsrc = gene.data.view(G64 * Pg, D)
+        for b in range(B):                   # rows (g, b) of the pathway-major gene tokens -> pass b's gene slots
+            ops.copy_rows(gsrc, c.data[b], G64, D, smap=rowmap(1, Pg, b if Pg > 1 else 0), dmap=rowmap(G64, T, ncl + nt))
 
         def bwd():
             if c.grad is None:
                 return
             if task is not None:
                 ops.copy_rows(c.grad, task.g(), B, D, smap=rowmap(1, T, ncl), accumulate=True)
-            gg = gene.g().view(G64, D)
-            for b in range(B):      # d gene_embedding (and d clinical token) = sum over the passes
-                ops.copy_rows(c.grad, gg, G64, D, smap=rowmap(G64, T, b * T + ncl + nt), accumulate=True)
+            gg = gene.g().view(G64 * Pg, D)
+            for b in range(B):      # d gene tokens of pass b (summed over the passes when they share one encoder pass)
+                ops.copy_rows(c.grad, gg, G64, D, smap=rowmap(G64, T, b * T + ncl + nt), dmap=rowmap(1, Pg, b if Pg > 1 else 0),
+                              accumulate=True)
                 if clin is not None:
                     ops.copy_rows(c.grad, clin.g(), 1, D, smap=rowmap(1, T, b * T), accumulate=True)
         tape.record(bwd)

@@ -195,13 +195,13 @@ def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
         TIMER.setdefault(name, []).append((e0, e1))
 
 
-def gene_snn_fwd(params, offs, sizes, goff, genes, G, latent, a1, a2, z, alpha_drop=None):
-    check(_lib.load().mt_gene_snn_fwd(_p(params), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, _p(a1), _p(a2), _p(z),
+def gene_snn_fwd(params, offs, sizes, goff, genes, G, latent, a1, a2, z, alpha_drop=None, passes=1):
+    check(_lib.load().mt_gene_snn_fwd(_p(params), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, passes, _p(a1), _p(a2), _p(z),
                                       _dr(alpha_drop), _s()), "gene_snn_fwd")
 
 
-def gene_snn_bwd(params, grads, offs, sizes, goff, genes, G, latent, a1, a2, dz, alpha_drop=None):
-    check(_lib.load().mt_gene_snn_bwd(_p(params), _p(grads), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, _p(a1),
+def gene_snn_bwd(params, grads, offs, sizes, goff, genes, G, latent, a1, a2, dz, alpha_drop=None, passes=1):
+    check(_lib.load().mt_gene_snn_bwd(_p(params), _p(grads), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, passes, _p(a1),
                                       _p(a2), _p(dz), _dr(alpha_drop), _s()), "gene_snn_bwd")
 
 

@@ -179,12 +179,13 @@ class Tape:
     def axis_linear(self, x: Var, W: Param, b: Param, act: int = ops.ACT_NONE, drop=None, resid: Optional[Var] = None) -> Var:
         """y[b, go, c] = [resid +] Dropout(act(sum_g W[go, g] x[b, g, c] + bias[go])): Conv1d(kernel 1) over the group axis
         (gene_encoder.py:140-158) and pathway_compression (gene_encoder.py:212); fused like `linear`."""
-        Bb, G, Cc = x.data.shape
-        assert Bb == 1, "the gene encoder runs once per slide (shared by the task passes)"
+        Bb, G = x.data.shape[0], x.data.shape[1]
+        assert Bb == 1, "one slide per call; task passes with their own dropout masks ride in the trailing dims [1, G, P, C]"
+        Cc = x.data.numel() // G          # everything behind the group axis is 'channels' to the kernel-1 convolution
         Go = W.data.shape[0]
         Wm = W.data.view(Go, G)
-        y = Var(self.new(Bb, Go, Cc))
-        pre = self.new(Bb, Go, Cc) if act != ops.ACT_NONE else None
+        y = Var(self.new(Bb, Go, *x.data.shape[2:]))
+        pre = self.new(*y.data.shape) if act != ops.ACT_NONE else None
         ops.sgemm(Wm, (G, 1), x.data, (1, Cc), y.data, (Cc, 1), Go, Cc, G, bias=b.data, bias_on_m=True, act=act, pre_out=pre,
                   c_drop=drop, resid=None if resid is None else resid.data)
 
