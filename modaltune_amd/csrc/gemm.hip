@@ -16,6 +16,15 @@ namespace {
 
 constexpr int BK = 64;
 
+#ifdef MT_GEMM_STAMP      // diagnostic build (tools/experiments): phase durations of the ping-pong kernel, summed over workgroups
+MT_DEVINL unsigned long long stamp_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define MT_STAMP(var) const unsigned long long var = stamp_now()
+#define MT_STAMP_ADD(g, slot, a, b) do { if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<float*>((g).pos_table)) + (slot), (b) - (a)); } while (0)
+#else
+#define MT_STAMP(var)
+#define MT_STAMP_ADD(g, slot, a, b)
+#endif
+
 struct GemmNtArgs {
   const h16* A; long lda; RowMap amap;
   const h16* W;
@@ -79,6 +88,7 @@ MT_DEVINL void gemm_epilogue_h16(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16]
 #pragma unroll
   for (int pass = 0; pass < BM / EROWS; ++pass) {
     const int rbase = pass * EROWS;
+    MT_STAMP(e0);
     if (pass > 0) __syncthreads();
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -92,6 +102,7 @@ MT_DEVINL void gemm_epilogue_h16(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16]
       }
     }
     __syncthreads();
+    MT_STAMP(e1);
 #pragma unroll 4
     for (int rr = r0; rr < EROWS; rr += RPP) {
       const int m = m0 + rbase + rr;
@@ -101,6 +112,9 @@ MT_DEVINL void gemm_epilogue_h16(const GemmNtArgs& g, f32x4 (&acc)[BM / WM / 16]
                                       : C + g.cmap.map(m) * g.ldc + n;
       *reinterpret_cast<h16x8*>(dst) = (h16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
+    MT_STAMP(e2);
+    MT_STAMP_ADD(g, 2, e0, e1);
+    MT_STAMP_ADD(g, 3, e1, e2);
   }
 }
 
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs g) {
   constexpr int RT = RH / 32;                    // 16-row fragment tiles per A quadrant
   __shared__ __attribute__((aligned(16))) h16 smem[2 * TILE];
 
+  MT_STAMP(t0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int nbn = (g.N + BN - 1) / BN, nbm = (g.m_end - g.m_begin + BM - 1) / BM, nwg = nbn * nbm;
@@ -398,6 +413,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs g) {
   if (nk > 1) { dma_b(0, TILE + B0, BK); dma_b(1, TILE + B1, BK); wait_vmcnt<4>(); }
   else wait_vmcnt<0>();
   bar();
+  MT_STAMP(t1);
   if (wr == 1) bar();                            // group 1 runs one interval behind
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -428,7 +444,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs g) {
   }
   if (wr == 0) bar();                            // group 0 matches group 1's extra barrier
   __syncthreads();
+  MT_STAMP(t2);
+  MT_STAMP_ADD(g, 0, t0, t1);
+  MT_STAMP_ADD(g, 1, t1, t2);
   gemm_epilogue<BM, BN, WM, WN, EPI, OutT, 2 * TILE * 2>(g, acc, smem, m0, n0);
+  MT_STAMP(t3);
+  MT_STAMP_ADD(g, 4, t2, t3);
+  MT_STAMP_ADD(g, 5, t3 - 1, t3);
 }
 
 template <int BN, int EPI, typename OutT>
