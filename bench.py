@@ -62,21 +62,56 @@ def launch_ranks(args) -> int:
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the hot path)")
     if n > ndev and args.backend == "nccl":
         raise RuntimeError(f"--gpus {n} with the RCCL backend needs {n} GPUs, found {ndev} (rehearse with --backend gloo)")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = rc or p.wait()
-    sys.stdout.write(out.decode())
+    import tempfile
+    import threading
+    rc = 1
+    for attempt in range(3):          # the bind/close port pick can lose a race with another process: retry on a fresh port
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs = []
+        errlog = tempfile.TemporaryFile()
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                          stderr=errlog if r == 0 else None))
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        # poll ALL children: the first non-zero exit (a rank that died in device / RCCL init would otherwise leave the others
+        # hanging in the rendezvous until the c10d timeout) terminates the rest and becomes the exit code
+        rc = 0
+        live = set(range(n))
+        while live and rc == 0:
+            for r in list(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        rc = code
+            if live and rc == 0:
+                time.sleep(0.05)
+        if rc != 0:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        reader.join(timeout=30)
+        errlog.seek(0)
+        err = errlog.read().decode(errors="replace")
+        errlog.close()
+        sys.stderr.write(err)
+        if rc != 0 and attempt < 2 and ("EADDRINUSE" in err or "Address already in use" in err):
+            continue
+        break
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     return rc
 
@@ -241,8 +276,8 @@ def main():
     try:
         run(nwarm)
     except Exception as e:            # graph capture unavailable -> same arithmetic with eager launches
-        if args.eager:                # (every rank runs the same code on the same hardware: the fallback is symmetric)
-            raise
+        if args.eager or world > 1:   # multi-rank: a capture failure must not pass unnoticed (ranks could also diverge on it):
+            raise                     # the run fails with a non-zero exit code; `--eager` is the explicit way to time eager launches
         print(f"[bench] hipGraph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
         args.eager = True
         ts._gcache.clear()

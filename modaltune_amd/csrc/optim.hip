@@ -140,8 +140,10 @@ __global__ void coords_to_grid_kernel(const float* __restrict__ coords, int L, f
                                       int* __restrict__ pcol, int* __restrict__ err) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
-  const int r = (int)floorf(coords[2 * i] / tile), c = (int)floorf(coords[2 * i + 1] / tile);
-  const bool bad = r < 0 || c < 0 || r >= ngrids || c >= ngrids;
+  const float fr = floorf(coords[2 * i] / tile), fc = floorf(coords[2 * i + 1] / tile);
+  // (int) of a NaN / out-of-range float is unspecified: test the floats (NaN fails every comparison -> bad)
+  const bool bad = !(fr >= 0.f && fc >= 0.f && fr < (float)ngrids && fc < (float)ngrids);
+  const int r = bad ? 0 : (int)fr, c = bad ? 0 : (int)fc;
   prow[i] = min(max(r, 0), ngrids - 1);
   pcol[i] = min(max(c, 0), ngrids - 1);
   if (bad && err) atomicOr(err, 1);

@@ -139,6 +139,8 @@ class Engine:
         # backward stages whose parameter gradients are final (data-parallel bucket boundaries): set by TrainStep
         self.grad_ready_hook = None
         self._coord_err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._coord_err_host = None           # pinned mirror of _coord_err + the event of its last async read-back:
+        self._coord_err_event = None          # bad coords raise at the next call WITHOUT a host sync (poll_inputs)
         self._pin_ring: List[tuple] = []      # pinned staging slots for host-side coords (no pageable-copy sync per step)
         self._pin_next = 0
         self.collect_taps = False      # tests: keep cls / token states after every interaction block
@@ -440,7 +442,14 @@ class Engine:
             c = coords.reshape(-1, 2).to(F32).contiguous()
             if c.shape[0] != L:
                 raise ValueError(f"coords has {c.shape[0]} rows for {L} patches")
+            self.poll_inputs()                # raises for a bad slide of an EARLIER call once its flag has landed (no sync)
             ops.coords_to_grid(c, L, float(cfg.tile_size), cfg.slide_ngrids, ws["prow"], ws["pcol"], self._coord_err)
+            if not torch.cuda.is_current_stream_capturing():
+                if self._coord_err_host is None:
+                    self._coord_err_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                    self._coord_err_event = torch.cuda.Event()
+                self._coord_err_host.copy_(self._coord_err, non_blocking=True)
+                self._coord_err_event.record()
         else:
             coords_np = coords.detach().numpy() if torch.is_tensor(coords) else np.asarray(coords)
             prow, pcol = coords_to_rowcol(coords_np.reshape(-1, 2), float(cfg.tile_size))
@@ -474,10 +483,23 @@ class Engine:
         return self._pin_ring[self._pin_last][0]
 
     def check_inputs(self):
-        """Raises if a device-side coords binning since the last call met a cell outside the positional grid (host sync)."""
+        """Raises if a device-side coords binning since the last call met a cell outside the positional grid or a
+        non-finite coordinate (host sync: call it where the host reads the loss / logits anyway)."""
         if int(self._coord_err) != 0:
             self._coord_err.zero_()
-            raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid")
+            if self._coord_err_host is not None:
+                self._coord_err_host.zero_()
+            raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid (or not finite)")
+
+    def poll_inputs(self):
+        """check_inputs() without the sync: looks at the pinned mirror of the error flag if its last asynchronous read-back
+        has completed.  Called at the top of every device-side binning, so a slide with bad / NaN coords (which trains
+        with clamped positions, SE:198-211 would index out of bounds) raises at the latest one call later."""
+        ev = self._coord_err_event
+        if ev is not None and ev.query() and int(self._coord_err_host[0]) != 0:
+            self._coord_err.zero_()
+            self._coord_err_host.zero_()
+            raise ValueError("coords outside the slide_ngrids x slide_ngrids positional grid (or not finite) in an earlier slide")
 
     # ------------------------------------------------------------------ token-side pieces
     def _gene_encoder(self, genes: Sequence[torch.Tensor], passes: int = 1) -> Var:

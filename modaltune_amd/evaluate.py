@@ -82,4 +82,5 @@ def get_features(extractor: EmbeddingExtractor, slides: Iterable[Dict]) -> Tuple
     for s in slides:
         feats.append(extractor(s["x"], s["coords"], s["genes"], s.get("clinical")).float().cpu().numpy())
         ids.append(s.get("case_id"))
+    extractor.engine.check_inputs()       # the host has just synchronised on every slide's logits: raise for bad coords now
     return np.stack(feats) if feats else np.zeros((0,)), ids

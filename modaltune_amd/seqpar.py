@@ -17,7 +17,8 @@ MI355X form (one process per GPU, RCCL over xGMI; what differs from the referenc
   * branch outputs / LSEs are moved between the two row spaces by strided row copies (`mt_copy_rows_f32` with row maps), so the
     branch mix, the inner LayerNorm and the final combine see ordinary local tensors.
 Everything between the collectives is launched on the current stream through the C ABI; torch only allocates and runs the
-collectives.  Backends without reduce-scatter (gloo, used by the tests) fall back to all-reduce + slice.
+collectives -- the same calls on RCCL and on gloo (the rehearsal backend stages through host copies of the same fp16 payloads).
+NOT routed through `Engine`: ModalTune never enables seq_parallel (config.py:60), so this is the standalone op.
 """
 from __future__ import annotations
 
@@ -124,26 +125,61 @@ class SeqParallelAttention:
     def _from_group_rows(self, src, dst, segs: int, words: int, Ng: int):
         ops.copy_rows(src, dst, segs * self.L, words, smap=rowmap(self.L, Ng, 0))
 
+    # -- collectives: the SAME torch.distributed calls on every backend (all_gather_into_tensor, all_to_all_single, fp16
+    # payloads).  RCCL ("nccl") takes the device tensors as they are; gloo (the CPU / one-GPU rehearsals) takes host copies.
+    def _host_staged(self) -> bool:
+        return self.dist.get_backend(self.group) == "gloo"
+
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
         out = torch.empty((self.W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        if self.dist.get_backend(self.group) == "gloo":              # (gloo: no fp16 / device tensors in every build)
-            parts = [torch.empty_like(t, dtype=F32, device="cpu") for _ in range(self.W)]
-            self.dist.all_gather(parts, t.float().cpu(), group=self.group)
-            for r in range(self.W):
-                out[r].copy_(parts[r])
+        if self._host_staged():
+            h = torch.empty(out.shape, dtype=t.dtype)
+            self.dist.all_gather_into_tensor(h, t.cpu(), group=self.group)
+            out.copy_(h)
         else:
             self.dist.all_gather_into_tensor(out, t, group=self.group)
         return out
 
-    def _reduce_scatter(self, contrib: torch.Tensor) -> torch.Tensor:
-        """contrib fp32 [W, P] -> sum over ranks of row `rank` (Allgather.backward, TS/component/utils.py:60-80)."""
-        if self.dist.get_backend(self.group) == "gloo":
-            host = contrib.cpu()
-            self.dist.all_reduce(host, group=self.group)
-            return host[self.rank].to(contrib.device)
-        out = torch.empty(contrib.shape[1], dtype=contrib.dtype, device=contrib.device)
-        self.dist.reduce_scatter_tensor(out, contrib, group=self.group)
-        return out
+    def _exchange_plan(self):
+        """Who gets which slices of the dK / dV payload: rank rc receives, for every long branch k whose group holds both of
+        us, my partial sums for ITS chunk.  Groups are symmetric, so what I send to rc is as long as what rc sends to me."""
+        if getattr(self, "_xplan", None) is None:
+            per_dst = [[] for _ in range(self.W)]
+            k = 0
+            for g in self.groups:
+                for _ in g.branches:
+                    for rc in g.ranks:
+                        per_dst[rc].append(k)
+                    k += 1
+            sizes = [sum(self.pay_off[k + 1] - self.pay_off[k] for k in ks) for ks in per_dst]
+            self._xplan = (per_dst, sizes)
+        return self._xplan
+
+    def _exchange_sum(self, contrib: torch.Tensor) -> torch.Tensor:
+        """contrib fp16 [W, pay] (row rc = my partial dK / dV for rank rc's chunk) -> fp32 [pay]: the sum over the ranks of my
+        groups of THEIR row for me (Allgather.backward, TS/component/utils.py:60-80, is a reduce-scatter; here an all-to-all
+        of the fp16 partials restricted to the group members -- half the wire bytes of an fp32 reduce-scatter over all W
+        ranks, nothing sent to ranks outside the segment -- followed by an fp32 sum on the receiver)."""
+        per_dst, sizes = self._exchange_plan()
+        send = torch.cat([contrib[rc, self.pay_off[k]:self.pay_off[k + 1]] for rc in range(self.W) for k in per_dst[rc]])
+        recv = torch.empty_like(send)
+        if self._host_staged():
+            hs, hr = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
+            self.dist.all_to_all_single(hr, hs, sizes, sizes, group=self.group)
+            recv.copy_(hr)
+        else:
+            self.dist.all_to_all_single(recv, send, sizes, sizes, group=self.group)
+        red = self._new(self.pay, dtype=F32, zero=True)
+        tmp = self._new(self.pay, dtype=F32)
+        off = 0
+        for src in range(self.W):
+            for k in per_dst[src]:
+                n = self.pay_off[k + 1] - self.pay_off[k]
+                ops.cast_f16_to_f32(recv[off:off + n], tmp[:n], n)
+                dst = red[self.pay_off[k]:self.pay_off[k + 1]]
+                ops.axpy(dst, tmp[:n], 1.0, dst, n)
+                off += n
+        return red
 
     # ------------------------------------------------------------------ forward
     def forward(self, qkv_hm: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor):
@@ -188,7 +224,7 @@ class SeqParallelAttention:
         if self.plan_loc is not None:
             ops.dilated_attn_bwd_phases(qkv_hm, dmixed, lse_tot, delta_br, self.plan_loc, ws, dqkv, ops.ATTN_BWD_KV | ops.ATTN_BWD_Q)
         if self.groups:
-            contrib = self._new(self.W, self.pay, zero=True)                     # fp16 entries, reduced in fp32 below
+            contrib = self._new(self.W, self.pay, zero=True)                     # fp16 entries, summed in fp32 by the receiver
             k = 0
             for g, S in zip(self.groups, slabs):
                 Ng = g.size * L
@@ -211,9 +247,7 @@ class SeqParallelAttention:
                         ops.copy_rows(ent, _f32(contrib[rc, self.pay_off[k]:self.pay_off[k + 1]]), B * H * nq, 72,
                                       smap=rowmap(nq, ng, c * nq))
                     k += 1
-            c32 = self._new(self.W, self.pay, dtype=F32)
-            ops.cast_f16_to_f32(contrib, c32)
-            red = self._reduce_scatter(c32)                                      # [pay] fp32: sum over the ranks
+            red = self._exchange_sum(contrib)                                    # [pay] fp32: sum over the ranks of my groups
             red16 = self._new(self.pay)
             ops.cast_f32_to_f16(red, red16)
             k = 0

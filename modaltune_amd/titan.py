@@ -119,9 +119,11 @@ class TorchBackbone:
 
     @staticmethod
     def backward(handle, dy: torch.Tensor) -> torch.Tensor:
+        """fp32 activation gradient of a recorded call (the block may have run under autocast: dy is cast to the output's
+        dtype, dx comes back in the input's and is returned as fp32)."""
         x, y = handle
-        (dx,) = torch.autograd.grad(y, x, dy)
-        return dx
+        (dx,) = torch.autograd.grad(y, x, dy.to(y.dtype))
+        return dx.to(F32)
 
     def pool(self, h: torch.Tensor, mask, need_grad: bool):
         """norm + forward_attn_pool (TA:400-402): [B, N, D] -> (image token [B, D], handle)."""
@@ -187,8 +189,9 @@ class TitanEngine(Engine):
         ctx, ws, D = self._ctx, self._ctx["ws"], self.cfg.embed_dim
         B, N, M = ctx["B"], ctx["N"], ctx["M"]
         bb, need = self.backbone, self._need
-        y, handle = bb.block(l, ws[f"hin{l}"].view(B, N, D), self._bias, None, need)
-        ops.copy_rows(y.reshape(M, D).contiguous(), out, M, D)
+        # the reference hands the cls-prefixed bg_mask to every block: blk(x, attn_bias, bg_mask) (adapter_modules.py:535)
+        y, handle = bb.block(l, ws[f"hin{l}"].view(B, N, D), self._bias, self._mask, need)
+        ops.copy_rows(y.to(F32).reshape(M, D).contiguous(), out, M, D)      # (a half-precision block output is widened first)
 
         def bwd():
             dh = ws["dh"]
@@ -202,7 +205,7 @@ class TitanEngine(Engine):
         ctx, D = self._ctx, self.cfg.embed_dim
         B, N, M, ws = ctx["B"], ctx["N"], ctx["M"], ctx["ws"]
         bb = self.backbone
-        pooled, handle = bb.pool(hout.view(B, N, D), None, self._need)
+        pooled, handle = bb.pool(hout.view(B, N, D), self._mask, self._need)      # forward_attn_pool(x, bg_mask=bg_mask), TA:402
         img = Var(pooled.to(F32).contiguous())
 
         def bwd():

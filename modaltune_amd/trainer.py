@@ -68,7 +68,8 @@ class TrainStep:
         # captured graphs: LRU over bag geometries (real data has a new length almost every slide: a geometry is captured
         # only once it has been seen `capture_after` times, everything else runs the eager schedule)
         self.graph_cache_size, self.capture_after = int(graph_cache_size), int(capture_after)
-        self._gcache: "OrderedDict[tuple, _Captured]" = OrderedDict()
+        self._gcache: "OrderedDict[tuple, _Captured]" = OrderedDict()      # LRU over geometries that HOLD captured graphs
+        self._visits: Dict[tuple, int] = {}        # eager visits of not-yet-captured geometries (never evicts a capture)
         self._ggen = -1
         self._opt_graph = None
         self._cap = None                    # state of a segmented capture in progress
@@ -153,7 +154,10 @@ class TrainStep:
             ops.copy_rows(drows[0:1], dlogits, 1, O)
             for r in range(1, R):
                 ops.copy_rows(drows[r:r + 1], dlogits, 1, O, accumulate=True)
-        eng.backward(dlogits)
+        try:
+            eng.backward(dlogits)
+        finally:
+            eng.grad_ready_hook = None        # a later direct eng.forward / backward must not start stray collectives
 
     def _adam_and_refresh(self, world: int):
         eng = self.engine
@@ -213,25 +217,30 @@ class TrainStep:
             self._ggen = eng.generation
         key = (L, world, bool(eng.stochastic))
         ent = self._gcache.get(key)
-        if ent is None:
-            ent = _Captured()
-            self._gcache[key] = ent
-            while len(self._gcache) > max(1, self.graph_cache_size):
-                self._gcache.popitem(last=False)
-        else:
-            self._gcache.move_to_end(key)
 
         def fwd_bwd():
             self._fwd_bwd(None, None, self._sgenes, self._stext, self._sclin, staged_geometry=(B, L))
 
-        if ent.segs is None and ent.visits < self.capture_after:      # eager visits (allocator, lazy kernel attributes,
-            ent.visits += 1                                            # the tape's gradient arena sized from the last step)
-            fwd_bwd()
-            self.eager_steps += 1
-            self.optimizer_step()
-            return self.loss
-        if ent.segs is None:
+        # Visit counts live OUTSIDE the LRU: on ragged data almost every slide has a new length, and a stream of one-off
+        # lengths must neither evict the captured graphs of a hot geometry nor reset its count.
+        if ent is None or ent.segs is None:
+            seen = self._visits.get(key, 0)
+            if seen < self.capture_after:         # eager visits (allocator, lazy kernel attributes, the tape's gradient arena
+                if len(self._visits) > 4096:      # sized from the last step)
+                    self._visits.clear()
+                self._visits[key] = seen + 1
+                fwd_bwd()
+                self.eager_steps += 1
+                self.optimizer_step()
+                return self.loss
+            if ent is None:
+                ent = _Captured()
+                self._gcache[key] = ent
+                while len(self._gcache) > max(1, self.graph_cache_size):
+                    self._gcache.popitem(last=False)
             self._capture(ent, fwd_bwd, world)
+        else:
+            self._gcache.move_to_end(key)
         for g, bucket in ent.segs:
             g.replay()
             if bucket is not None:
@@ -294,6 +303,13 @@ class TrainStep:
         g = torch.cuda.CUDAGraph()
         g.capture_begin(pool=cap["pool"], capture_error_mode="thread_local")
         cap["cur"] = g
+
+    def loss_value(self) -> float:
+        """The last step's loss on the host.  This is where the trainer synchronises anyway (`loss.item()`, TM:239), so the
+        deferred input check (bad / non-finite coords binned on the device) is raised here too."""
+        v = float(self.loss)
+        self.engine.check_inputs()
+        return v
 
     def unscaled_grads(self) -> Dict[str, torch.Tensor]:
         s = float(self.scale)

@@ -1,7 +1,8 @@
 """Rank process of the multi-process GPU tests (tests/test_dp_gpu.py): `python tests/dp_worker.py MODE RANK WORLD PORT OUT`.
 
-Every rank uses GPU 0 and the gloo backend (one GPU per box; RCCL refuses two ranks on one device) -- the code path
-is the one `torch.distributed` runs over RCCL on a real node: dp.GradReducer's async all-reduces from inside the backward,
+By default every rank uses GPU 0 and the gloo backend (one GPU per box; RCCL refuses two ranks on one device); with
+MT_TEST_BACKEND=nccl (set by the tests when the box has >= WORLD GPUs) rank r takes GPU r over RCCL -- the code path
+is the same either way: dp.GradReducer's async all-reduces from inside the backward,
 segmented hipGraph capture, DistributedDataParallel's reducer hooks on the nn.Module bridge.
 """
 import os
@@ -78,7 +79,7 @@ def ddp_module(rank, world, out):
     local = torch.cat([params[k].grad.reshape(-1) for k in names]).clone()
     for k in names:
         params[k].grad = None
-    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[torch.cuda.current_device()])
     loss_of(ddp).backward()
     torch.cuda.synchronize()
     avg = torch.cat([params[k].grad.reshape(-1) for k in names]).clone()
@@ -94,8 +95,12 @@ def ddp_module(rank, world, out):
 if __name__ == "__main__":
     mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("MT_TEST_BACKEND", "gloo") == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         {"trainstep": trainstep, "ddp_module": ddp_module}[mode](rank, world, out)
     finally:

@@ -52,6 +52,10 @@ class _Block(nn.Module):
 
     def forward(self, x, attn_bias=None, bg_mask=None):
         B, N, D = x.shape
+        # the reference passes the cls-prefixed background mask of the WHOLE grid to every block (adapter_modules.py:535):
+        # [1, 1 + w * h] bool, cls kept, exactly N entries set (the tokens were already filtered with it, TA:282-291)
+        assert bg_mask is not None and bg_mask.dtype == torch.bool and bg_mask.dim() == 2 and bool(bg_mask[0, 0])
+        assert int(bg_mask.sum()) == N, (int(bg_mask.sum()), N)
         q, k, v = self.qkv(self.norm1(x)).view(B, N, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         s = q @ k.transpose(-1, -2) * (D // self.heads) ** -0.5
         if attn_bias is not None:
@@ -103,6 +107,7 @@ class VisionTransformer(nn.Module):
         return torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)      # ALiBi: no additive position table
 
     def forward_attn_pool(self, x, bg_mask=None):
+        assert bg_mask is not None and bg_mask.dtype == torch.bool and int(bg_mask.sum()) == x.shape[1]      # TA:402
         q = self.pool_query.expand(x.shape[0], -1, -1)
         out, _ = self.pool_attn(q, x, x, need_weights=False)
         return self.pool_norm(out[:, 0]), x

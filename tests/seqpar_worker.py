@@ -1,7 +1,7 @@
 """Rank process of the sequence-parallel attention test (tests/test_seqpar_gpu.py):
-`python tests/seqpar_worker.py CASE RANK WORLD PORT OUT`.  Every rank uses GPU 0 over gloo (one GPU per box); the collectives are
-the ones `torch.distributed` runs over RCCL on a node (modaltune_amd/seqpar.py falls back to all-reduce where the backend
-has no reduce-scatter)."""
+`python tests/seqpar_worker.py CASE RANK WORLD PORT OUT`.  Default: every rank uses GPU 0 over gloo (one GPU per box); with
+MT_TEST_BACKEND=nccl (set by the tests when the box has >= WORLD GPUs) rank r takes GPU r and the collectives run over RCCL.
+modaltune_amd/seqpar.py issues the same torch.distributed calls on both (gloo through host copies of the fp16 payloads)."""
 import os
 import sys
 
@@ -43,8 +43,13 @@ def rounded(case):
 def main():
     case, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    backend = os.environ.get("MT_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
     from modaltune_amd.seqpar import SeqParallelAttention
     W, B, L, segs, ratios = CASES[case]
     assert W == world

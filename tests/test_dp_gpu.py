@@ -31,10 +31,10 @@ def _free_port():
     return p
 
 
-def _run_ranks(mode, tmp_path, world=2, timeout=600):
+def _run_ranks(mode, tmp_path, world=2, timeout=600, backend="gloo"):
     port = str(_free_port())
-    outs = [str(tmp_path / f"{mode}_{r}.npz") for r in range(world)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    outs = [str(tmp_path / f"{mode}_{backend}_{r}.npz") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MT_TEST_BACKEND=backend)
     procs = [subprocess.Popen([sys.executable, WORKER, mode, str(r), str(world), port, outs[r]], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
@@ -50,15 +50,31 @@ def _run_ranks(mode, tmp_path, world=2, timeout=600):
     return [np.load(o) for o in outs]
 
 
+def _need_gpus(n):
+    """RCCL tests: one rank per GPU.  They skip cleanly on the 1-GPU boxes and run the moment a box has n GPUs."""
+    if torch.cuda.device_count() < n:
+        pytest.skip(f"needs {n} GPUs for one rank per GPU over RCCL (found {torch.cuda.device_count()})")
+
+
 def test_two_rank_trainstep_matches_gradient_averaging(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    _check_trainstep(_run_ranks("trainstep", tmp_path))
+
+
+def test_two_rank_trainstep_over_rccl(tmp_path):
+    """(a) over RCCL, one rank per GPU: GradReducer's async collectives between segmented hipGraph replays on RCCL's stream."""
+    _need_gpus(2)
+    _check_trainstep(_run_ranks("trainstep", tmp_path, backend="nccl"))
+
+
+def _check_trainstep(results):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dp_worker as W
     from modaltune_amd import synth
     from modaltune_amd.engine import Engine
     from modaltune_amd.trainer import TrainStep
-    r0, r1 = _run_ranks("trainstep", tmp_path)
+    r0, r1 = results
     assert int(r0["steps"]) == W.STEPS and int(r0["replays"]) == W.STEPS - 1      # one eager visit, then capture + replays
     assert int(r0["nseg"]) == int(r0["buckets"]) == 4                              # the backward was cut at every bucket boundary
     assert np.array_equal(r0["flat"], r1["flat"])                                  # same reduced gradient -> same weights, bitwise
@@ -108,7 +124,17 @@ def synth_flat(eng, cfg, sizes, seed):
 def test_module_under_distributed_data_parallel(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    r0, r1 = _run_ranks("ddp_module", tmp_path)
+    _check_ddp(_run_ranks("ddp_module", tmp_path))
+
+
+def test_module_under_distributed_data_parallel_over_rccl(tmp_path):
+    """(b) over RCCL: DistributedDataParallel(device_ids=[rank]) around the nn.Module bridge, one rank per GPU."""
+    _need_gpus(2)
+    _check_ddp(_run_ranks("ddp_module", tmp_path, backend="nccl"))
+
+
+def _check_ddp(results):
+    r0, r1 = results
     mean = 0.5 * (r0["local"].astype(np.float64) + r1["local"].astype(np.float64))
     scale = np.abs(mean).max()
     for r in (r0, r1):
@@ -121,9 +147,20 @@ def test_module_under_distributed_data_parallel(tmp_path):
 def test_bench_launches_its_own_ranks():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    _check_bench("gloo")
+
+
+def test_bench_two_gpus_over_rccl():
+    """(d) `bench.py --gpus 2` over RCCL: fresh rank processes, one per GPU; the step must run as hipGraph replays (a capture
+    failure with world > 1 exits non-zero instead of silently timing eager launches)."""
+    _need_gpus(2)
+    _check_bench("nccl")
+
+
+def _check_bench(backend):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--patches", "1024",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", backend, "--patches", "1024",
                         "--steps", "3", "--warmup", "3", "--no-cpu-baseline"], env=env, capture_output=True, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]

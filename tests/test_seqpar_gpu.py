@@ -26,10 +26,10 @@ def _free_port():
     return p
 
 
-def _run(case, world, tmp_path, timeout=600):
+def _run(case, world, tmp_path, timeout=600, backend="gloo"):
     port = str(_free_port())
-    outs = [str(tmp_path / f"{case}_{r}.npz") for r in range(world)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    outs = [str(tmp_path / f"{case}_{backend}_{r}.npz") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MT_TEST_BACKEND=backend)
     procs = [subprocess.Popen([sys.executable, WORKER, case, str(r), str(world), port, outs[r]], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
@@ -54,10 +54,25 @@ def rel(a, b):
 def test_sequence_parallel_attention_matches_oracle(case, tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    _check(case, tmp_path, "gloo")
+
+
+@pytest.mark.parametrize("case", ["w2", "big2", "big4"])
+def test_sequence_parallel_attention_over_rccl(case, tmp_path):
+    """(c) one rank per GPU over RCCL: all_gather_into_tensor of the k | v slab and the fp16 all_to_all_single of the dK / dV
+    partials on device tensors.  Skips on boxes with fewer GPUs than ranks."""
+    import seqpar_worker as SW
+    W = SW.CASES[case][0]
+    if torch.cuda.device_count() < W:
+        pytest.skip(f"needs {W} GPUs for one rank per GPU over RCCL (found {torch.cuda.device_count()})")
+    _check(case, tmp_path, "nccl")
+
+
+def _check(case, tmp_path, backend):
     import seqpar_worker as SW
     from oracle import modaltune_oracle as O
     W, B, L, segs, ratios = SW.CASES[case]
-    got = _run(case, W, tmp_path)
+    got = _run(case, W, tmp_path, backend=backend)
     q16, k16, v16, dy16 = SW.rounded(case)
     qs = [(q16[r].double() / SW.QK).requires_grad_(True) for r in range(W)]
     ks = [k16[r].double().requires_grad_(True) for r in range(W)]
