@@ -152,6 +152,14 @@ int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, int in_dtype
 int mt_add_layernorm_fwd(const float* x, const mt_half* branch, const MtDropout* drop, const float* w, const float* b,
                          float* h, mt_half* y, float* stats, int M, int D, mt_stream_t stream);
 
+/* The same two launchers with an explicit epsilon (the entries above use the reference's 1e-5, ENC / AM / GE LayerNorms; the
+ * TITAN ViT's LayerNorms carry their own `eps`, e.g. timm's 1e-6).  The backward needs no epsilon: it reads the saved rstd. */
+int mt_layernorm_fwd_eps(const void* x, long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in, const float* w,
+                         const float* b, const float* add_rows, int add_period, void* y, long ldy, const MtRowMap* ymap,
+                         int out_dtype, float* stats, int M, int D, float eps, mt_stream_t stream);
+int mt_add_layernorm_fwd_eps(const float* x, const mt_half* branch, const MtDropout* drop, const float* w, const float* b,
+                             float* h, mt_half* y, float* stats, int M, int D, float eps, mt_stream_t stream);
+
 /* dx (+)= LN backward.  dy fp16 or fp32 [M,D]; x as in forward (gelu_in: also backprop through the GELU).
  * dx_dtype F32 with accumulate=1 adds into the fp32 residual-gradient stream (ENC:137-154 backward);
  * dw/db (fp32 [D], atomically accumulated) may be NULL for frozen norms (selective backward).
@@ -211,6 +219,47 @@ long mt_dilated_attn_bwd_workspace_bytes(const MtDilatedPlan* plan);
 enum { MT_ATTN_BWD_KV = 1, MT_ATTN_BWD_Q = 2, MT_ATTN_BWD_COMBINE = 4, MT_ATTN_BWD_ALL = 7 };   /* `phases` mask */
 int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot, const float* delta_br,
                         const MtDilatedPlan* plan, void* workspace, mt_half* dqkv, int phases, mt_stream_t stream);
+
+/* ------------------------------------------------- dense attention with 2-D ALiBi (TITAN blocks) ---- */
+/* The attention of the TITAN slide encoder's ViT blocks (titan_adapter.py:253-293 `get_alibi`, :359-361,394
+ * `blocks.modules_list[i](x, attn_bias, bg_mask)`; adapter_modules.py:526-558): H heads of 64 over one sequence of N tokens
+ * per pass (cls + the slide's foreground cells), softmax(q k^T / 8 + bias) v with bias[h, i, j] = -slope_h * euclidean distance
+ * of the tokens' grid cells (0 to and from cls).  The bias is computed inside the kernels from two [N, 8] fp16 side tables
+ * (mt_alibi_pos) -- the squared distance comes off one extra MFMA k-step, exactly -- instead of a [H, N, N] table.
+ * qkv: fp16 TOKEN-MAJOR [B*N, 3*H*64] (q' | k | v) as the qkv GEMM writes it, q' = MT_DENSE_QK_SCALE_LOG2 * q (the caller
+ * bakes 64^-1/2 log2(e) into the q rows of the frozen qkv weight / bias).  o: fp16 [B*N, H*64]; lse: fp32 [B*N, H] (natural
+ * log, bias included). */
+#define MT_DENSE_QK_SCALE_LOG2 0.18033688011112042f     /* 64^-1/2 * log2(e) */
+typedef struct {
+  int N;                 /* tokens per pass */
+  int B;                 /* task passes batched */
+  int H;                 /* heads (head dim 64) */
+  const mt_half* posk;   /* [N, 8] key-side table, or NULL (with posq): no bias */
+  const mt_half* posq;   /* [N, 8] query-side table */
+  const float* nslope;   /* [H]: -slope_h * log2(e) */
+} MtDensePlan;
+/* posk / posq rows of token i (row 0 = cls: zeros) from cells[i - 1] = (row, col) of its grid cell, centred at dims / 2
+ * (dims: DEVICE int[2] = {H, W} as mt_titan_grid wrote them); *err |= 2 if a centred coordinate leaves [-1024, 1024]. */
+int mt_alibi_pos(const int* cells, int N, const int* dims, mt_half* posk, mt_half* posq, int* err, mt_stream_t stream);
+int mt_dense_attn_fwd(const mt_half* qkv, const MtDensePlan* plan, mt_half* o, float* lse, mt_stream_t stream);
+/* dqkv fp16 [B*N, 3*H*64] (overwritten; q columns = gradient of the pre-scaled q') from qkv, o, dO (fp16 [B*N, H*64]) and lse.
+ * delta: fp32 [B*N, H] workspace (sum_d dO * O, written by the DELTA phase).  The bias carries no gradient.  Every output
+ * element is written exactly once: no atomics, no combine pass. */
+enum { MT_DENSE_BWD_DELTA = 1, MT_DENSE_BWD_KV = 2, MT_DENSE_BWD_Q = 4, MT_DENSE_BWD_ALL = 7 };
+int mt_dense_attn_bwd(const mt_half* qkv, const mt_half* o, const mt_half* d_o, const float* lse, const MtDensePlan* plan,
+                      float* delta, mt_half* dqkv, int phases, mt_stream_t stream);
+
+/* y = gelu(x) (erf form, nn.GELU) / dx = dy * gelu'(x) on fp16 vectors, n % 8 == 0: the ViT block's MLP activation */
+int mt_gelu_f16_fwd(const mt_half* x, mt_half* y, long n, mt_stream_t stream);
+int mt_gelu_f16_bwd(const mt_half* x, const mt_half* dy, mt_half* dx, long n, mt_stream_t stream);
+
+/* Attentional pooling core (TA:401-402 `forward_attn_pool`): nq learned queries attend over the N tokens of every pass.
+ * q fp32 [nq, E] (projected; frozen, so no dq); kv fp16 [B*N, 2E] (k | v projected); out fp32 [B, nq, E]; probs fp32
+ * [B, heads, nq, N] (saved).  backward: dkv fp16 [B*N, 2E] (overwritten). */
+int mt_pool_attn_fwd(const float* q, const mt_half* kv, int B, int N, int E, int heads, int nq, float* out, float* probs,
+                     mt_stream_t stream);
+int mt_pool_attn_bwd(const float* q, const mt_half* kv, const float* probs, const float* dout, int B, int N, int E, int heads,
+                     int nq, mt_half* dkv, mt_stream_t stream);
 
 /* ------------------------------------------------------------ adapter ops -------------------------- */
 /* Injector attention core (AM:225-229 inside AM:359-369): for each of M patch rows and 12 heads (dim 16):
@@ -323,10 +372,27 @@ int mt_axpy_dev(const float* a, const float* b, const float* alpha, float* y, lo
  * the host raises when it next looks (the reference would index out of bounds, SE:116-120,237). */
 int mt_coords_to_grid(const float* coords, int L, float tile, int ngrids, int* prow, int* pcol, int* err,
                       mt_stream_t stream);
-/* TITAN feature gridding (titan_adapter.py:295-327, preprocess_features): dst(idx[m], :) (+)= src(src_idx[m], :) for fp32
- * rows of D (index_add of the patch features into their grid cells; idx computed by the host: floor((coords - min) /
- * patch_size); src_idx NULL = identity).  The caller launches one pass per occurrence rank of a cell, so the cells of a
- * pass are distinct and the sums come out in patch order (bitwise reproducible, as index_add_ on the CPU).
+/* TITAN feature gridding on the device (titan_adapter.py:295-327 `preprocess_features` + the background drop of
+ * `prepare_forward_features`, TA:282-291) WITHOUT materialising the H x W grid: the tokens of a slide are its occupied cells
+ * in row-major order, each the sum of its patches' features in patch order (what index_add_ produces on the CPU, bitwise
+ * reproducible: no atomics, no sort -- O(L^2) integer compares through LDS).
+ *   mt_titan_grid         cells[i] = floor((coords[i] - min coords) / patch) (fp32 coords [L, 2]); dims (device int[2]) = {H, W};
+ *                         *err |= 1 for non-finite / out-of-range coordinates
+ *   mt_titan_cell_sums    first[i] / next[i]: chain of the patches of one cell in patch order; sums[i, :] (fp32 [L, C]) = the cell's
+ *                         summed features for its first patch; nz[i] = any(sum != 0) (the reference's bg_mask, TA:326)
+ *   mt_titan_token_order  pos[i] = token index (without cls) of the cell patch i owns, or -1; cells_tok[pos] = (row, col);
+ *                         *count = number of tokens
+ *   mt_titan_gather_tokens x16[pos[i], :] = fp16(sums[i, :]): the A operand of the patch-embedding GEMM */
+int mt_titan_grid(const float* coords, int L, float patch, int* cells, int* dims, int* err, mt_stream_t stream);
+int mt_titan_cell_sums(const float* feat, long ldf, const int* cells, int L, int C, int* first, int* next, float* sums, int* nz,
+                       mt_stream_t stream);
+int mt_titan_token_order(const int* cells, const int* first, const int* nz, int L, int* pos, int* cells_tok, int* count,
+                         mt_stream_t stream);
+int mt_titan_gather_tokens(const float* sums, const int* pos, int L, int C, mt_half* x16, mt_stream_t stream);
+/* The same index_add as one strided scatter (host-computed indices): the bring-your-own-backbone path of modaltune_amd/titan.py,
+ * which must hand the backbone module the dense [1, C, H, W] grid its own `prepare_forward_features` expects.
+ * dst(idx[m], :) (+)= src(src_idx[m], :) for fp32 rows of D (src_idx NULL = identity); the caller launches one pass per
+ * occurrence rank of a cell, so the cells of a pass are distinct.
  * mt_row_absmax_f32: out[m] = max_d |x(m, d)| (the background mask is "any feature of the cell != 0", TA:326). */
 int mt_scatter_rows_f32(const float* src, const int* src_idx, const int* idx, float* dst, int M, int D, int accumulate,
                         mt_stream_t stream);

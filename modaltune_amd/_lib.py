@@ -48,10 +48,15 @@ class MtDilatedPlan(C.Structure):
                 ("nseg", I * MT_MAX_BRANCHES), ("n", I * MT_MAX_BRANCHES), ("qlimit", I * MT_MAX_BRANCHES)]
 
 
+class MtDensePlan(C.Structure):
+    _fields_ = [("N", I), ("B", I), ("H", I), ("posk", P), ("posq", P), ("nslope", P)]
+
+
 RM = C.POINTER(MtRowMap)
 DR = C.POINTER(MtDropout)
 EP = C.POINTER(MtGemmEpilogue)
 PL = C.POINTER(MtDilatedPlan)
+DP = C.POINTER(MtDensePlan)
 
 # name -> argtypes (restype int unless listed in _RESTYPE)
 SIGNATURES = {
@@ -64,6 +69,8 @@ SIGNATURES = {
     "mt_sgemm_multi": [C.POINTER(MtSgemm), I, P],
     "mt_layernorm_fwd": [P, L, RM, I, I, P, P, P, I, P, L, RM, I, P, I, I, P],
     "mt_add_layernorm_fwd": [P, P, DR, P, P, P, P, P, I, I, P],
+    "mt_layernorm_fwd_eps": [P, L, RM, I, I, P, P, P, I, P, L, RM, I, P, I, I, F, P],
+    "mt_add_layernorm_fwd_eps": [P, P, DR, P, P, P, P, P, I, I, F, P],
     "mt_layernorm_bwd": [P, L, RM, I, P, L, RM, I, I, P, P, P, L, RM, I, I, P, P, P, DR, I, I, P],
     "mt_dilated_attn_fwd": [P, PL, P, P, P],
     "mt_dilated_mix_ln_fwd": [P, P, PL, P, P, P, P, P, P],
@@ -99,6 +106,17 @@ SIGNATURES = {
     "mt_absmax_scale": [P, L, F, P, P],
     "mt_axpy_dev": [P, P, P, P, L, P],
     "mt_coords_to_grid": [P, I, F, I, P, P, P, P],
+    "mt_alibi_pos": [P, I, P, P, P, P, P],
+    "mt_dense_attn_fwd": [P, DP, P, P, P],
+    "mt_dense_attn_bwd": [P, P, P, P, DP, P, P, I, P],
+    "mt_gelu_f16_fwd": [P, P, L, P],
+    "mt_gelu_f16_bwd": [P, P, P, L, P],
+    "mt_pool_attn_fwd": [P, P, I, I, I, I, I, P, P, P],
+    "mt_pool_attn_bwd": [P, P, P, P, I, I, I, I, I, P, P],
+    "mt_titan_grid": [P, I, F, P, P, P, P],
+    "mt_titan_cell_sums": [P, L, P, I, I, P, P, P, P, P],
+    "mt_titan_token_order": [P, P, P, I, P, P, P, P],
+    "mt_titan_gather_tokens": [P, P, I, I, P, P],
     "mt_scatter_rows_f32": [P, P, P, P, I, I, I, P],
     "mt_row_absmax_f32": [P, P, I, I, P],
 }

@@ -1,0 +1,613 @@
+// Dense multi-head flash attention with an in-kernel 2-D ALiBi bias: the attention of the TITAN slide encoder's pre-norm ViT
+// blocks (reference call sites: models/aggregators/titan_adapter.py:253-293 `get_alibi`, :359-361,394
+// `blocks.modules_list[i](x, attn_bias, bg_mask)`; models/vitadapter/adapter_modules.py:526-558).  H heads of 64, one
+// sequence of N tokens per task pass (cls + the slide's foreground cells), no dilation, no padding keys.
+//
+// Layout: q | k | v stay TOKEN-MAJOR, exactly as the qkv GEMM writes them ([B*N, 3*H*64] fp16): with a head dimension of 64 a
+// head's row is one aligned 128-byte line, so a 64-key tile is 64 full lines whatever the row stride -- no head-major epilogue,
+// no combine pass; o, dO and dq | dk | dv are token-major too and feed / come from plain GEMMs.
+//
+// ALiBi: bias[h, i, j] = -slope_h * |cell_i - cell_j| (euclidean, in grid cells; 0 to and from cls).  A [H, N, N] table would
+// cost more HBM traffic than K and V together (N = 4097: 805 MB per layer and pass), so the squared distance is produced ON THE
+// MATRIX PIPE from two [N, 8] fp16 side tables (mt_alibi_pos): a_k = [x, y, n0, n1, n2, 1, 64, 4096] and
+// b_q = [-2x, -2y, 1, 64, 4096, n0, n1, n2] with n = x^2 + y^2 = n0 + 64 n1 + 4096 n2, so that a_k . b_q = |p_k - p_q|^2
+// EXACTLY (all operands are integers below 2^11 or powers of two, the fp32 accumulation is exact below 2^24; |x|, |y| <= 1024
+// after centring); cls carries all-zero rows, which zeroes its row and column.  One extra MFMA k-step per 32 keys, then
+// s += nslope_h * sqrt(d2) on the VALU (nslope_h = -slope_h log2 e: the logits live in log2 units).
+//
+// Kernel structure = the dilated kernels of attn.hip: swapped products with the query (forward, dQ) or the key (dK / dV) in the
+// lane, 64-row LDS-DMA tile images with XOR-swizzled 16-byte chunks (attn_common.h: img_off -- all eight chunks are data here),
+// double-buffered, one barrier per tile; q pre-scaled by 64^-1/2 log2 e inside the frozen qkv weight cache; per-query constants
+// as initial accumulators; deferred exact rescale; P from the accumulators as the next operand.  The row sum is accumulated on
+// the VALU (there is no spare column for a ones trick at d = 64).
+#include "attn_common.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int PIMG = 64 * 8;          // halves per positional tile image: 64 rows x 16 B
+
+struct DenseArgs {
+  const h16* qkv; long ld;            // [B*N, ld]: q at column 0, k at D, v at 2 D (D = H * 64); ld = 3 D
+  const h16* posk; const h16* posq;   // [N, 8] each (mt_alibi_pos), or nullptr: no bias
+  const float* nslope;                // [H]: -slope_h * log2(e)
+  int N, B, H, D, qtiles;
+};
+
+struct DItem { int b, h, qt; bool live; };
+// Workgroup -> (pass, head, 128-row tile): blocks b and b + 8 share an XCD, so XCD x walks the (pass, head) groups x, x + 8, ...
+// with the tiles of a group back to back: every tile of a group re-reads the same K / V rows from ONE L2.
+MT_DEVINL DItem ddecode(const DenseArgs& a, int bid) {
+  const int x = bid & 7, j = bid >> 3;
+  DItem w;
+  w.qt = __builtin_amdgcn_readfirstlane(j % a.qtiles);
+  const int gid = __builtin_amdgcn_readfirstlane((j / a.qtiles) * 8 + x);
+  w.live = gid < a.B * a.H;
+  w.h = __builtin_amdgcn_readfirstlane(gid % a.H);
+  w.b = __builtin_amdgcn_readfirstlane(gid / a.H);
+  return w;
+}
+
+struct DmaLane64 {      // this thread's two 16-byte pieces of a [64][128 B] tile image: piece p = 2 * wave + i covers rows 8p..8p+7
+  uint32_t voff[2]; int lds_halves[2];
+  MT_DEVINL DmaLane64(int tid, int row_stride_bytes) {
+    const int wave = tid >> 6, j = tid & 63;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = 2 * wave + i, row = 8 * piece + (j >> 3);
+      const int c = (j & 7) ^ img_f(row);
+      voff[i] = (uint32_t)(row * row_stride_bytes + c * 16);
+      lds_halves[i] = piece * 512;
+    }
+  }
+};
+MT_DEVINL void dma_tile64(h16* img, __amdgpu_buffer_rsrc_t rs, const DmaLane64& d) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + d.lds_halves[i]), 16, d.voff[i], 0, 0, 0);
+}
+// positional tile image: 64 rows x 16 B = one 1-KiB piece, issued by the first wave
+MT_DEVINL void dma_pos(h16* img, const h16* tab, int t, int N, int lane) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(tab, (long)t * 1024, (long)N * 16),
+                                           (__attribute__((address_space(3))) void*)img, 16, (uint32_t)(lane * 16), 0, 0, 0);
+}
+MT_DEVINL f32x16 splat16(float v) {
+  f32x16 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = v;
+  return r;
+}
+MT_DEVINL float sum_halves(float x) { return x + __shfl_xor(x, 32, 64); }
+
+// ------------------------------------------------------------------------------------------------ forward
+template <bool BIAS>
+__global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseArgs a, h16* __restrict__ o, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // K0 | K1 | V0 | V1
+  __shared__ __attribute__((aligned(16))) h16 pos_s[2 * PIMG + 8];       // key a_k tiles (two buffers) + a zero chunk
+  h16* const Ks = smem;
+  h16* const Vs = smem + 2 * IMG_HALVES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const DItem w = ddecode(a, blockIdx.x);
+  if (!w.live) return;
+  const int N = a.N;
+  const long ld = a.ld;
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid == 0) *reinterpret_cast<h16x8*>(&pos_s[2 * PIMG]) = zero8;
+
+  const int iq = w.qt * 128 + wave * 32 + l31;
+  const bool qvalid = iq < N;
+  const long qrow = (long)w.b * N + min(iq, N - 1);
+  h16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = sel8(qvalid, ldg8(a.qkv + qrow * ld + w.h * DH + ks * 16 + hh * 8));
+  h16x8 pqf = zero8;
+  float nslope = 0.f;
+  if (BIAS) {
+    pqf = sel8(qvalid && hh == 0, ldg8(a.posq + (long)min(iq, N - 1) * 8));
+    nslope = a.nslope[w.h];
+  }
+
+  const int ntile = (N + 63) >> 6;
+  const int row_bytes = (int)ld * 2;
+  const long valid_bytes = (long)(N - 1) * row_bytes + DH * 2;
+  const long tile_bytes = 64L * row_bytes;
+  const h16* const kseq = a.qkv + (long)w.b * N * ld + a.D + w.h * DH;
+  const h16* const vseq = kseq + a.D;
+  const DmaLane64 dl(tid, row_bytes);
+  auto dma = [&](int t) {
+    dma_tile64(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), dl);
+    dma_tile64(Vs + (t & 1) * IMG_HALVES, tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl);
+    if (BIAS && tid < 64) dma_pos(pos_s + (t & 1) * PIMG, a.posk, t, N, lane);
+  };
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  int krd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) krd[ks] = img_off(l31, 2 * ks + hh);
+  const int vc = 2 * (grp & 1) + (tp >> 1), vo = 4 * (tp & 1);
+  const int va0 = img_off(4 * hh + tq, vc) + vo, va1 = img_off(4 * hh + tq, vc + 4) + vo;
+  const int vb0 = img_off(4 * hh + tq + 8, vc) + vo, vb1 = img_off(4 * hh + tq + 8, vc + 4) + vo;
+
+  // logits of one 64-key tile in log2 units, relative to the reference: s[sub][reg] = q'.k + nslope * dist - m2
+  auto scores = [&](int t, f32x16 (&s)[2], const f32x16& init) {
+    const h16* Kb = Ks + (t & 1) * IMG_HALVES;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + krd[ks]]);
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? init : s[sub], 0, 0, 0);
+      }
+    }
+    if (BIAS) {
+      const h16* Pb = pos_s + (t & 1) * PIMG;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        // a_k fragment of key row (sub * 32 + l31): the hh = 0 lanes carry k = 0..7, the hh = 1 lanes (k = 8..15) the zero chunk
+        const h16x8 pk = *reinterpret_cast<const h16x8*>(hh ? &pos_s[2 * PIMG] : &Pb[(sub * 32 + l31) * 8]);
+        const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pk, pqf, splat16(0.f), 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[sub][i] = fmaf(__builtin_amdgcn_sqrtf(d2[i]), nslope, s[sub][i]);
+      }
+    }
+  };
+
+  f32x16 o0 = splat16(0.f), o1 = splat16(0.f);
+  float lsum = 0.f;
+  dma(0);
+  dma_wait_all();
+  __syncthreads();
+  // running reference m2 (log2 units), carried as the accumulator initialiser minit = splat(-m2); starts at the row maximum of
+  // tile 0 (bias included: the ALiBi term can push a whole tile far below its raw scores)
+  float m2;
+  f32x16 minit;
+  {
+    f32x16 s0[2];
+    scores(0, s0, splat16(0.f));
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kidx = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        mx = fmaxf(mx, kidx < N ? s0[sub][i] : NEG_BIG);
+      }
+    m2 = max_halves(mx);
+    minit = splat16(-m2);
+  }
+
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int kb = t * 64;
+    const h16* Vb = Vs + (t & 1) * IMG_HALVES;
+    if (t + 1 < ntile) dma(t + 1);
+    f32x16 s_cur[2];
+    scores(t, s_cur, minit);
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (TAIL) {
+          const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kidx >= N) s_cur[sub][i] = NEG_BIG;
+        }
+        mx = fmaxf(mx, s_cur[sub][i]);
+      }
+    mx = max_halves(mx);
+    if (__any(mx > RESCALE_LOG2)) {      // deferred exact rescale (attn.hip)
+      const float up = fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-up);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; s_cur[0][i] -= up; s_cur[1][i] -= up; }
+      lsum *= alpha;
+      m2 += up;
+      minit = splat16(-m2);
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        h16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 p = pk_exp2((f32x2){s_cur[sub][8 * s2 + e], s_cur[sub][8 * s2 + e + 1]});
+          pf[e] = (h16)p[0]; pf[e + 1] = (h16)p[1];
+          lsum += p[0] + p[1];
+        }
+        const h16* vblk = Vb + (sub * 32 + s2 * 16) * IMG_ROW;
+        const h16x8 v0 = cat8(lds_tr4(vblk + va0), lds_tr4(vblk + vb0));
+        const h16x8 v1 = cat8(lds_tr4(vblk + va1), lds_tr4(vblk + vb1));
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf, o1, 0, 0, 0);
+      }
+    dma_wait_all();
+    __syncthreads();
+  };
+  const bool tail_last = (N & 63) != 0;
+  const int nplain = tail_last ? ntile - 1 : ntile;
+  for (int t = 0; t < nplain; ++t) tile(t, std::false_type{});
+  if (tail_last) tile(ntile - 1, std::true_type{});
+
+  const float l = sum_halves(lsum);
+  if (qvalid) {
+    const float inv = 1.0f / l;
+    h16* orow = o + qrow * a.D + w.h * DH;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const h16x4 v0 = {(h16)(o0[4 * gq] * inv), (h16)(o0[4 * gq + 1] * inv), (h16)(o0[4 * gq + 2] * inv), (h16)(o0[4 * gq + 3] * inv)};
+      const h16x4 v1 = {(h16)(o1[4 * gq] * inv), (h16)(o1[4 * gq + 1] * inv), (h16)(o1[4 * gq + 2] * inv), (h16)(o1[4 * gq + 3] * inv)};
+      *reinterpret_cast<h16x4*>(orow + 8 * gq + 4 * hh) = v0;
+      *reinterpret_cast<h16x4*>(orow + 32 + 8 * gq + 4 * hh) = v1;
+    }
+    if (hh == 0) lse[qrow * a.H + w.h] = (m2 + __log2f(l)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (query = lane)
+//   P'^T = exp2(S'^T + bias - L2[q] + log2 ln2) ; dP^T = V . dO^T - delta[q] ; dS^T = P'^T dP^T ; dQ'^T += K^T . dS^T
+template <bool BIAS>
+__global__ __launch_bounds__(256) void dense_attn_bwd_q_kernel(DenseArgs a, const h16* __restrict__ d_o, const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, h16* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // K0 | K1 | V0 | V1
+  __shared__ __attribute__((aligned(16))) h16 pos_s[2 * PIMG + 8];
+  h16* const Ks = smem;
+  h16* const Vs = smem + 2 * IMG_HALVES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const DItem w = ddecode(a, blockIdx.x);
+  if (!w.live) return;
+  const int N = a.N;
+  const long ld = a.ld;
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid == 0) *reinterpret_cast<h16x8*>(&pos_s[2 * PIMG]) = zero8;
+
+  const int iq = w.qt * 128 + wave * 32 + l31;
+  const bool qvalid = iq < N;
+  const long qrow = (long)w.b * N + min(iq, N - 1);
+  h16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = sel8(qvalid, ldg8(a.qkv + qrow * ld + w.h * DH + ks * 16 + hh * 8));
+    dof[ks] = sel8(qvalid, ldg8(d_o + qrow * a.D + w.h * DH + ks * 16 + hh * 8));
+  }
+  h16x8 pqf = zero8;
+  float nslope = 0.f;
+  if (BIAS) {
+    pqf = sel8(qvalid && hh == 0, ldg8(a.posq + (long)min(iq, N - 1) * 8));
+    nslope = a.nslope[w.h];
+  }
+  const float L2raw = lse[qrow * a.H + w.h], dlraw = delta[qrow * a.H + w.h];
+  const f32x16 nl2i = splat16(qvalid ? fmaf(-L2raw, LOG2E, LOG2_LN2) : -1.0e30f);      // invalid queries: P' = 0
+  const f32x16 ndli = splat16(qvalid ? -dlraw : 0.f);
+
+  const int ntile = (N + 63) >> 6;
+  const int row_bytes = (int)ld * 2;
+  const long valid_bytes = (long)(N - 1) * row_bytes + DH * 2;
+  const long tile_bytes = 64L * row_bytes;
+  const h16* const kseq = a.qkv + (long)w.b * N * ld + a.D + w.h * DH;
+  const h16* const vseq = kseq + a.D;
+  const DmaLane64 dl(tid, row_bytes);
+  auto dma = [&](int t) {
+    dma_tile64(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), dl);
+    dma_tile64(Vs + (t & 1) * IMG_HALVES, tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl);
+    if (BIAS && tid < 64) dma_pos(pos_s + (t & 1) * PIMG, a.posk, t, N, lane);
+  };
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  int rrd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rrd[ks] = img_off(l31, 2 * ks + hh);
+  const int kc = 2 * (grp & 1) + (tp >> 1), ko = 4 * (tp & 1);
+  const int ka0 = img_off(4 * hh + tq, kc) + ko, ka1 = img_off(4 * hh + tq, kc + 4) + ko;
+  const int kb0 = img_off(4 * hh + tq + 8, kc) + ko, kb1 = img_off(4 * hh + tq + 8, kc + 4) + ko;
+
+  f32x16 dq0 = splat16(0.f), dq1 = splat16(0.f);
+  dma(0);
+  dma_wait_all();
+  __syncthreads();
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int kb = t * 64;
+    const h16* Kb = Ks + (t & 1) * IMG_HALVES;
+    const h16* Vb = Vs + (t & 1) * IMG_HALVES;
+    const h16* Pb = pos_s + (t & 1) * PIMG;
+    if (t + 1 < ntile) dma(t + 1);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + rrd[ks]]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? nl2i : s, 0, 0, 0);
+        const h16x8 vf = *reinterpret_cast<const h16x8*>(&Vb[sub * 32 * IMG_ROW + rrd[ks]]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], ks == 0 ? ndli : dp, 0, 0, 0);
+      }
+      if (BIAS) {
+        const h16x8 pk = *reinterpret_cast<const h16x8*>(hh ? &pos_s[2 * PIMG] : &Pb[(sub * 32 + l31) * 8]);
+        const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pk, pqf, splat16(0.f), 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = fmaf(__builtin_amdgcn_sqrtf(d2[i]), nslope, s[i]);
+      }
+      h16x8 dsf[2];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]});
+        if (TAIL) {
+          const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kidx >= N) pt[0] = 0.f;
+          if (kidx + 1 >= N) pt[1] = 0.f;
+        }
+        const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
+        dsf[i >> 3][i & 7] = (h16)d[0];
+        dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const h16* kblk = Kb + (sub * 32 + s2 * 16) * IMG_ROW;
+        const h16x8 k0 = cat8(lds_tr4(kblk + ka0), lds_tr4(kblk + kb0));
+        const h16x8 k1 = cat8(lds_tr4(kblk + ka1), lds_tr4(kblk + kb1));
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, dsf[s2], dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, dsf[s2], dq1, 0, 0, 0);
+      }
+    }
+    dma_wait_all();
+    __syncthreads();
+  };
+  const bool tail_last = (N & 63) != 0;
+  const int nplain = tail_last ? ntile - 1 : ntile;
+  for (int t = 0; t < nplain; ++t) tile(t, std::false_type{});
+  if (tail_last) tile(ntile - 1, std::true_type{});
+  if (qvalid) {
+    h16* out = dqkv + qrow * ld + w.h * DH;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const h16x4 v0 = {(h16)dq0[4 * gq], (h16)dq0[4 * gq + 1], (h16)dq0[4 * gq + 2], (h16)dq0[4 * gq + 3]};
+      const h16x4 v1 = {(h16)dq1[4 * gq], (h16)dq1[4 * gq + 1], (h16)dq1[4 * gq + 2], (h16)dq1[4 * gq + 3]};
+      *reinterpret_cast<h16x4*>(out + 8 * gq + 4 * hh) = v0;
+      *reinterpret_cast<h16x4*>(out + 32 + 8 * gq + 4 * hh) = v1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV (key = lane)
+//   S[q,key] = Q' . K^T + bias ; dP = dO . V^T ; P' = exp2(S - L2[q] + log2 ln2) ; dS = P' (dP - delta[q])
+//   dV^T[d,key] += dO^T . P' (x 1 / ln2 at the end) ; dK^T[d,key] += Q'^T . dS
+template <bool BIAS>
+__global__ __launch_bounds__(256) void dense_attn_bwd_kv_kernel(DenseArgs a, const h16* __restrict__ d_o, const float* __restrict__ lse,
+                                                                const float* __restrict__ delta, h16* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // Q0 | Q1 | D0 | D1
+  __shared__ __attribute__((aligned(16))) h16 pos_s[2 * PIMG + 8];       // query b_q tiles + zero chunk
+  __shared__ __attribute__((aligned(16))) float L2s[2][64];
+  __shared__ __attribute__((aligned(16))) float Dls[2][64];
+  h16* const Qx = smem;
+  h16* const Dx = smem + 2 * IMG_HALVES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const DItem w = ddecode(a, blockIdx.x);
+  if (!w.live) return;
+  const int N = a.N;
+  const long ld = a.ld;
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid == 0) *reinterpret_cast<h16x8*>(&pos_s[2 * PIMG]) = zero8;
+
+  const int ik = w.qt * 128 + wave * 32 + l31;
+  const bool kvalid = ik < N;
+  const long krow = (long)w.b * N + min(ik, N - 1);
+  h16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = sel8(kvalid, ldg8(a.qkv + krow * ld + a.D + w.h * DH + ks * 16 + hh * 8));
+    vf[ks] = sel8(kvalid, ldg8(a.qkv + krow * ld + 2 * a.D + w.h * DH + ks * 16 + hh * 8));
+  }
+  h16x8 pkf = zero8;
+  float nslope = 0.f;
+  if (BIAS) {
+    pkf = sel8(kvalid && hh == 0, ldg8(a.posk + (long)min(ik, N - 1) * 8));
+    nslope = a.nslope[w.h];
+  }
+
+  const int ntile = (N + 63) >> 6;
+  const int qrow_bytes = (int)ld * 2, drow_bytes = a.D * 2;
+  const long qvalid_bytes = (long)(N - 1) * qrow_bytes + DH * 2, dvalid_bytes = (long)(N - 1) * drow_bytes + DH * 2;
+  const h16* const qseq = a.qkv + (long)w.b * N * ld + w.h * DH;
+  const h16* const dseq = d_o + (long)w.b * N * a.D + w.h * DH;
+  const DmaLane64 dlq(tid, qrow_bytes), dld(tid, drow_bytes);
+  const float* const lbase = lse + (long)w.b * N * a.H + w.h;
+  const float* const dbase = delta + (long)w.b * N * a.H + w.h;
+  float rl2 = 0.f, rdl = 0.f;
+  auto issue = [&](int t) {
+    dma_tile64(Qx + (t & 1) * IMG_HALVES, tile_rsrc(qseq, t * 64L * qrow_bytes, qvalid_bytes), dlq);
+    dma_tile64(Dx + (t & 1) * IMG_HALVES, tile_rsrc(dseq, t * 64L * drow_bytes, dvalid_bytes), dld);
+    if (tid < 64) {
+      if (BIAS) dma_pos(pos_s + (t & 1) * PIMG, a.posq, t, N, lane);
+      const int i = t * 64 + lane;
+      const long off = (long)min(i, N - 1) * a.H;
+      const bool ok = i < N;
+      rl2 = ok ? fmaf(-lbase[off], LOG2E, LOG2_LN2) : 0.f;      // (Q = dO = 0 past the end: P' meets zeros)
+      rdl = ok ? -dbase[off] : 0.f;
+    }
+  };
+  auto publish = [&](int t) {
+    if (tid < 64) { L2s[t & 1][tid] = rl2; Dls[t & 1][tid] = rdl; }
+  };
+
+  f32x16 dk0 = splat16(0.f), dk1 = splat16(0.f), dv0 = splat16(0.f), dv1 = splat16(0.f);
+  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  int rrd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rrd[ks] = img_off(l31, 2 * ks + hh);
+  const int trc = 2 * (grp & 1) + (tp >> 1), tro = 4 * (tp & 1);
+  const int tr_a0 = img_off(4 * hh + tq, trc) + tro, tr_a1 = img_off(4 * hh + tq, trc + 4) + tro;
+  const int tr_b0 = img_off(4 * hh + tq + 8, trc) + tro, tr_b1 = img_off(4 * hh + tq + 8, trc + 4) + tro;
+
+  issue(0);
+  publish(0);
+  dma_wait_all();
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const h16* Qb = Qx + (t & 1) * IMG_HALVES;
+    const h16* Db = Dx + (t & 1) * IMG_HALVES;
+    const h16* Pb = pos_s + (t & 1) * PIMG;
+    const float* L2b = L2s[t & 1];
+    const float* Dlb = Dls[t & 1];
+    if (t + 1 < ntile) issue(t + 1);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(&L2b[sub * 32 + 8 * g4 + 4 * hh]);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(&Dlb[sub * 32 + 8 * g4 + 4 * hh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = x0[e]; dp[4 * g4 + e] = x1[e]; }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qb[sub * 32 * IMG_ROW + rrd[ks]]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s, 0, 0, 0);
+        const h16x8 da = *reinterpret_cast<const h16x8*>(&Db[sub * 32 * IMG_ROW + rrd[ks]]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp, 0, 0, 0);
+      }
+      if (BIAS) {      // rows = queries: A = b_q of the tile's query rows, B = a_k of this lane's key
+        const h16x8 pq = *reinterpret_cast<const h16x8*>(hh ? &pos_s[2 * PIMG] : &Pb[(sub * 32 + l31) * 8]);
+        const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pq, pkf, splat16(0.f), 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = fmaf(__builtin_amdgcn_sqrtf(d2[i]), nslope, s[i]);
+      }
+      h16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]});
+        const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
+        pf[i >> 3][i & 7] = (h16)pt[0]; pf[i >> 3][(i & 7) + 1] = (h16)pt[1];
+        dsf[i >> 3][i & 7] = (h16)d[0]; dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int rb = (sub * 32 + s2 * 16) * IMG_ROW;
+        const h16x8 d0 = cat8(lds_tr4(&Db[rb + tr_a0]), lds_tr4(&Db[rb + tr_b0]));
+        const h16x8 d1 = cat8(lds_tr4(&Db[rb + tr_a1]), lds_tr4(&Db[rb + tr_b1]));
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, pf[s2], dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, pf[s2], dv1, 0, 0, 0);
+        const h16x8 q0 = cat8(lds_tr4(&Qb[rb + tr_a0]), lds_tr4(&Qb[rb + tr_b0]));
+        const h16x8 q1 = cat8(lds_tr4(&Qb[rb + tr_a1]), lds_tr4(&Qb[rb + tr_b1]));
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, dsf[s2], dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, dsf[s2], dk1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntile) publish(t + 1);
+    dma_wait_all();
+    __syncthreads();
+  }
+  if (kvalid) {
+    h16* outk = dqkv + krow * ld + a.D + w.h * DH;
+    h16* outv = outk + a.D;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const h16x4 k0 = {(h16)dk0[4 * gq], (h16)dk0[4 * gq + 1], (h16)dk0[4 * gq + 2], (h16)dk0[4 * gq + 3]};
+      const h16x4 k1 = {(h16)dk1[4 * gq], (h16)dk1[4 * gq + 1], (h16)dk1[4 * gq + 2], (h16)dk1[4 * gq + 3]};
+      const h16x4 v0 = {(h16)(dv0[4 * gq] * INV_LN2), (h16)(dv0[4 * gq + 1] * INV_LN2), (h16)(dv0[4 * gq + 2] * INV_LN2),
+                        (h16)(dv0[4 * gq + 3] * INV_LN2)};
+      const h16x4 v1 = {(h16)(dv1[4 * gq] * INV_LN2), (h16)(dv1[4 * gq + 1] * INV_LN2), (h16)(dv1[4 * gq + 2] * INV_LN2),
+                        (h16)(dv1[4 * gq + 3] * INV_LN2)};
+      *reinterpret_cast<h16x4*>(outk + 8 * gq + 4 * hh) = k0;
+      *reinterpret_cast<h16x4*>(outk + 32 + 8 * gq + 4 * hh) = k1;
+      *reinterpret_cast<h16x4*>(outv + 8 * gq + 4 * hh) = v0;
+      *reinterpret_cast<h16x4*>(outv + 32 + 8 * gq + 4 * hh) = v1;
+    }
+  }
+}
+
+// delta[m, h] = sum_d dO[m, h, d] * O[m, h, d] (token-major fp16 rows of H * 64): eight lanes per (row, head), 16 bytes each
+__global__ __launch_bounds__(256) void dense_attn_delta_kernel(const h16* __restrict__ o, const h16* __restrict__ d_o,
+                                                               float* __restrict__ delta, long M, int H) {
+  const long nchunk = M * H * 8;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (long)gridDim.x * blockDim.x) {
+    const h16x8 x = ldg8(o + c * 8), y = ldg8(d_o + c * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf((float)x[e], (float)y[e], s);
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if ((c & 7) == 0) delta[c >> 3] = s;
+  }
+}
+
+// ALiBi side tables from the grid cells of the tokens (token 0 = cls: all-zero rows); see the file header.
+__global__ void alibi_pos_kernel(const int* __restrict__ cells, int N, const int* __restrict__ dims, h16* __restrict__ posk,
+                                 h16* __restrict__ posq, int* __restrict__ err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int cx = dims[0] >> 1, cy = dims[1] >> 1;
+  h16x8 ak = {0, 0, 0, 0, 0, 0, 0, 0}, bq = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (i > 0) {
+    int x = cells[2 * (i - 1)] - cx, y = cells[2 * (i - 1) + 1] - cy;
+    if (x < -1024 || x > 1024 || y < -1024 || y > 1024) {
+      if (err) atomicOr(err, 2);
+      x = min(max(x, -1024), 1024); y = min(max(y, -1024), 1024);
+    }
+    const int n = x * x + y * y, n0 = n & 63, n1 = (n >> 6) & 63, n2 = n >> 12;
+    ak = (h16x8){(h16)(float)x, (h16)(float)y, (h16)(float)n0, (h16)(float)n1, (h16)(float)n2, (h16)1.f, (h16)64.f, (h16)4096.f};
+    bq = (h16x8){(h16)(float)(-2 * x), (h16)(float)(-2 * y), (h16)1.f, (h16)64.f, (h16)4096.f, (h16)(float)n0, (h16)(float)n1,
+                 (h16)(float)n2};
+  }
+  *reinterpret_cast<h16x8*>(posk + (long)i * 8) = ak;
+  *reinterpret_cast<h16x8*>(posq + (long)i * 8) = bq;
+}
+
+bool dense_plan_ok(const MtDensePlan* p) {
+  if (!p || p->N < 1 || p->B < 1 || p->H < 1 || p->H > 64) return false;
+  if ((p->posk == nullptr) != (p->posq == nullptr)) return false;
+  if (p->posk && !p->nslope) return false;
+  return true;
+}
+DenseArgs dense_args(const mt_half* qkv, const MtDensePlan* p) {
+  DenseArgs a;
+  a.qkv = (const h16*)qkv; a.N = p->N; a.B = p->B; a.H = p->H; a.D = p->H * DH; a.ld = 3L * a.D;
+  a.posk = (const h16*)p->posk; a.posq = (const h16*)p->posq; a.nslope = p->nslope;
+  a.qtiles = cdiv(p->N, 128);
+  return a;
+}
+int dense_grid(const DenseArgs& a) { return cdiv(a.B * a.H, 8) * 8 * a.qtiles; }
+
+}  // namespace
+
+extern "C" int mt_alibi_pos(const int* cells, int N, const int* dims, mt_half* posk, mt_half* posq, int* err, mt_stream_t stream) {
+  if (!posk || !posq || !dims || N < 1 || (N > 1 && !cells)) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(alibi_pos_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, cells, N, dims, (h16*)posk,
+                     (h16*)posq, err);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_dense_attn_fwd(const mt_half* qkv, const MtDensePlan* plan, mt_half* o, float* lse, mt_stream_t stream) {
+  if (!qkv || !o || !lse || !dense_plan_ok(plan)) return MT_ERR_BAD_ARG;
+  const DenseArgs a = dense_args(qkv, plan);
+  if (a.posk)
+    hipLaunchKernelGGL(dense_attn_fwd_kernel<true>, dim3(dense_grid(a)), dim3(256), 0, (hipStream_t)stream, a, (h16*)o, lse);
+  else
+    hipLaunchKernelGGL(dense_attn_fwd_kernel<false>, dim3(dense_grid(a)), dim3(256), 0, (hipStream_t)stream, a, (h16*)o, lse);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_dense_attn_bwd(const mt_half* qkv, const mt_half* o, const mt_half* d_o, const float* lse, const MtDensePlan* plan,
+                                 float* delta, mt_half* dqkv, int phases, mt_stream_t stream) {
+  if (!qkv || !o || !d_o || !lse || !delta || !dqkv || !dense_plan_ok(plan) || !(phases & 7)) return MT_ERR_BAD_ARG;
+  const DenseArgs a = dense_args(qkv, plan);
+  hipStream_t s = (hipStream_t)stream;
+  const long M = (long)a.B * a.N;
+  if (phases & MT_DENSE_BWD_DELTA)
+    hipLaunchKernelGGL(dense_attn_delta_kernel, dim3((int)min((M * a.H * 8 + 255) / 256, 16384L)), dim3(256), 0, s, (const h16*)o,
+                       (const h16*)d_o, delta, M, a.H);
+  const dim3 grid(dense_grid(a));
+  if (phases & MT_DENSE_BWD_KV) {
+    if (a.posk) hipLaunchKernelGGL(dense_attn_bwd_kv_kernel<true>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
+    else hipLaunchKernelGGL(dense_attn_bwd_kv_kernel<false>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
+  }
+  if (phases & MT_DENSE_BWD_Q) {
+    if (a.posk) hipLaunchKernelGGL(dense_attn_bwd_q_kernel<true>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
+    else hipLaunchKernelGGL(dense_attn_bwd_q_kernel<false>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
+  }
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}

@@ -24,6 +24,7 @@ struct LnFwdArgs {
   const float* w; const float* b; const float* add_rows; int add_period;
   void* y; long ldy; RowMap ymap;
   float* stats; int M;
+  float eps;
 };
 
 template <int D, typename InT, typename OutT, bool GELU>
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float d = v[c][e] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + a.eps);
     OutT* y = reinterpret_cast<OutT*>(a.y) + a.ymap.map(m) * a.ldy;
     const float* add = a.add_rows ? a.add_rows + (long)(m % a.add_period) * D : nullptr;
 #pragma unroll
@@ -79,6 +80,7 @@ struct AddLnArgs {
   const float* x; const h16* branch; DropArgs drop;
   const float* w; const float* b;
   float* h; h16* y; float* stats; int M;
+  float eps;
 };
 
 template <int D>
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(AddLnArgs a) {
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float d = v[c][e] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + a.eps);
     h16* y = a.y + (long)m * D;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void ln_gelu_fwd_kernel(LnFwdArgs a) {
     const float pq = wave_sum(q2[0] + q2[1]);
     if (lane == 0) red[1][wave] = pq;
     __syncthreads();
-    const float rstd = rsqrtf((red[1][2 * rsel] + red[1][2 * rsel + 1]) * (1.0f / D) + 1e-5f);
+    const float rstd = rsqrtf((red[1][2 * rsel] + red[1][2 * rsel + 1]) * (1.0f / D) + a.eps);
     if (valid) {
       h16* y = reinterpret_cast<h16*>(a.y) + a.ymap.map(m) * a.ldy;
       const f32x2 rs = splat2(rstd);
@@ -609,12 +611,12 @@ int ew_grid(long n) { return (int)max(1L, min((n + 1023) / 1024, 4096L)); }
 
 }  // namespace
 
-extern "C" int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in,
-                                const float* w, const float* b, const float* add_rows, int add_period, void* y,
-                                long ldy, const MtRowMap* ymap, int out_dtype, float* stats, int M, int D,
-                                mt_stream_t stream) {
-  if (!x || !y || !w || !b || M <= 0 || (ldx & 3) || (ldy & 3)) return MT_ERR_BAD_ARG;
-  LnFwdArgs a{x, ldx, make_rowmap(xmap), w, b, add_rows, add_period > 0 ? add_period : 1, y, ldy, make_rowmap(ymap), stats, M};
+extern "C" int mt_layernorm_fwd_eps(const void* x, long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in,
+                                    const float* w, const float* b, const float* add_rows, int add_period, void* y,
+                                    long ldy, const MtRowMap* ymap, int out_dtype, float* stats, int M, int D, float eps,
+                                    mt_stream_t stream) {
+  if (!x || !y || !w || !b || M <= 0 || (ldx & 3) || (ldy & 3) || !(eps > 0.f)) return MT_ERR_BAD_ARG;
+  LnFwdArgs a{x, ldx, make_rowmap(xmap), w, b, add_rows, add_period > 0 ? add_period : 1, y, ldy, make_rowmap(ymap), stats, M, eps};
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
     case 256: return ln_fwd_types<256>(a, in_dtype, out_dtype, gelu_in, s);
@@ -625,14 +627,28 @@ extern "C" int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, i
   }
 }
 
-extern "C" int mt_add_layernorm_fwd(const float* x, const mt_half* branch, const MtDropout* drop, const float* w,
-                                    const float* b, float* h, mt_half* y, float* stats, int M, int D, mt_stream_t stream) {
-  if (!x || !branch || !w || !b || !h || !y || !stats || M <= 0 || h == x) return MT_ERR_BAD_ARG;
+extern "C" int mt_layernorm_fwd(const void* x, long ldx, const MtRowMap* xmap, int in_dtype, int gelu_in,
+                                const float* w, const float* b, const float* add_rows, int add_period, void* y,
+                                long ldy, const MtRowMap* ymap, int out_dtype, float* stats, int M, int D,
+                                mt_stream_t stream) {
+  return mt_layernorm_fwd_eps(x, ldx, xmap, in_dtype, gelu_in, w, b, add_rows, add_period, y, ldy, ymap, out_dtype, stats, M, D, 1e-5f,
+                              stream);
+}
+
+extern "C" int mt_add_layernorm_fwd_eps(const float* x, const mt_half* branch, const MtDropout* drop, const float* w,
+                                        const float* b, float* h, mt_half* y, float* stats, int M, int D, float eps,
+                                        mt_stream_t stream) {
+  if (!x || !branch || !w || !b || !h || !y || !stats || M <= 0 || h == x || !(eps > 0.f)) return MT_ERR_BAD_ARG;
   if (D != 768) return MT_ERR_UNSUPPORTED;
-  AddLnArgs a{x, (const h16*)branch, make_drop(drop), w, b, h, (h16*)y, stats, M};
+  AddLnArgs a{x, (const h16*)branch, make_drop(drop), w, b, h, (h16*)y, stats, M, eps};
   hipLaunchKernelGGL((add_ln_fwd_kernel<768>), dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, a);
   MT_CHECK_LAUNCH();
   return MT_OK;
+}
+
+extern "C" int mt_add_layernorm_fwd(const float* x, const mt_half* branch, const MtDropout* drop, const float* w,
+                                    const float* b, float* h, mt_half* y, float* stats, int M, int D, mt_stream_t stream) {
+  return mt_add_layernorm_fwd_eps(x, branch, drop, w, b, h, y, stats, M, D, 1e-5f, stream);
 }
 
 template <int D>

@@ -257,34 +257,10 @@ class Engine:
         key = (B, L)
         if not fresh and key in self._ws:
             return self._ws[key]
-        cfg, dev = self.cfg, self.device
-        D, Fd = cfg.embed_dim, cfg.ffn_dim
-        nb = len(self.seg_lengths)
+        dev = self.device
 
         def spec(Lx):       # name -> (dtype, shape) at bag length Lx
-            N = Lx + 1
-            M, Mp = B * N, B * Lx
-            sp = {"x16": (H16, (Lx, cfg.in_chans)), "x0": (F32, (Lx, D)), "prow": (torch.int32, (Lx,)), "pcol": (torch.int32, (Lx,))}
-            if self.stochastic:
-                sp["x0d"] = (F32, (B * Lx, D))      # per-pass input dropout (ENC:339) of the shared patch embedding
-            for l in range(cfg.depth):
-                sp[f"hin{l}"] = (F32, (M, D)); sp[f"hmid{l}"] = (F32, (M, D)); sp[f"qkv{l}"] = (H16, (M, 3 * D))
-                sp[f"obr{l}"] = (H16, (nb, M, D)); sp[f"lsebr{l}"] = (F32, (nb, M, 16)); sp[f"lsetot{l}"] = (F32, (M, 16))
-                sp[f"a1_{l}"] = (H16, (M, Fd))
-                for st in ("st1", "stin", "st2", "stf"):
-                    sp[f"{st}_{l}"] = (F32, (M, 2))
-            for i in range(len(cfg.interaction_indexes)):
-                sp[f"hout{i}"] = (F32, (M, D))
-            # transients shared by all layers
-            for nm in ("u16", "br16", "dy16", "dh16", "dmixed"):
-                sp[nm] = (H16, (M, D))
-            for nm in ("t16", "dt16", "da1"):
-                sp[nm] = (H16, (M, Fd))
-            sp["dh"] = (F32, (M, D)); sp["delta"] = (F32, (nb, M, 16)); sp["dqkv16"] = (H16, (M, 3 * D))
-            sp["scratch32"] = (F32, (Mp, D))
-            plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
-            sp["attn_ws"] = (H16, (ops.dilated_attn_bwd_workspace_bytes(plan) // 2,))
-            return sp
+            return self._ws_spec(B, Lx)
 
         def numel(shape):
             n = 1
@@ -307,6 +283,36 @@ class Engine:
         w = {k: store["flat"][k][:numel(shape)].view(shape) for k, (dt, shape) in spec(L).items()}
         self._ws[key] = w
         return w
+
+    def _ws_spec(self, B: int, Lx: int) -> Dict[str, tuple]:
+        """name -> (dtype, shape) of every activation / gradient buffer at bag length Lx (overridden by the TITAN engine, whose
+        frozen blocks save different tensors)."""
+        cfg = self.cfg
+        D, Fd = cfg.embed_dim, cfg.ffn_dim
+        nb = len(self.seg_lengths)
+        N = Lx + 1
+        M, Mp = B * N, B * Lx
+        sp = {"x16": (H16, (Lx, cfg.in_chans)), "x0": (F32, (Lx, D)), "prow": (torch.int32, (Lx,)), "pcol": (torch.int32, (Lx,))}
+        if self.stochastic:
+            sp["x0d"] = (F32, (B * Lx, D))      # per-pass input dropout (ENC:339) of the shared patch embedding
+        for l in range(cfg.depth):
+            sp[f"hin{l}"] = (F32, (M, D)); sp[f"hmid{l}"] = (F32, (M, D)); sp[f"qkv{l}"] = (H16, (M, 3 * D))
+            sp[f"obr{l}"] = (H16, (nb, M, D)); sp[f"lsebr{l}"] = (F32, (nb, M, 16)); sp[f"lsetot{l}"] = (F32, (M, 16))
+            sp[f"a1_{l}"] = (H16, (M, Fd))
+            for st in ("st1", "stin", "st2", "stf"):
+                sp[f"{st}_{l}"] = (F32, (M, 2))
+        for i in range(len(cfg.interaction_indexes)):
+            sp[f"hout{i}"] = (F32, (M, D))
+        # transients shared by all layers
+        for nm in ("u16", "br16", "dy16", "dh16", "dmixed"):
+            sp[nm] = (H16, (M, D))
+        for nm in ("t16", "dt16", "da1"):
+            sp[nm] = (H16, (M, Fd))
+        sp["dh"] = (F32, (M, D)); sp["delta"] = (F32, (nb, M, 16)); sp["dqkv16"] = (H16, (M, 3 * D))
+        sp["scratch32"] = (F32, (Mp, D))
+        plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
+        sp["attn_ws"] = (H16, (ops.dilated_attn_bwd_workspace_bytes(plan) // 2,))
+        return sp
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, coords, genes: Sequence[torch.Tensor], task_onehots: torch.Tensor,
@@ -341,8 +347,7 @@ class Engine:
             self._fresh_calls += 1       # tied to the call, not to the device step counter alone
         self._site_base = 4096 * (self._fresh_calls & 0xFFFFF) if fresh else 0
         self._ctx = dict(B=B, L=L, N=N, M=M, Mp=Mp, ws=ws)
-        plan = ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
-        self._ctx["plan"] = plan
+        self._ctx["plan"] = self._attention_plan(N, B)
         P = self.store.param
         patch_map = rowmap(L, N, 1)     # patch rows of a [B, N, D] buffer
         self._ctx["patch_map"] = patch_map
@@ -400,7 +405,10 @@ class Engine:
         self.tape = self._main_tape
         return logits.data
 
-    # -- overridable pieces of the image side (modaltune_amd/titan.py plugs an external backbone in here)
+    # -- overridable pieces of the image side (modaltune_amd/titan.py plugs the TITAN backbone in here)
+    def _attention_plan(self, N: int, B: int):
+        return ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)
+
     def _embed_patches(self, x, coords, ws, staged: bool, L: int):
         cfg, t = self.cfg, self.store.tensors
         if not staged:

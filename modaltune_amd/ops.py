@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import MT_SGEMM_MAX, MtDilatedPlan, MtDropout, MtGemmEpilogue, MtRowMap, MtSgemm, check, rowmap
+from ._lib import MT_SGEMM_MAX, MtDensePlan, MtDilatedPlan, MtDropout, MtGemmEpilogue, MtRowMap, MtSgemm, check, rowmap
 
 F16, F32 = 0, 1
 EPI_BIAS, EPI_BIAS_RESID, EPI_INJECT, EPI_POSEMB, EPI_QKV_HM = 0, 1, 2, 3, 4
@@ -129,16 +129,16 @@ def sgemm(A, a_str, B, b_str, Cm, c_str, M, N, K, **k):
 
 
 def layernorm_fwd(x, w, b, y, stats, M, D, *, ldx=None, xmap=None, ldy=None, ymap=None, gelu_in=False, add_rows=None,
-                  add_period=0):
-    check(_lib.load().mt_layernorm_fwd(_p(x), ldx if ldx is not None else D, _rm(xmap), _dt(x), int(gelu_in), _p(w), _p(b),
-                                       _p(add_rows), add_period, _p(y), ldy if ldy is not None else D, _rm(ymap), _dt(y),
-                                       _p(stats), M, D, _s()), "layernorm_fwd")
+                  add_period=0, eps=1e-5):
+    check(_lib.load().mt_layernorm_fwd_eps(_p(x), ldx if ldx is not None else D, _rm(xmap), _dt(x), int(gelu_in), _p(w), _p(b),
+                                           _p(add_rows), add_period, _p(y), ldy if ldy is not None else D, _rm(ymap), _dt(y),
+                                           _p(stats), M, D, float(eps), _s()), "layernorm_fwd")
 
 
-def add_layernorm_fwd(x, branch, w, b, h, y, stats, M, D, drop=None):
+def add_layernorm_fwd(x, branch, w, b, h, y, stats, M, D, drop=None, eps=1e-5):
     """h = x + drop(branch); y = fp16(LN(h) * w + b) (include/modaltune_hip.h: mt_add_layernorm_fwd)."""
-    check(_lib.load().mt_add_layernorm_fwd(_p(x), _p(branch), _dr(drop), _p(w), _p(b), _p(h), _p(y), _p(stats), M, D, _s()),
-          "add_layernorm_fwd")
+    check(_lib.load().mt_add_layernorm_fwd_eps(_p(x), _p(branch), _dr(drop), _p(w), _p(b), _p(h), _p(y), _p(stats), M, D,
+                                               float(eps), _s()), "add_layernorm_fwd")
 
 
 def layernorm_bwd(dy, x, w, stats, dx, M, D, *, lddy=None, dymap=None, ldx=None, xmap=None, lddx=None, dxmap=None,
@@ -193,6 +193,79 @@ def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
         _dilated_attn_bwd_phase(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16, ph)
         e1.record()
         TIMER.setdefault(name, []).append((e0, e1))
+
+
+# ---- dense attention with in-kernel 2-D ALiBi + the other TITAN-side launchers (include/modaltune_hip.h)
+DENSE_QK_SCALE_LOG2 = 0.125 * 1.4426950408889634
+DENSE_BWD_DELTA, DENSE_BWD_KV, DENSE_BWD_Q, DENSE_BWD_ALL = 1, 2, 4, 7
+
+
+def make_dense_plan(N: int, B: int, H: int, posk=None, posq=None, nslope=None) -> MtDensePlan:
+    """posk / posq: fp16 [N, 8] side tables of mt_alibi_pos (both or neither); nslope: fp32 [H] = -slope_h * log2(e).
+    The tensors must outlive every launch made with the plan."""
+    p = MtDensePlan()
+    p.N, p.B, p.H = N, B, H
+    p.posk, p.posq = (posk.data_ptr() if posk is not None else None), (posq.data_ptr() if posq is not None else None)
+    p.nslope = nslope.data_ptr() if nslope is not None else None
+    return p
+
+
+def alibi_pos(cells, N, dims, posk, posq, err=None):
+    check(_lib.load().mt_alibi_pos(_p(cells), N, _p(dims), _p(posk), _p(posq), _p(err), _s()), "alibi_pos")
+
+
+def dense_attn_fwd(qkv, plan, o, lse):
+    check(_lib.load().mt_dense_attn_fwd(_p(qkv), C.byref(plan), _p(o), _p(lse), _s()), "dense_attn_fwd")
+
+
+def _dense_attn_bwd_phase(qkv, o, d_o, lse, plan, delta, dqkv, phases):
+    check(_lib.load().mt_dense_attn_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), C.byref(plan), _p(delta), _p(dqkv), phases, _s()),
+          "dense_attn_bwd")
+
+
+def dense_attn_bwd(qkv, o, d_o, lse, plan, delta, dqkv):
+    if TIMER is None:
+        return _dense_attn_bwd_phase(qkv, o, d_o, lse, plan, delta, dqkv, DENSE_BWD_ALL)
+    for name, ph in (("dense_attn_delta", DENSE_BWD_DELTA), ("dense_attn_bwd_kv", DENSE_BWD_KV), ("dense_attn_bwd_q", DENSE_BWD_Q)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _dense_attn_bwd_phase(qkv, o, d_o, lse, plan, delta, dqkv, ph)
+        e1.record()
+        TIMER.setdefault(name, []).append((e0, e1))
+
+
+def gelu_f16_fwd(x, y, n=None):
+    check(_lib.load().mt_gelu_f16_fwd(_p(x), _p(y), n if n is not None else x.numel(), _s()), "gelu_f16_fwd")
+
+
+def gelu_f16_bwd(x, dy, dx, n=None):
+    check(_lib.load().mt_gelu_f16_bwd(_p(x), _p(dy), _p(dx), n if n is not None else x.numel(), _s()), "gelu_f16_bwd")
+
+
+def pool_attn_fwd(q, kv, out, probs, B, N, E, heads, nq):
+    check(_lib.load().mt_pool_attn_fwd(_p(q), _p(kv), B, N, E, heads, nq, _p(out), _p(probs), _s()), "pool_attn_fwd")
+
+
+def pool_attn_bwd(q, kv, probs, dout, dkv, B, N, E, heads, nq):
+    check(_lib.load().mt_pool_attn_bwd(_p(q), _p(kv), _p(probs), _p(dout), B, N, E, heads, nq, _p(dkv), _s()), "pool_attn_bwd")
+
+
+def titan_grid(coords, L, patch, cells, dims, err=None):
+    check(_lib.load().mt_titan_grid(_p(coords), L, float(patch), _p(cells), _p(dims), _p(err), _s()), "titan_grid")
+
+
+def titan_cell_sums(feat, cells, L, Cc, first, nxt, sums, nz, ldf=None):
+    check(_lib.load().mt_titan_cell_sums(_p(feat), ldf if ldf is not None else Cc, _p(cells), L, Cc, _p(first), _p(nxt), _p(sums),
+                                         _p(nz), _s()), "titan_cell_sums")
+
+
+def titan_token_order(cells, first, nz, L, pos, cells_tok, count):
+    check(_lib.load().mt_titan_token_order(_p(cells), _p(first), _p(nz), L, _p(pos), _p(cells_tok), _p(count), _s()),
+          "titan_token_order")
+
+
+def titan_gather_tokens(sums, pos, L, Cc, x16):
+    check(_lib.load().mt_titan_gather_tokens(_p(sums), _p(pos), L, Cc, _p(x16), _s()), "titan_gather_tokens")
 
 
 def gene_snn_fwd(params, offs, sizes, goff, genes, G, latent, a1, a2, z, alpha_drop=None, passes=1):
@@ -366,6 +439,9 @@ def _timed(name_fn):
 gemm_nt = _timed(lambda A, W, out, M, N, K, **k: f"gemm_nt[{M}x{N}x{K}]")(gemm_nt)
 gemm_tn = _timed(lambda A, B, out, M, N1, N2, **k: f"gemm_tn[{N1}x{N2}]")(gemm_tn)
 dilated_attn_fwd = _timed(lambda *a, **k: "dilated_attn_fwd")(dilated_attn_fwd)
+dense_attn_fwd = _timed(lambda *a, **k: "dense_attn_fwd")(dense_attn_fwd)
+gelu_f16_fwd = _timed(lambda *a, **k: "gelu_f16_fwd")(gelu_f16_fwd)
+gelu_f16_bwd = _timed(lambda *a, **k: "gelu_f16_bwd")(gelu_f16_bwd)
 dilated_mix_ln_fwd = _timed(lambda *a, **k: "dilated_mix_ln_fwd")(dilated_mix_ln_fwd)
 dilated_mix_ln_bwd = _timed(lambda *a, **k: "dilated_mix_ln_bwd")(dilated_mix_ln_bwd)
 layernorm_fwd = _timed(lambda x, w, b, y, stats, M, D, **k: f"layernorm_fwd[{D}]" if M > 1024 else "token_side")(layernorm_fwd)

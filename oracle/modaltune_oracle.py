@@ -356,6 +356,29 @@ def titan_gridding(features, coords, patch_size_lv0):
             (fg != 0).any(dim=1).view(1, H, W))
 
 
+def alibi_bias_2d(cells, slopes):
+    """The additive attention bias the TITAN blocks receive (TA:253-269 `get_alibi(w, h, bg_mask)`; the snapshot's source is absent,
+    the structure is the one tests/golden/titan_standin.py implements and modaltune_amd.titan verifies against the user's module):
+    bias[h, i, j] = -slopes[h] * euclidean distance of the grid cells of tokens i, j; token 0 = cls: zero row and column.
+    cells [Lv, 2] (row, col) of the kept tokens in order; returns [H, 1 + Lv, 1 + Lv]."""
+    pos = cells.to(torch.float64)
+    T = pos.shape[0] + 1
+    bias = torch.zeros(slopes.numel(), T, T, dtype=torch.float64)
+    bias[:, 1:, 1:] = -slopes.to(torch.float64).view(-1, 1, 1) * torch.cdist(pos, pos)
+    return bias
+
+
+def dense_alibi_attention(q, k, v, bias=None):
+    """softmax(q k^T / sqrt(d) + bias) v per head: the attention of a TITAN ViT block as the reference drives it
+    (`blocks.modules_list[i](x, attn_bias, bg_mask)`, TA:359-361; adapter_modules.py:535).  q, k, v [B, N, H, d]; bias [H, N, N]
+    or None; returns [B, N, H, d]."""
+    d = q.shape[-1]
+    s = torch.einsum("bihd,bjhd->bhij", q, k) / math.sqrt(d)
+    if bias is not None:
+        s = s + bias.to(s.dtype)
+    return torch.einsum("bhij,bjhd->bihd", torch.softmax(s, dim=-1), v)
+
+
 def titan_model_forward(sd, cfg, vit, x, coords, genes, task_token, patch_size_lv0=1024, clinical=None):
     """TITANGeneAdapter.forward (TA:329-438) / the clinical variant: x [1, L, C], coords [1, L, 2] -> [1, output_dim]."""
     heads = cfg.num_heads
