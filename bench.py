@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--ragged", action="store_true", help="a different bag length every step (8 lengths in [0.5, 1] x --patches): "
                                                           "the steady state of real data; runs the eager schedule")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--config", default="gigapath", choices=["gigapath", "titan"],
+                    help="gigapath: BASELINE config 2 (the headline metric); titan: BASELINE config 4 (TITAN backbone configuration, "
+                         "--patches foreground cells, --ragged: mixed bag lengths) -- a separate JSON line, never the headline")
     return ap.parse_args()
 
 
@@ -207,8 +210,146 @@ def kernel_rooflines(summ, prof_steps, fl, L, T, B=3):
     return rows
 
 
+# the keys of the reference's model_configs/modaltune_titan_config.json (values restated; no weights are loaded: pretrained False)
+TITAN_JSON = dict(num_heads=12, output_dim=256, init_values=0.0, interaction_indexes=[[0, 1], [2, 3], [4, 5]],
+                  geneclass_name="gene_mixer_group", with_cffn=True, cffn_ratio=0.25, add_prompt_feature=True, use_extra_extractor=True,
+                  freeze_vit=True, with_cp=False, use_prompt_sa=True, prompt_dropout=0.0, prompt_agg="avg", token_agg="cat",
+                  pretrained=False, drop_path_rate=0.2, clinfeat_dim=5)
+
+
+def titan_cpu_baseline(vit_cpu, N, depth, passes, max_seconds=20.0):
+    """The torch-CPU form of one frozen TITAN block forward + input-gradient backward at N tokens (the oracle's TITAN path runs
+    the backbone module's own blocks: oracle.titan_model_forward), all host cores; a slide step = passes x depth of them."""
+    import torch
+    from oracle import modaltune_oracle as O     # CPU baseline leg only
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, N, 768, generator=g).requires_grad_(True)
+    side = int(N ** 0.5) + 1
+    cells = torch.stack([torch.arange(N - 1) // side, torch.arange(N - 1) % side], 1)
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / 12) for i in range(12)])
+    bias = O.alibi_bias_2d(cells, slopes).float().unsqueeze(0)
+    mask = torch.ones(1, N, dtype=torch.bool)
+    blk = vit_cpu.blocks.modules_list[0]
+    times, t_all = [], time.time()
+    for it in range(8):
+        t0 = time.time()
+        blk(x, bias, mask).sum().backward()
+        if it > 0:
+            times.append(time.time() - t0)
+        x.grad = None
+        if time.time() - t_all > max_seconds and times:
+            break
+    t = min(times)
+    n = passes * depth
+    return {"value": 1.0 / (n * t), "unit": "slides/s", "cores": cores, "kind": "port",
+            "sample": f"torch-CPU fp32 ViT block (the stand-in module the oracle's TITAN path runs), {cores} threads, best of {len(times)}: 1 block "
+                      f"fwd+bwd at N={N}, 1 pass: {t:.2f} s; step = {n} block passes ({passes} tasks x {depth} blocks) -> {n * t:.1f} s/slide"}
+
+
+def main_titan(args):
+    """BASELINE config 4: TITAN backbone configuration (model_configs/modaltune_titan_config.json), ~4k foreground cells, mixed bag
+    lengths.  The TITAN snapshot is not in the reference tree: the backbone is a random-init ViT of TITAN's published geometry
+    (768-d, 6 blocks, 12 heads x 64, MLP ratio 4, 2-D ALiBi, one-query attentional pooling: tests/golden/titan_standin.py) running
+    on the native kernels -- backbone arithmetic parity against the real snapshot is UNPINNED and the line says so."""
+    import torch
+    if args.gpus != 1:
+        raise RuntimeError("--config titan is a 1-GPU line (slides shard over ranks exactly as in the gigapath configuration)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import titan_standin
+    from modaltune_amd import ops, synth
+    from modaltune_amd.config import flops_per_titan_step
+    from modaltune_amd.titan import NativeBackbone, TitanEngine, titan_model_config
+    from modaltune_amd.trainer import TrainStep
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    vit = titan_standin.VisionTransformer(mlp_ratio=4.0)
+    titan_standin.init_standin(vit, 0)
+    vit_cpu = titan_standin.VisionTransformer(mlp_ratio=4.0)
+    vit_cpu.load_state_dict(vit.state_dict())
+    sizes = synth.toy_group_sizes(int(args.pathways) if args.pathways != "real" else 6)
+    cfg = titan_model_config(TITAN_JSON, 3, False, 6)
+    eng = TitanEngine(cfg, sizes, NativeBackbone(vit, dev), dev)
+    report = eng.backbone.report
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed=0))
+    eng.set_stochastic(not args.no_dropout, seed=20260)      # train mode: Extractor-FFN DropPath(0.2), gene-encoder dropouts
+    ts = TrainStep(eng)
+    ts.set_projector(synth.projector_state(0))
+    Lc = args.patches if args.patches != 10000 else 4096
+    fr = (1.0, 0.625, 1.375, 0.75, 1.5, 0.5, 1.125, 0.875) if args.ragged else (1.0,)      # 2048 .. 6144 around 4096
+    slides, cells_per = [], []
+    for j, f in enumerate(fr):
+        want = int(Lc * f)
+        L = want + want // 15                    # a sixteenth of the patches share a cell with another (synth_inputs_titan)
+        inp = synth.synth_inputs_titan(L, sizes, seed=2000 + j, grid=96)
+        slides.append((torch.from_numpy(inp["x"]).to(dev).reshape(L, -1).contiguous(), torch.from_numpy(inp["coords"]).to(dev).reshape(L, 2),
+                       [torch.from_numpy(a).to(dev) for a in inp["genes"]], torch.from_numpy(inp["text"]).to(dev)))
+        cells_per.append(L - L // 16)
+
+    def run(n, first=0):
+        for i in range(first, first + n):
+            x, coords, genes, text = slides[i % len(slides)]
+            ts.step(x, coords, genes, text, update=True)
+
+    nwarm = max(args.warmup, len(slides))
+    run(nwarm)
+    eng.check_inputs()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, first=nwarm)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss = float(ts.loss)
+    prof_steps = len(slides)
+    ops.TIMER = {}
+    run(prof_steps, first=0)
+    torch.cuda.synchronize()
+    timer, ops.TIMER = ops.TIMER, None
+    summ = ops.timer_summary(timer)
+    T = cfg.num_tokens
+    used = [cells_per[i % len(slides)] for i in range(nwarm, nwarm + args.steps)]
+    step_flops = sum(flops_per_titan_step(c, T)["step"] for c in used) / len(used)
+    value = args.steps / dt
+    # dominant kernel: the dK / dV kernel of the dense attention backward, one launch per block per step over the 3 passes;
+    # algorithmic FLOPs per launch = S, dP, dV, dK = 2 x the forward's two products, averaged over the profiled bag lengths
+    n_l, ms = summ["dense_attn_bwd_kv"]
+    kv_flops = sum(2.0 * 3 * flops_per_titan_step(c, T)["attn_layer"] for c in cells_per) / len(cells_per)
+    achieved = kv_flops / (ms / n_l * 1e-3) / 1e12
+    table = []
+    for key, mult in (("dense_attn_fwd", 1.0), ("dense_attn_bwd_kv", 2.0), ("dense_attn_bwd_q", 1.5)):
+        if key in summ:
+            n, m_ = summ[key]
+            fl = sum(mult * 3 * flops_per_titan_step(c, T)["attn_layer"] for c in cells_per) / len(cells_per)
+            a_ = fl / (m_ / n * 1e-3) / 1e12
+            table.append({"kernel": key, "bound": "mfma", "achieved": round(a_, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(a_ / PEAK_F16_MFMA_TFLOPS, 4), "avg_launch_ms": round(m_ / n, 4), "ms_per_step": round(m_ / prof_steps, 3)})
+    out = {
+        "metric": "slides/sec (train step), TITAN backbone configuration, ~4k foreground cells", "value": value, "unit": "slides/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 4: TITAN-geometry ViT (768-d, 6 blocks, 12 heads x 64, MLP 3072, 2-D ALiBi in-kernel, attentional pooling; "
+                               f"random init, stand-in for the absent MahmoodLab/TITAN snapshot: backbone parity UNPINNED) + Modal Adapter, "
+                               f"{T - 1} gene tokens + 1 task token, 3 task passes batched, fp16 operands / fp32 accumulate, eager schedule, "
+                               + ("train mode (DropPath 0.2 on the Extractor FFN, gene-encoder dropouts), " if not args.no_dropout else "dropout off, ") +
+                               f"foreground cells per slide: " + "/".join(str(c) for c in cells_per) + (" in rotation (mixed bag lengths)" if args.ragged else ""),
+                   "cells": cells_per, "tokens": T, "parallelism": "dp1", "backbone_impl": eng.backbone.kind, "self_check": report},
+        "loss": loss, "step_tflops": step_flops / 1e12, "step_mfma_frac": step_flops * value / 1e12 / PEAK_F16_MFMA_TFLOPS,
+        "roofline": {"kernel": "dense_attn_bwd_kv_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms / n_l, "flops_per_launch": kv_flops,
+                     "measured": f"HIP events around each launch, eager instrumented pass over the {prof_steps} bag lengths after the timed region"},
+        "roofline_kernels": table, "launch": "eager",
+        "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:14]},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = titan_cpu_baseline(vit_cpu, int(sum(cells_per) / len(cells_per)) + 1, 6, 3)
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
+    if args.config == "titan":
+        return main_titan(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 

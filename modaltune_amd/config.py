@@ -194,3 +194,22 @@ def flops_per_slide_step(L: int, T: int, depth: int = 12, seg=None, tasks: int =
     step = tasks * (fwd + bwd) - (tasks - 1) * patch
     return {"fwd_pass": fwd, "bwd_pass": bwd, "step": step, "gemm_layer": gemm_layer,
             "attn_layer": attn_layer, "attn_layer_executed": attn_exec, "adapter": adapter, "patch": patch}
+
+
+def flops_per_titan_step(Lv: int, T: int, depth: int = 6, D: int = 768, F: int = 3072, C: int = 768, tasks: int = 3) -> Dict[str, float]:
+    """Algorithmic FLOPs of one TITAN-configuration slide step with Lv foreground cells (same counting rules as
+    flops_per_slide_step: 2mnk GEMMs, 4 nq nk d attention, frozen blocks dX-only in the backward, flash backward = 2.5 x
+    forward, adapters 2 x): dense ViT blocks qkv + proj + fc1 + fc2 (TA:359-361), patch-embedding MLP once per slide, attentional
+    pooling K|V projection (TA:401-402), Injector x3 / Extractor x5 as in the LongNet path."""
+    N, E = Lv + 1, 192
+    patch = 2.0 * Lv * (C * D + D * D)
+    gemm_layer = 2.0 * N * (4 * D * D + 2 * D * F)
+    attn_layer = 4.0 * N * N * D
+    pool = 2.0 * N * D * 2 * D
+    inj = 2.0 * Lv * (D * E + E * E + E * E + E * D) + 4.0 * Lv * T * E + 2.0 * T * 2 * D * E
+    ext = 2.0 * T * (D * E + E * E + E * E + E * D) + 4.0 * Lv * T * E + 2.0 * Lv * 2 * D * E + 2.0 * T * 2 * D * E
+    adapter = 3 * inj + 5 * ext
+    fwd = depth * (gemm_layer + attn_layer) + adapter + pool
+    bwd = depth * (gemm_layer + 2.5 * attn_layer) + 2 * adapter + pool
+    return {"fwd_pass": fwd, "bwd_pass": bwd, "step": tasks * (fwd + bwd) + patch, "gemm_layer": gemm_layer, "attn_layer": attn_layer,
+            "adapter": adapter, "patch": patch}

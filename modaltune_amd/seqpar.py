@@ -132,12 +132,13 @@ class SeqParallelAttention:
 
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
         out = torch.empty((self.W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        # flat views: every backend accepts the concatenated form [W * n] <- [n]
         if self._host_staged():
-            h = torch.empty(out.shape, dtype=t.dtype)
-            self.dist.all_gather_into_tensor(h, t.cpu(), group=self.group)
-            out.copy_(h)
+            h = torch.empty(out.numel(), dtype=t.dtype)
+            self.dist.all_gather_into_tensor(h, t.reshape(-1).cpu(), group=self.group)
+            out.view(-1).copy_(h)
         else:
-            self.dist.all_gather_into_tensor(out, t, group=self.group)
+            self.dist.all_gather_into_tensor(out.view(-1), t.reshape(-1), group=self.group)
         return out
 
     def _exchange_plan(self):

@@ -627,6 +627,8 @@ class TitanEngine(Engine):
             sp[f"hin{l}"] = (F32, (M, D))
         for i in range(len(cfg.interaction_indexes)):
             sp[f"hout{i}"] = (F32, (M, D))
+        if self.stochastic:
+            sp["x0d"] = (F32, (4,))       # (Engine._workspace keys its rebuild on this name; the TITAN config has no input dropout)
         if self.native:
             sp.update(self.backbone.ws_spec(B, Lx))
         return sp

@@ -76,6 +76,7 @@ class TrainStep:
         self._static_key = None
         self.graph_replays = 0
         self.eager_steps = 0
+        self.patch_size_lv0 = 1024          # TITAN configuration only (titan_adapter.py:335)
 
     # ------------------------------------------------------------------ learning-rate schedule hook
     @property
@@ -135,7 +136,10 @@ class TrainStep:
             ops.rng_advance(eng.rng)          # a fresh set of dropout / DropPath masks per step
         target = self.project_text(text)
         eng.store.flat_grad.zero_()
-        if staged_geometry is None:
+        if staged_geometry is None and hasattr(eng, "forward_slide"):      # TITAN configuration: gridding + backbone embed first
+            logits = eng.forward_slide(x, coords, genes, self.onehots, patch_size_lv0=self.patch_size_lv0, need_grad=True,
+                                       clinical=clinical)
+        elif staged_geometry is None:
             logits = eng.forward(x, coords, genes, self.onehots, need_grad=True, clinical=clinical)
         else:
             logits = eng.forward(None, None, genes, self.onehots, need_grad=True, staged=True, geometry=staged_geometry,
@@ -191,6 +195,9 @@ class TrainStep:
         first.  With world_size > 1 the capture is cut where a gradient bucket becomes final: the reducer starts that
         bucket's all-reduce between two replays, and the optimiser graph runs after the wait."""
         eng = self.engine
+        if hasattr(eng, "forward_slide"):
+            raise NotImplementedError("the TITAN configuration runs the eager schedule (TrainStep.step): every slide has its own "
+                                      "token count, known only after the on-device gridding")
         if not eng._caches_ready:
             eng._build_caches()
         x = x.reshape(-1, x.shape[-1])

@@ -2,7 +2,7 @@
 # One round's profile set on the GPU box (everything lands under gpurun_out/prof_$1/):
 #   bench line + per-kernel times, rocprofv3 kernel-trace stats of the same command, ragged / eager bench lines,
 #   SQ counters of the attention kernels, HBM counters of the attention backward kernels.
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag; mkdir -p $out
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 python bench.py --kernel-times > $out/bench.json 2> $out/kernel_times.txt
@@ -16,4 +16,8 @@ python tools/pmc_summary.py gpurun_out/pmc_${tag}_fwd > $out/pmc_attn_fwd.txt
 python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd > $out/pmc_attn_bwd.txt
 python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd/f > $out/pmc_hbm_f.txt; python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd/w > $out/pmc_hbm_w.txt
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+# BASELINE config 4 (TITAN configuration, mixed bag lengths): bench line + rocprofv3 kernel-trace stats of the same command
+python bench.py --config titan --patches 4096 --ragged --steps 16 --warmup 8 > $out/titan_bench.json 2> $out/titan_bench.err
+rocprofv3 --kernel-trace --stats -d $out/titan_stats -o s --output-format csv -- python3 bench.py --config titan --patches 4096 --ragged --steps 16 --warmup 8 --no-cpu-baseline > $out/titan_stats.log 2>&1
+find $out/titan_stats -name "*kernel_stats.csv" -exec cp {} $out/titan_kernel_stats.csv \;
 echo profile set done
