@@ -95,22 +95,58 @@ def grad_buckets(slots: dict, n_interactions: int, n_flat: int) -> List[List[tup
 
 
 class GradReducer:
-    """start(b): launch the SUM all-reduce of bucket b's ranges (asynchronous: RCCL runs it on its own stream behind
-    everything enqueued so far on the current stream); wait(): make the current stream wait for every collective in
-    flight.  These are the `mt_grad_allreduce_start / _wait` of SURVEY §8b; they live above the C ABI because the
-    communicator belongs to torch.distributed ("nccl" = RCCL over xGMI on the GPUs, gloo in the rehearsals)."""
+    """start(b): launch the collective of bucket b's ranges (asynchronous: RCCL runs it on its own stream behind everything
+    enqueued so far on the current stream); wait(): make the current stream wait for every collective in flight.  These are
+    the `mt_grad_allreduce_start / _wait` of SURVEY §8b; they live above the C ABI because the communicator belongs to
+    torch.distributed ("nccl" = RCCL over xGMI on the GPUs, gloo in the rehearsals).
 
-    def __init__(self, flat_grad: torch.Tensor, buckets: List[List[tuple]], group=None):
+    Buckets 0 .. last-1 are SUM all-reduced.  The LAST bucket (gene encoder + token parameters: 3 MB with toy pathways, 100 MB
+    with the reference's 331) closes with the backward itself, so nothing can hide it; with `flat_param` given it is SHARDED
+    instead (reduce-scatter + all-gather as separate exchanges): reduce-scatter of the gradients -> every rank runs
+    AdamW on its 1/W of the bucket (`adam_pieces`) -> all-gather of the updated PARAMETERS (`start_param_gather`, waited for at
+    the top of the next step by `wait_params`, i.e. under the next slide's input staging).  What is exposed in front of AdamW is
+    the reduce-scatter alone -- half the bytes of the all-reduce -- and the optimiser touches 1/W of the bucket."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[List[tuple]], group=None, flat_param: Optional[torch.Tensor] = None,
+                 shard_last: bool = True):
         self.flat, self.buckets, self.group = flat_grad, buckets, group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.views = [[flat_grad[o:o + n] for o, n in bk] for bk in buckets]
         self.pending: list = []
         self.started: set = set()
+        self.param = flat_param
+        self.sharded = bool(self.world > 1 and shard_last and flat_param is not None and len(buckets) > 0)
+        self._param_pending: list = []
+        self._rs: list = []                   # (range offset, elements per rank, reduce-scatter output buffer)
+        self._tails: list = []                # (offset, length) of the few elements past W * s of a range: plain all-reduce
+        if self.sharded:
+            W = self.world
+            for o, n in buckets[-1]:
+                s = (n // (4 * W)) * 4        # elements per rank: 16-byte aligned shards, [o, o + W s) is reduce-scattered
+                if s > 0:
+                    self._rs.append((o, s, torch.empty(s, dtype=flat_grad.dtype, device=flat_grad.device)))
+                if n - W * s > 0:
+                    self._tails.append((o + W * s, n - W * s))
+        self._host = self.world > 1 and dist.get_backend(group) == "gloo"      # rehearsal backend: RS / AG through host copies
 
+    # -- gradient side
     def start(self, b: int):
         if self.world == 1 or b in self.started:
             return
         self.started.add(b)
+        if self.sharded and b == len(self.buckets) - 1:
+            for o, s, out in self._rs:
+                src = self.flat[o:o + self.world * s]
+                if self._host:
+                    h = torch.empty(s, dtype=src.dtype)
+                    dist.reduce_scatter_tensor(h, src.cpu(), op=dist.ReduceOp.SUM, group=self.group)
+                    out.copy_(h)
+                else:
+                    self.pending.append(dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for o, n in self._tails:
+                self.pending.append(dist.all_reduce(self.flat[o:o + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
         for v in self.views[b]:
             self.pending.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -119,9 +155,56 @@ class GradReducer:
             self.start(b)
 
     def wait(self) -> int:
-        """Returns the world size (the mean is folded into AdamW as grad_mult = 1 / world)."""
+        """Returns the world size (the mean is folded into AdamW as grad_mult = 1 / world).  Sharded: this rank's slice of the
+        last bucket now holds the summed gradient (the other slices keep their local values and are not read)."""
         for w in self.pending:
             w.wait()
         self.pending.clear()
+        if self.sharded and (len(self.buckets) - 1) in self.started:
+            for o, s, out in self._rs:
+                self.flat[o + self.rank * s:o + (self.rank + 1) * s].copy_(out)
         self.started.clear()
         return self.world
+
+    def sync_flag_(self, flag: torch.Tensor):
+        """found_inf must be the same on every rank (GradScaler skips the WHOLE step): with a sharded bucket a rank only sees
+        its own slice of the sums, so the flags are MAX-reduced (4 bytes)."""
+        if self.sharded:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+
+    def adam_pieces(self, n_flat: int) -> List[tuple]:
+        """(offset, length) ranges of the flat buffers THIS rank's optimiser step updates: everything outside the sharded
+        bucket, the tails, and its own shard of every reduce-scattered range."""
+        if not self.sharded:
+            return [(0, n_flat)]
+        skip = sorted((o, o + self.world * s, s) for o, s, _ in self._rs)
+        out, cur = [], 0
+        for a, b, s in skip:
+            if a > cur:
+                out.append((cur, a - cur))
+            out.append((a + self.rank * s, s))
+            cur = b
+        if cur < n_flat:
+            out.append((cur, n_flat - cur))
+        return out
+
+    # -- parameter side (sharded bucket only)
+    def start_param_gather(self):
+        """After the optimiser step: every rank's updated shard -> all ranks (asynchronous)."""
+        if not self.sharded:
+            return
+        W, r = self.world, self.rank
+        for o, s, _ in self._rs:
+            full = self.param[o:o + W * s]
+            mine = self.param[o + r * s:o + (r + 1) * s]
+            if self._host:
+                h = torch.empty(W * s, dtype=full.dtype)
+                dist.all_gather_into_tensor(h, mine.cpu(), group=self.group)
+                full.copy_(h)
+            else:       # in place: this rank's input IS its slot of the output (the RCCL in-place form)
+                self._param_pending.append(dist.all_gather_into_tensor(full, mine, group=self.group, async_op=True))
+
+    def wait_params(self):
+        for w in self._param_pending:
+            w.wait()
+        self._param_pending.clear()

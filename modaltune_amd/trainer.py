@@ -64,7 +64,8 @@ class TrainStep:
         # data-parallel reducer (buckets in the order the backward finalises them)
         nint = len(engine.cfg.interaction_indexes)
         self._nint = nint
-        self.reducer = dp.GradReducer(engine.store.flat_grad, dp.grad_buckets(engine.store.slots, nint, n), process_group)
+        self.reducer = dp.GradReducer(engine.store.flat_grad, dp.grad_buckets(engine.store.slots, nint, n), process_group,
+                                      flat_param=engine.store.flat)
         # captured graphs: LRU over bag geometries (real data has a new length almost every slide: a geometry is captured
         # only once it has been seen `capture_after` times, everything else runs the eager schedule)
         self.graph_cache_size, self.capture_after = int(graph_cache_size), int(capture_after)
@@ -131,6 +132,7 @@ class TrainStep:
 
     def _fwd_bwd(self, x, coords, genes, text, clinical, staged_geometry=None, reduce: bool = True):
         eng = self.engine
+        self.reducer.wait_params()        # the all-gather of the last step's sharded parameter update (no-op otherwise)
         eng.grad_ready_hook = self._on_grad_ready if (reduce and self._world() > 1) else None
         if eng.stochastic:
             ops.rng_advance(eng.rng)          # a fresh set of dropout / DropPath masks per step
@@ -163,21 +165,38 @@ class TrainStep:
         finally:
             eng.grad_ready_hook = None        # a later direct eng.forward / backward must not start stray collectives
 
-    def _adam_and_refresh(self, world: int):
+    def _check_finite(self):
+        """GradScaler's inf check over what this rank holds; with a sharded last bucket the flag is MAX-reduced so that every
+        rank takes the same skip decision (a collective: never inside a captured graph)."""
+        eng = self.engine
+        ops.check_finite(eng.store.flat_grad, eng.store.n_flat, self.found_inf)
+        self.reducer.sync_flag_(self.found_inf)
+
+    def _adam_and_refresh(self, world: int, check: bool = True):
         eng = self.engine
         n = eng.store.n_flat
-        ops.check_finite(eng.store.flat_grad, n, self.found_inf)
-        ops.adamw_step(eng.store.flat, eng.store.flat_grad, self.m, self.v, n, self._lr, self.betas[0], self.betas[1], self.eps,
-                       self.wd, 0, scale=self.scale, found_inf=self.found_inf, grad_mult=1.0 / world, step_dev=self.step_dev,
-                       lr_dev=self.lr_dev)
+        if check:
+            ops.check_finite(eng.store.flat_grad, n, self.found_inf)
+        p, g = eng.store.flat, eng.store.flat_grad
+        for o, k in self.reducer.adam_pieces(n):      # one launch, or: everything but the sharded bucket + this rank's shards
+            ops.adamw_step(p[o:o + k], g[o:o + k], self.m[o:o + k], self.v[o:o + k], k, self._lr, self.betas[0], self.betas[1], self.eps,
+                           self.wd, 0, scale=self.scale, found_inf=self.found_inf, grad_mult=1.0 / world, step_dev=self.step_dev,
+                           lr_dev=self.lr_dev)
         ops.scaler_update(self.scale, self.tracker, self.found_inf, self.step_dev, 2.0, 0.5, self.growth_interval)
         eng.refresh_trainable_caches()
 
     def optimizer_step(self):
-        """Launch whatever buckets the backward has not started, wait for the collectives, AdamW + weight-cache refresh."""
+        """Launch whatever buckets the backward has not started, wait for the collectives, AdamW + weight-cache refresh; with
+        a sharded last bucket (world > 1) the updated shards are then all-gathered asynchronously (waited for at the top of the
+        next step)."""
         self.reducer.start_rest()
         world = self.reducer.wait()
-        self._adam_and_refresh(world)
+        if self.reducer.sharded:
+            self._check_finite()
+            self._adam_and_refresh(world, check=False)
+            self.reducer.start_param_gather()
+        else:
+            self._adam_and_refresh(world)
 
     def step(self, x, coords, genes, text, update: bool = True, clinical=None) -> torch.Tensor:
         """One train step on one slide, eager launches.  Returns the (device) loss scalar; no host sync happens here."""
@@ -212,6 +231,7 @@ class TrainStep:
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
             self._gcache.clear()
         eng.stage_inputs(x, coords, B=B)          # (may grow the workspace: bumps eng.generation)
+        self.reducer.wait_params()                # last step's sharded parameter all-gather ran under the staging above
         self._sgenes.copy_(gflat, non_blocking=True)
         self._stext.copy_(text, non_blocking=True)
         if self._sclin is not None:
@@ -257,7 +277,10 @@ class TrainStep:
         if world > 1:
             self.reducer.start_rest()
             self.reducer.wait()
+            if self.reducer.sharded:
+                self._check_finite()
             self._opt_graph.replay()
+            self.reducer.start_param_gather()
         return self.loss
 
     @property
@@ -295,7 +318,7 @@ class TrainStep:
                 og = torch.cuda.CUDAGraph()
                 og.capture_begin(pool=pool, capture_error_mode="thread_local")
                 try:
-                    self._adam_and_refresh(world)
+                    self._adam_and_refresh(world, check=not self.reducer.sharded)
                 finally:
                     og.capture_end()
                 self._opt_graph = og

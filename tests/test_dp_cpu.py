@@ -58,6 +58,33 @@ def _worker(rank, world, port, n):
         assert red.wait() == world and not red.pending
         want = torch.arange(st.n_flat, dtype=torch.float32) % 1000 * sum(r + 1 for r in range(world))
         assert torch.equal(st.flat_grad, want)
+        # sharded last bucket (reduce-scatter -> AdamW on the shard -> all-gather of the parameters): every rank
+        # ends with the parameters a full all-reduce + full update gives; a rank updates exactly n_flat - (W-1)/W of the
+        # reduce-scattered ranges; the flag sync makes found_inf global
+        g0 = torch.sin(torch.arange(st.n_flat, dtype=torch.float32) * 0.37) * (rank + 1)
+        st.flat_grad.copy_(g0)
+        st.flat.copy_(torch.cos(torch.arange(st.n_flat, dtype=torch.float32) * 0.11))
+        p0 = st.flat.clone()
+        red = dp.GradReducer(st.flat_grad, buckets, flat_param=st.flat)
+        assert red.sharded and red._rs
+        red.start_rest()
+        assert red.wait() == world
+        pieces = red.adam_pieces(st.n_flat)
+        total = torch.sin(torch.arange(st.n_flat, dtype=torch.float32) * 0.37) * sum(r + 1 for r in range(world))
+        covered = torch.zeros(st.n_flat, dtype=torch.bool)
+        for o, k in pieces:
+            assert not covered[o:o + k].any()
+            covered[o:o + k] = True
+            assert torch.allclose(st.flat_grad[o:o + k], total[o:o + k], rtol=1e-6, atol=1e-6)      # what the optimiser reads is the SUM
+            st.flat[o:o + k] -= 0.1 * st.flat_grad[o:o + k]                                       # stand-in for AdamW on the piece
+        sharded_elems = sum(world * s_ for _, s_, _ in red._rs)
+        assert int(covered.sum()) == st.n_flat - sharded_elems + sharded_elems // world
+        red.start_param_gather()
+        red.wait_params()
+        assert torch.allclose(st.flat, p0 - 0.1 * total, rtol=1e-6, atol=1e-6)                      # == all-reduce + full update
+        flag = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
+        red.sync_flag_(flag)
+        assert int(flag) == 1
     finally:
         dist.destroy_process_group()
 
