@@ -50,6 +50,10 @@ def parse_args():
     ap.add_argument("--ragged", action="store_true", help="a different bag length every step (8 lengths in [0.5, 1] x --patches): "
                                                           "the steady state of real data; runs the eager schedule")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--api", default="trainstep", choices=["trainstep", "module"],
+                    help="trainstep: the fused TrainStep (3 task passes batched, device-side loss / GradScaler / AdamW, hipGraph replay); "
+                         "module: the reference trainer's own loop on the drop-in nn.Module (train_modaltune.py:172-177,225-238): "
+                         "3x model(...) -> torch KL loss -> GradScaler.scale(loss).backward() -> torch.optim.AdamW.step()")
     ap.add_argument("--config", default="gigapath", choices=["gigapath", "titan"],
                     help="gigapath: BASELINE config 2 (the headline metric); titan: BASELINE config 4 (TITAN backbone configuration, "
                          "--patches foreground cells, --ragged: mixed bag lengths) -- a separate JSON line, never the headline")
@@ -346,10 +350,92 @@ def main_titan(args):
     print(json.dumps(out))
 
 
+def main_module(args):
+    """The boundary north_star names, driven exactly as the reference trainer drives it (train_modaltune.py:123-149,172-177,
+    195-240): Aggregator.create -> per step the frozen torch projector, three model(...) calls (one per task id), torch's
+    KL-divergence loss under autocast, GradScaler.scale(loss).backward(), GradScaler.step(torch.optim.AdamW), update, zero_grad."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    if args.gpus != 1:
+        raise RuntimeError("--api module is a 1-GPU line")
+    from modaltune_amd import synth
+    from modaltune_amd.aggregators import Aggregator
+    from modaltune_amd.config import flops_per_slide_step
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    L = args.patches
+    sizes = json.load(open(os.path.join(ROOT, "tests", "golden", "pathway_sizes_331.json"))) if args.pathways == "real" else \
+        synth.toy_group_sizes(int(args.pathways))
+    groups = {i: ["g%d_%d" % (i, j) for j in range(n)] for i, n in enumerate(sizes)}
+    kw = {} if not args.no_dropout else dict(dropout=0.0, drop_path_rate=0.0)
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3, **kw).to(dev)      # TM:123-126
+    cfg = model.cfg
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, sizes, seed=0).items()}, strict=True)
+    params = [{"params": list(filter(lambda p: p.requires_grad, model.parameters())), "lr": 1e-4 / 20}]             # TM:139-149
+    opt = torch.optim.AdamW(params, weight_decay=0.01, betas=(0.9, 0.999))
+    scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=2.0 ** 15)                                        # TM:107
+    psd = {k: torch.from_numpy(v).to(dev) for k, v in synth.projector_state(0).items()}
+
+    def projector(t):       # Projection_layer (TM:44-59): frozen random Conv1x1 -> LayerNorm -> ReLU -> Conv1x1, the trainer's own torch code
+        h = F.linear(t, psd["conv1.0.weight"].flatten(1), psd["conv1.0.bias"])
+        h = F.layer_norm(h, (h.shape[-1],), psd["conv1.1.weight"].flatten(), psd["conv1.1.bias"].flatten(), 1e-5)
+        return F.linear(F.relu(h), psd["conv1.3.weight"].flatten(1), psd["conv1.3.bias"])
+    loss_fn = nn.KLDivLoss(reduction="sum")
+    eye = torch.eye(3, device=dev)
+    slides = []
+    for j in range(2):
+        inp = synth.synth_inputs(L, sizes, seed=1000 + j, grid=128 if L <= 128 * 128 else 512)
+        slides.append((torch.from_numpy(inp["x"]).to(dev), torch.from_numpy(inp["coords"]).to(dev),
+                       {i: torch.from_numpy(a).to(dev) for i, a in enumerate(inp["genes"])}, torch.from_numpy(inp["text"]).to(dev)))
+    model.train()
+    last = {}
+
+    def step(i):
+        images, coords, gene_data, text = slides[i % len(slides)]
+        text = projector(text)
+        text = text / text.norm(dim=-1, keepdim=True)
+        with torch.autocast("cuda", enabled=True):
+            logit = torch.cat([model(x=images, coords=coords, genes=gene_data, clinical=[], task_token=eye[t]) for t in (0, 1, 2)], dim=0)
+            logit = logit / logit.norm(dim=-1, keepdim=True)
+            loss = loss_fn(F.log_softmax(logit, dim=1), F.softmax(text[[0, 1, 3], :], dim=1)) * 10
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad()
+        last["loss"] = loss.detach()
+
+    nwarm = max(args.warmup, 3)
+    for i in range(nwarm):
+        step(i)
+    model.engine.check_inputs()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(nwarm, nwarm + args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    T = cfg.num_tokens
+    fl = flops_per_slide_step(L, T)
+    value = args.steps / dt
+    out = {"metric": "slides/sec (train step) at 10k patches x 1536-d", "value": value, "unit": "slides/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16", "data": "synthetic",
+           "config": {"workload": f"Prov-GigaPath ModalAdapter train step through the drop-in nn.Module exactly as train_modaltune.py drives it "
+                                  f"(3 model calls, torch KL loss, GradScaler, torch.optim.AdamW), {L} patches x 1536-d, {len(sizes)} pathways -> {T - 1} gene "
+                                  f"tokens + 1 task token, 1 slide per step, eager, " + ("dropout off" if args.no_dropout else "train mode (Dropout / DropPath on)"),
+                      "api": "module", "patches": L, "tokens": T, "parallelism": "dp1"},
+           "loss": float(last["loss"]), "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / 1e12 / PEAK_F16_MFMA_TFLOPS,
+           "launch": "eager (torch autograd + torch.optim)"}
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
     if args.config == "titan":
         return main_titan(args)
+    if args.api == "module":
+        return main_module(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 

@@ -253,13 +253,16 @@ int mt_dense_attn_bwd(const mt_half* qkv, const mt_half* o, const mt_half* d_o, 
 int mt_gelu_f16_fwd(const mt_half* x, mt_half* y, long n, mt_stream_t stream);
 int mt_gelu_f16_bwd(const mt_half* x, const mt_half* dy, mt_half* dx, long n, mt_stream_t stream);
 
-/* Attentional pooling core (TA:401-402 `forward_attn_pool`): nq learned queries attend over the N tokens of every pass.
- * q fp32 [nq, E] (projected; frozen, so no dq); kv fp16 [B*N, 2E] (k | v projected); out fp32 [B, nq, E]; probs fp32
- * [B, heads, nq, N] (saved).  backward: dkv fp16 [B*N, 2E] (overwritten). */
-int mt_pool_attn_fwd(const float* q, const mt_half* kv, int B, int N, int E, int heads, int nq, float* out, float* probs,
-                     mt_stream_t stream);
-int mt_pool_attn_bwd(const float* q, const mt_half* kv, const float* probs, const float* dout, int B, int N, int E, int heads,
-                     int nq, mt_half* dkv, mt_stream_t stream);
+/* Attentional pooling core (TA:401-402 `forward_attn_pool`): nq learned queries attend over the N tokens of every pass, keys
+ * split over workgroups (flash-decoding form).  q fp32 [nq, E] (projected; frozen, so no dq); kv fp16 [B*N, 2E] (k | v
+ * projected); out fp32 [B, nq, E]; scores fp32 [B, heads, nq, N] (raw scaled logits, saved) and lse fp32 [B, heads, nq]: the
+ * backward recomputes p = exp(score - lse); workspace: mt_pool_attn_workspace_floats() floats.
+ * backward: dkv fp16 [B*N, 2E] (overwritten) from scores, lse, out and dout (fp32 [B, nq, E]). */
+long mt_pool_attn_workspace_floats(int B, int N, int heads, int nq);
+int mt_pool_attn_fwd(const float* q, const mt_half* kv, int B, int N, int E, int heads, int nq, float* out, float* scores,
+                     float* lse, float* workspace, mt_stream_t stream);
+int mt_pool_attn_bwd(const float* q, const mt_half* kv, const float* scores, const float* lse, const float* out,
+                     const float* dout, int B, int N, int E, int heads, int nq, mt_half* dkv, mt_stream_t stream);
 
 /* ------------------------------------------------------------ adapter ops -------------------------- */
 /* Injector attention core (AM:225-229 inside AM:359-369): for each of M patch rows and 12 heads (dim 16):

@@ -111,8 +111,9 @@ SIGNATURES = {
     "mt_dense_attn_bwd": [P, P, P, P, DP, P, P, I, P],
     "mt_gelu_f16_fwd": [P, P, L, P],
     "mt_gelu_f16_bwd": [P, P, P, L, P],
-    "mt_pool_attn_fwd": [P, P, I, I, I, I, I, P, P, P],
-    "mt_pool_attn_bwd": [P, P, P, P, I, I, I, I, I, P, P],
+    "mt_pool_attn_workspace_floats": [I, I, I, I],
+    "mt_pool_attn_fwd": [P, P, I, I, I, I, I, P, P, P, P, P],
+    "mt_pool_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, P, P],
     "mt_titan_grid": [P, I, F, P, P, P, P],
     "mt_titan_cell_sums": [P, L, P, I, I, P, P, P, P, P],
     "mt_titan_token_order": [P, P, P, I, P, P, P, P],
@@ -120,7 +121,7 @@ SIGNATURES = {
     "mt_scatter_rows_f32": [P, P, P, P, I, I, I, P],
     "mt_row_absmax_f32": [P, P, I, I, P],
 }
-_RESTYPE = {"mt_status_string": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long}
+_RESTYPE = {"mt_status_string": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long, "mt_pool_attn_workspace_floats": C.c_long}
 
 _lib = None
 

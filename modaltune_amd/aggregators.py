@@ -43,41 +43,84 @@ class Aggregator(nn.Module):
         return cls.subclasses[subclass_name](**params)
 
 
+class _StepGroup:
+    """The forward calls of ONE slide that a single backward pass will meet: the reference calls the model once per task id and
+    then runs loss.backward() (TM:172-177,235).  Calls of a group are chained in the autograd graph through a scalar token, so
+    the engine runs their backward nodes last-call-first and the FIRST call's node runs last; every node replays its tape into
+    the same flat gradient buffer and only that last node hands the (unscaled) sum to autograd -- one zero / unscale / hand-over
+    per step instead of one per call, and every parameter's AccumulateGrad (and DDP reducer hook) fires exactly once."""
+    __slots__ = ("key", "token", "count", "limit", "scale", "started", "share")
+
+    def __init__(self, key, limit: int):
+        self.key, self.token, self.count, self.limit = key, None, 0, max(1, int(limit))
+        self.scale, self.started, self.share = None, False, {}
+
+
+def _slide_key(x, coords):
+    def k(t):
+        return (t.data_ptr(), t._version, tuple(t.shape), str(t.device)) if torch.is_tensor(t) else id(t)
+    return (k(x), k(coords))
+
+
+def _bridge_backward(ctx, dlogits):
+    """Shared by the LongNet and TITAN bridges: returns (gradient of the chain token input or None, tuple of parameter
+    gradients or Nones)."""
+    module, eng, grp = ctx.module, ctx.module.engine, ctx.group
+    store = eng.store
+    nparams = len(module._slots)
+    if ctx.call is None:
+        raise RuntimeError("backward through a forward that ran with gradients disabled (or a second backward through the same call)")
+    if dlogits is not None:
+        # The tape runs an fp16 activation-gradient stream: rescale the incoming gradients to max |.| = 2^10 on the DEVICE (no
+        # read-back; the factor of a group's first backward serves the whole group), run the tapes, undo the scale once when
+        # the flat gradient is handed over.
+        dl = dlogits.to(F32).contiguous()
+        if not grp.started:
+            grp.scale = torch.empty(2, dtype=F32, device=dl.device)
+            ops.absmax_scale(dl, grp.scale, 1024.0)
+            store.flat_grad.zero_()
+            grp.started = True
+        scaled = torch.empty_like(dl)
+        ops.axpy_dev(None, dl, grp.scale[0:1], scaled)
+        hook, eng.grad_ready_hook = eng.grad_ready_hook, None      # (a TrainStep sharing the engine must not see this pass)
+        try:
+            eng.backward(scaled, call=ctx.call)
+        finally:
+            eng.grad_ready_hook = hook
+    ctx.call = None                                                # the tape and its private workspace are dead from here
+    if ctx.has_pred:       # an earlier call of the group runs after this node and delivers
+        return torch.zeros((), dtype=F32, device=store.flat_grad.device), (None,) * nparams
+    if module._group is grp:
+        module._group = None
+    if not grp.started:
+        return None, (None,) * nparams
+    out = torch.empty_like(store.flat_grad)
+    ops.axpy_dev(None, store.flat_grad, grp.scale[1:2], out)
+    grp.started = False
+    return None, tuple(out[o:o + n].view(shape) for o, n, shape in module._slots)
+
+
 class _ModelFn(torch.autograd.Function):
     """autograd bridge: forward runs the HIP engine (own tape + workspace per call); backward replays that call's tape.
     The trainable parameters are REAL inputs of the Function and their gradients its outputs, so autograd's
-    AccumulateGrad nodes run as for any module: `param.grad` accumulates over the three forward calls of a step
-    (TM:175-177), torch optimisers / GradScaler see ordinary gradients, and DistributedDataParallel's reducer hooks fire
-    (utils/base_trainer.py:205-211 wraps the model in DDP)."""
+    AccumulateGrad nodes run as for any module: torch optimisers / GradScaler see ordinary gradients, and
+    DistributedDataParallel's reducer hooks fire (utils/base_trainer.py:205-211 wraps the model in DDP).  The calls of one step
+    are chained (`_StepGroup`)."""
 
     @staticmethod
-    def forward(ctx, module, x, coords, genes, onehots, need, clinical, *params):
+    def forward(ctx, module, x, coords, genes, onehots, need, clinical, token, *params):
         eng = module.engine
-        logits = eng.forward(x, coords, genes, onehots, need_grad=need, fresh=need, clinical=clinical)
-        ctx.module, ctx.call, ctx.nparams = module, (eng.last_call if need else None), len(params)
-        return logits.clone()
+        ctx.set_materialize_grads(False)
+        grp = module._group if need else None
+        logits = eng.forward(x, coords, genes, onehots, need_grad=need, fresh=need, clinical=clinical,
+                             share=grp.share if grp is not None else None)
+        ctx.module, ctx.call, ctx.group, ctx.has_pred = module, (eng.last_call if need else None), grp, token is not None
+        return logits.clone(), torch.zeros((), dtype=F32, device=logits.device)
 
     @staticmethod
-    def backward(ctx, dlogits):
-        module, eng = ctx.module, ctx.module.engine
-        if ctx.call is None:
-            raise RuntimeError("backward through a forward that ran with gradients disabled")
-        store = eng.store
-        # The tape runs an fp16 activation-gradient stream: rescale the incoming gradient to max |.| = 2^10 on the DEVICE
-        # (no read-back), run the tape, and undo the scale while copying the flat gradient out.
-        dl = dlogits.to(F32).contiguous()
-        s = torch.empty(2, dtype=F32, device=dl.device)
-        ops.absmax_scale(dl, s, 1024.0)
-        scaled = torch.empty_like(dl)
-        ops.axpy_dev(None, dl, s[0:1], scaled)
-        hook, eng.grad_ready_hook = eng.grad_ready_hook, None      # (a TrainStep sharing the engine must not see this pass)
-        store.flat_grad.zero_()
-        eng.backward(scaled, call=ctx.call)
-        eng.grad_ready_hook = hook
-        out = torch.empty_like(store.flat_grad)
-        ops.axpy_dev(None, store.flat_grad, s[1:2], out)
-        grads = tuple(out[o:o + n].view(shape) for o, n, shape in module._slots)
-        return (None,) * 7 + grads
+    def backward(ctx, dlogits, dtoken):
+        tok, grads = _bridge_backward(ctx, dlogits)
+        return (None,) * 7 + (tok,) + grads
 
 
 @Aggregator.register("longnetvit_gene_adapter")
@@ -99,7 +142,26 @@ class LongNetGeneAdapter(Aggregator):
         self._slots = [self.engine.store.slots[k] for k in self._trainable]      # (offset, numel, shape) in the flat buffers
         self._versions = None
         self.training_grad = True
+        self._group = None
+        self._spec = self._hist = self._spec_rows = None      # speculative batching of the per-task calls (_forward_one_task)
+        self.speculate = True                                 # (False: every call runs on its own; the calls of a step still share one hand-over)
         self.train(True)
+
+    def _open_group(self, x, coords):
+        """The chain token for this call (None = first call of a new group) -- see _StepGroup.  A group is the consecutive
+        grad-mode calls on the same slide tensors, at most `multi_task` of them (what one step of the reference makes)."""
+        key = _slide_key(x, coords)
+        grp = self._group
+        if grp is not None and grp.key == key and grp.count < grp.limit and grp.token is not None:
+            return grp.token
+        self._group = _StepGroup(key, self.cfg.multi_task)
+        return None
+
+    def _close_call(self, need, out):
+        logits, tok = out
+        if need and self._group is not None:
+            self._group.token, self._group.count = tok, self._group.count + 1
+        return logits
 
     def train(self, mode: bool = True):
         """model.train() leaves Dropout / DropPath active in the reference (frozen != eval); eval() and
@@ -140,21 +202,82 @@ class LongNetGeneAdapter(Aggregator):
         if self.is_multi:
             if task_token is None:
                 raise ValueError("task_token is required when multi_task > 1")
-            onehots = task_token.reshape(1, -1)
-        else:
-            onehots = torch.zeros(1, 1, device=self.engine.device)
+            return self._forward_one_task(x, coords, genes, task_token.reshape(1, -1), clinical)
+        onehots = torch.zeros(1, 1, device=self.engine.device)
         return self.forward_tasks(x, coords, genes, onehots, clinical=clinical)
+
+    @staticmethod
+    def _gene_list(genes):
+        if isinstance(genes, dict):
+            return [genes[k] for k in sorted(genes.keys())] if all(isinstance(k, int) for k in genes) else list(genes.values())
+        return genes
+
+    def _extra_key(self):
+        return None
+
+    def _call_key(self, x, coords, genes, clinical, need):
+        """Identity of "the same slide under the same weights and mode": what makes a cached task pass reusable."""
+        def k(t):
+            return (t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else id(t)
+        gk = k(genes) if torch.is_tensor(genes) else tuple(k(g) for g in genes)
+        return (k(x), k(coords), gk, k(clinical) if self.CLINICAL else None, bool(need), bool(self.training), self._versions,
+                self.engine.stochastic, self._extra_key())
+
+    # -- speculative batching of the per-task calls (TM:156-179 `multitask_forward`: one model call per task id)
+    def _forward_one_task(self, x, coords, genes, onehot, clinical):
+        """The reference trainer calls the model once per task id with `torch.eye(num_tasks)[t]` (TM:174-176) and concatenates.
+        Everything but the task token is shared by those calls, so once the module has SEEN a slide served with task ids
+        r0, r1, ... it answers the next slide's first call (task r0) with ONE batched engine pass over all of them and hands the
+        later calls their rows of that result: one B = len(rows) forward, and -- the rows being slices of one autograd output --
+        one backward, exactly what the fused TrainStep runs.  A call that does not fit the prediction (other task id, repeated
+        id, different tensors / weights / mode) simply runs on its own and the observed pattern is learnt afresh.  Reading the
+        one-hot costs one small host read-back per call."""
+        genes = self._gene_list(genes)
+        if not self.speculate:
+            return self.forward_tasks(x, coords, genes, onehot, clinical=clinical)
+        self._sync_weight_caches()
+        need = torch.is_grad_enabled() and self.training_grad
+        vals = onehot.detach().reshape(-1).tolist()
+        row = vals.index(1.0) if (vals.count(1.0) == 1 and vals.count(0.0) == len(vals) - 1) else None
+        if row is None:                       # not a one-hot: no prediction possible
+            self._spec = self._hist = self._spec_rows = None
+            return self.forward_tasks(x, coords, genes, onehot, clinical=clinical)
+        key = self._call_key(x, coords, genes, clinical, need)
+        sp = self._spec
+        if sp is not None and sp["key"] == key and row in sp["rows"] and row not in sp["used"]:
+            sp["used"].add(row)
+            self._hist["rows"].append(row)
+            i = sp["rows"].index(row)
+            return sp["logits"][i:i + 1]
+        hist = self._hist
+        if hist is not None and hist["key"] == key and sp is None and row not in hist["rows"]:
+            hist["rows"].append(row)          # another task of the slide being learnt
+        else:                                 # a new slide (or a break of the pattern): what the last one showed is the prediction
+            if hist is not None:
+                r = hist["rows"]
+                self._spec_rows = list(r) if (len(r) >= 2 and len(set(r)) == len(r)) else None
+            self._hist = {"key": key, "rows": [row]}
+            self._spec = None
+            rows = self._spec_rows
+            if rows and row == rows[0]:
+                eye = torch.eye(self.cfg.multi_task, dtype=F32, device=self.engine.device)[rows]
+                logits = self.forward_tasks(x, coords, genes, eye, clinical=clinical)
+                self._spec = {"key": key, "rows": rows, "used": {row}, "logits": logits}
+                return logits[0:1]
+        return self.forward_tasks(x, coords, genes, onehot, clinical=clinical)
 
     def forward_tasks(self, x, coords, genes, task_onehots, clinical=None):
         """All task passes of one slide in one batched engine call: logits [B, output_dim]."""
         self._sync_weight_caches()
-        if isinstance(genes, dict):
-            genes = [genes[k] for k in sorted(genes.keys())] if all(isinstance(k, int) for k in genes) else list(genes.values())
+        genes = self._gene_list(genes)
         need = torch.is_grad_enabled() and self.training_grad     # (grad mode is off inside Function.forward)
         if not self.CLINICAL:
             clinical = None                      # the base adapter ignores `clinical` like the reference's **kwargs
-        return _ModelFn.apply(self, x, coords, genes, task_onehots.to(self.engine.device, F32), need, clinical,
-                              *self._trainable.values())
+        token = self._open_group(x, coords) if need else None
+        return self._close_call(need, self._apply_bridge(x, coords, genes, task_onehots.to(self.engine.device, F32), need, clinical, token))
+
+    def _apply_bridge(self, x, coords, genes, onehots, need, clinical, token):
+        return _ModelFn.apply(self, x, coords, genes, onehots, need, clinical, token, *self._trainable.values())
 
 
 @Aggregator.register("longnetvit_gene_clinical_adapter")

@@ -160,105 +160,127 @@ __global__ __launch_bounds__(256) void gelu_f16_bwd_kernel(const h16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ attentional pooling core
-// One workgroup per (pass, head, query): scores over the N tokens, softmax, out = P V; probs saved for the backward.
+// A few learned queries attend over the N tokens of every pass (flash-decoding form: the keys are split over workgroups).
 // q fp32 [nq, E] (already projected, frozen); kv fp16 [B*N, 2E] (k | v, projected); hd = E / heads <= 128, hd % 8 == 0.
-__global__ __launch_bounds__(256) void pool_attn_fwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv, int B, int N, int E, int heads,
-                                                            int nq, float scale, float* __restrict__ out, float* __restrict__ probs) {
+// Phase 1: workgroup = (pass, head, query, split): one key per thread; raw scaled scores saved (the backward recomputes
+// p = exp(s - lse)), partial (max, sum, sum p v) per split.  Phase 2: combine the splits -> out, lse.
+constexpr int POOL_KEYS = 256;      // keys per split = threads per workgroup
+__global__ __launch_bounds__(256) void pool_attn_part_kernel(const float* __restrict__ q, const h16* __restrict__ kv, int B, int N, int E, int heads,
+                                                             int nq, int nsplit, float scale, float* __restrict__ scores,
+                                                             float* __restrict__ part) {
   __shared__ float qs[128];
+  __shared__ float ps[POOL_KEYS];
   __shared__ float red[4];
-  __shared__ float part[4][128];
+  __shared__ float accs[4][128];
   const int hd = E / heads;
-  const int iq = blockIdx.x % nq, h = (blockIdx.x / nq) % heads, b = blockIdx.x / (nq * heads);
+  const int sp = blockIdx.x % nsplit, iq = (blockIdx.x / nsplit) % nq, h = (blockIdx.x / (nsplit * nq)) % heads, b = blockIdx.x / (nsplit * nq * heads);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < hd) qs[tid] = q[(long)iq * E + h * hd + tid] * scale;
   __syncthreads();
-  float* prow = probs + (((long)b * heads + h) * nq + iq) * N;
-  float mx = -3.0e38f;
-  for (int n = tid; n < N; n += 256) {
+  const int n = sp * POOL_KEYS + tid;
+  float s = -3.0e38f;
+  if (n < N) {
     const h16* kr = kv + ((long)b * N + n) * 2 * E + h * hd;
-    float s = 0.f;
+    s = 0.f;
     for (int d = 0; d < hd; d += 8) {
       const h16x8 kk = ldg8(kr + d);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s = fmaf(qs[d + e], (float)kk[e], s);
     }
-    prow[n] = s;
-    mx = fmaxf(mx, s);
+    scores[(((long)b * heads + h) * nq + iq) * N + n] = s;
   }
-  mx = wave_max(mx);
+  float mx = wave_max(s);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float p = n < N ? __expf(s - mx) : 0.f;
+  ps[tid] = p;
+  float sum = wave_sum(p);
   __syncthreads();
-  float sum = 0.f;
-  for (int n = tid; n < N; n += 256) { const float p = __expf(prow[n] - mx); prow[n] = p; sum += p; }
-  sum = wave_sum(sum);
   if (lane == 0) red[wave] = sum;
   __syncthreads();
-  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
-  for (int n = tid; n < N; n += 256) prow[n] *= inv;
-  __syncthreads();      // (a thread reads other threads' probabilities below: the barrier orders the workgroup's global stores)
-  // out[d] = sum_n p[n] v[n][d]: thread -> (d = tid % 128, key slice tid / 128)
-  const int d = tid & 127, sl = tid >> 7;
-  float acc = 0.f;
-  if (d < hd)
-    for (int n = sl; n < N; n += 2) acc = fmaf(prow[n], (float)kv[((long)b * N + n) * 2 * E + E + h * hd + d], acc);
-  part[sl][d] = acc;
+  sum = red[0] + red[1] + red[2] + red[3];
+  // sum_n p[n] v[n][d]: thread -> (d = tid % 64 (+ 64), key group tid / 64); consecutive threads read consecutive halves of a row
+  const int g = tid >> 6;
+  float a0 = 0.f, a1 = 0.f;
+  const int nk = min(POOL_KEYS, N - sp * POOL_KEYS);
+  for (int j = g; j < nk; j += 4) {
+    const h16* vr = kv + ((long)b * N + sp * POOL_KEYS + j) * 2 * E + E + h * hd;
+    const float pj = ps[j];
+    if (lane < hd) a0 = fmaf(pj, (float)vr[lane], a0);
+    if (lane + 64 < hd) a1 = fmaf(pj, (float)vr[lane + 64], a1);
+  }
+  accs[g][lane] = a0; accs[g][lane + 64] = a1;
   __syncthreads();
-  if (tid < hd) out[((long)b * nq + iq) * E + h * hd + tid] = part[0][tid] + part[1][tid];
+  float* pp = part + (long)blockIdx.x * (2 + 128);
+  if (tid < hd) pp[2 + tid] = accs[0][tid] + accs[1][tid] + accs[2][tid] + accs[3][tid];
+  if (tid == 0) { pp[0] = mx; pp[1] = sum; }
+}
+__global__ __launch_bounds__(128) void pool_attn_combine_kernel(const float* __restrict__ part, int E, int heads, int nq, int nsplit,
+                                                                float* __restrict__ out, float* __restrict__ lse) {
+  const int hd = E / heads;
+  const int iq = blockIdx.x % nq, h = (blockIdx.x / nq) % heads, b = blockIdx.x / (nq * heads);
+  const float* pp = part + (long)blockIdx.x * nsplit * (2 + 128);
+  float mx = -3.0e38f;
+  for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, pp[s * 130]);
+  float l = 0.f, acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = __expf(pp[s * 130] - mx);
+    l = fmaf(w, pp[s * 130 + 1], l);
+    if (threadIdx.x < hd) acc = fmaf(w, pp[s * 130 + 2 + threadIdx.x], acc);
+  }
+  if (threadIdx.x < hd) out[((long)b * nq + iq) * E + h * hd + threadIdx.x] = acc / l;
+  if (threadIdx.x == 0) lse[((long)b * heads + h) * nq + iq] = mx + __logf(l);
 }
 
-// dkv (fp16 [B*N, 2E], OVERWRITTEN for the nq = 1 case, accumulated over queries otherwise by the caller looping iq):
-// dV[n] = p[n] dout ; dP[n] = dout . v[n] ; dS[n] = p[n] (dP[n] - sum_m p[m] dP[m]) ; dK[n] = scale dS[n] q
-__global__ __launch_bounds__(256) void pool_attn_bwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv, const float* __restrict__ probs,
-                                                            const float* __restrict__ dout, int B, int N, int E, int heads, int nq, float scale,
-                                                            h16* __restrict__ dkv) {
+// dkv (fp16 [B*N, 2E], overwritten): p = exp(s - lse) ; dV[n] = sum_q p dout_q ; dP = dout . v[n] ; dS = p (dP - dout . out) ;
+// dK[n] = scale sum_q dS q.  One key per thread (the flash identity sum_m p[m] dP[m] = dout . out needs no second pass).
+__global__ __launch_bounds__(256) void pool_attn_bwd_kernel(const float* __restrict__ q, const h16* __restrict__ kv, const float* __restrict__ scores,
+                                                            const float* __restrict__ lse, const float* __restrict__ out,
+                                                            const float* __restrict__ dout, int B, int N, int E, int heads, int nq, int nsplit,
+                                                            float scale, h16* __restrict__ dkv) {
   __shared__ float qs[128], dos[128];
-  __shared__ float red[4];
+  __shared__ float tots;
   const int hd = E / heads;
-  const int h = blockIdx.x % heads, b = blockIdx.x / heads;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sp = blockIdx.x % nsplit, h = (blockIdx.x / nsplit) % heads, b = blockIdx.x / (nsplit * heads);
+  const int tid = threadIdx.x;
+  const int n = sp * POOL_KEYS + tid;
   for (int iq = 0; iq < nq; ++iq) {
     __syncthreads();
-    if (tid < hd) { qs[tid] = q[(long)iq * E + h * hd + tid] * scale; dos[tid] = dout[((long)b * nq + iq) * E + h * hd + tid]; }
-    __syncthreads();
-    const float* prow = probs + (((long)b * heads + h) * nq + iq) * N;
-    float dot = 0.f;
-    for (int n = tid; n < N; n += 256) {
-      const h16* vr = kv + ((long)b * N + n) * 2 * E + E + h * hd;
-      float dp = 0.f;
-      for (int d = 0; d < hd; d += 8) {
-        const h16x8 vv = ldg8(vr + d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dp = fmaf(dos[d + e], (float)vv[e], dp);
-      }
-      dot = fmaf(prow[n], dp, dot);
+    if (tid < hd) {
+      qs[tid] = q[(long)iq * E + h * hd + tid] * scale;
+      dos[tid] = dout[((long)b * nq + iq) * E + h * hd + tid];
     }
-    dot = wave_sum(dot);
-    if (lane == 0) red[wave] = dot;
     __syncthreads();
-    const float tot = red[0] + red[1] + red[2] + red[3];
-    for (int n = tid; n < N; n += 256) {
+    if (tid == 0) {
+      float t = 0.f;
+      for (int d = 0; d < hd; ++d) t = fmaf(dos[d], out[((long)b * nq + iq) * E + h * hd + d], t);
+      tots = t;
+    }
+    __syncthreads();
+    if (n < N) {
       const h16* vr = kv + ((long)b * N + n) * 2 * E + E + h * hd;
-      h16* dk = dkv + ((long)b * N + n) * 2 * E + h * hd;
-      h16* dv = dk + E;
       float dp = 0.f;
       for (int d = 0; d < hd; d += 8) {
         const h16x8 vv = ldg8(vr + d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dp = fmaf(dos[d + e], (float)vv[e], dp);
       }
-      const float p = prow[n], ds = p * (dp - tot);
-      for (int d = 0; d < hd; d += 8) {
-        h16x8 ok, ov;
-        if (iq > 0) { ok = ldg8(dk + d); ov = ldg8(dv + d); }
+      const long row = ((long)b * heads + h) * nq + iq;
+      const float p = __expf(scores[row * N + n] - lse[row]);
+      const float ds = p * (dp - tots);
+      h16* okp = dkv + ((long)b * N + n) * 2 * E + h * hd;
+      h16* ovp = okp + E;
+      for (int d = 0; d < hd; d += 8) {      // (further queries accumulate onto what the earlier ones wrote: same thread, same key)
+        h16x8 a, c;
+        if (iq > 0) { a = ldg8(okp + d); c = ldg8(ovp + d); }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float a = ds * qs[d + e], c = p * dos[d + e];
-          ok[e] = (h16)(iq > 0 ? (float)ok[e] + a : a);
-          ov[e] = (h16)(iq > 0 ? (float)ov[e] + c : c);
+          const float x = ds * qs[d + e], y = p * dos[d + e];
+          a[e] = (h16)(iq > 0 ? (float)a[e] + x : x);
+          c[e] = (h16)(iq > 0 ? (float)c[e] + y : y);
         }
-        stg8(dk + d, ok); stg8(dv + d, ov);
+        stg8(okp + d, a); stg8(ovp + d, c);
       }
     }
   }
@@ -318,24 +340,32 @@ extern "C" int mt_gelu_f16_bwd(const mt_half* x, const mt_half* dy, mt_half* dx,
   return MT_OK;
 }
 
-extern "C" int mt_pool_attn_fwd(const float* q, const mt_half* kv, int B, int N, int E, int heads, int nq, float* out, float* probs,
-                                mt_stream_t stream) {
-  if (!q || !kv || !out || !probs || B < 1 || N < 1 || heads < 1 || nq < 1 || E % heads) return MT_ERR_BAD_ARG;
+extern "C" long mt_pool_attn_workspace_floats(int B, int N, int heads, int nq) {
+  return (long)B * heads * nq * cdiv(N, POOL_KEYS) * (2 + 128);
+}
+
+extern "C" int mt_pool_attn_fwd(const float* q, const mt_half* kv, int B, int N, int E, int heads, int nq, float* out, float* scores,
+                                float* lse, float* workspace, mt_stream_t stream) {
+  if (!q || !kv || !out || !scores || !lse || !workspace || B < 1 || N < 1 || heads < 1 || nq < 1 || E % heads) return MT_ERR_BAD_ARG;
   const int hd = E / heads;
   if (hd > 128 || (hd & 7)) return MT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pool_attn_fwd_kernel, dim3(B * heads * nq), dim3(256), 0, (hipStream_t)stream, q, (const h16*)kv, B, N, E, heads, nq,
-                     1.0f / sqrtf((float)hd), out, probs);
+  const int nsplit = cdiv(N, POOL_KEYS);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(pool_attn_part_kernel, dim3(B * heads * nq * nsplit), dim3(256), 0, s, q, (const h16*)kv, B, N, E, heads, nq, nsplit,
+                     1.0f / sqrtf((float)hd), scores, workspace);
+  hipLaunchKernelGGL(pool_attn_combine_kernel, dim3(B * heads * nq), dim3(128), 0, s, (const float*)workspace, E, heads, nq, nsplit, out, lse);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
 
-extern "C" int mt_pool_attn_bwd(const float* q, const mt_half* kv, const float* probs, const float* dout, int B, int N, int E, int heads,
-                                int nq, mt_half* dkv, mt_stream_t stream) {
-  if (!q || !kv || !probs || !dout || !dkv || B < 1 || N < 1 || heads < 1 || nq < 1 || E % heads) return MT_ERR_BAD_ARG;
+extern "C" int mt_pool_attn_bwd(const float* q, const mt_half* kv, const float* scores, const float* lse, const float* out,
+                                const float* dout, int B, int N, int E, int heads, int nq, mt_half* dkv, mt_stream_t stream) {
+  if (!q || !kv || !scores || !lse || !out || !dout || !dkv || B < 1 || N < 1 || heads < 1 || nq < 1 || E % heads) return MT_ERR_BAD_ARG;
   const int hd = E / heads;
   if (hd > 128 || (hd & 7)) return MT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pool_attn_bwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, q, (const h16*)kv, probs, dout, B, N, E,
-                     heads, nq, 1.0f / sqrtf((float)hd), (h16*)dkv);
+  const int nsplit = cdiv(N, POOL_KEYS);
+  hipLaunchKernelGGL(pool_attn_bwd_kernel, dim3(B * heads * nsplit), dim3(256), 0, (hipStream_t)stream, q, (const h16*)kv, scores, lse, out,
+                     dout, B, N, E, heads, nq, nsplit, 1.0f / sqrtf((float)hd), (h16*)dkv);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -317,12 +317,15 @@ class Engine:
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, coords, genes: Sequence[torch.Tensor], task_onehots: torch.Tensor,
                 need_grad: bool = True, fresh: bool = False, staged: bool = False, geometry=None,
-                clinical: Optional[torch.Tensor] = None) -> torch.Tensor:
+                clinical: Optional[torch.Tensor] = None, share: Optional[dict] = None) -> torch.Tensor:
         """x [L, in_chans] (or [1,L,in]); coords [L,2] (host or device); genes: list of [1, n_i]; task_onehots [B, num_tasks].
         Returns logits [B, output_dim] (fp32, device).  fresh=True gives this call its own tape and workspace so that
         several forwards can precede one backward (the reference calls the model 3x before loss.backward(), TM:175-177);
         `self.last_call` is the handle `backward(..., call=)` takes.  staged=True: x / coords were already uploaded with
-        stage_inputs() into this geometry's workspace (hipGraph replay path: no host work inside the step)."""
+        stage_inputs() into this geometry's workspace (hipGraph replay path: no host work inside the step).
+        share (fresh calls of the module API): a dict owned by the caller for the calls of ONE slide -- the first call leaves the
+        task-independent patch embedding in it (`x0`: input cast + patch-embed GEMM + positional term, LVA:232-242), the later
+        ones take it from there instead of recomputing it (the reference recomputes it for every task id)."""
         cfg, dev, t = self.cfg, self.device, self.store.tensors
         if not self._caches_ready:
             self._build_caches()
@@ -353,7 +356,12 @@ class Engine:
         self._ctx["patch_map"] = patch_map
 
         # ---- patch embedding + positional table + cls (LVA:232-242); shared by the B passes
-        self._embed_patches(x, coords, ws, staged, L)
+        if share is not None and "x0" in share and tuple(share["x0"].shape) == (L, D):
+            ws["x0"] = share["x0"]            # read-only from here on (block 0's input carries no gradient)
+        else:
+            self._embed_patches(x, coords, ws, staged, L)
+            if share is not None:
+                share["x0"] = ws["x0"]
 
         # ---- token side: gene encoder (one pass when dropout is off, own masks per task pass otherwise) + task token per pass
         # (LVA:257-266)

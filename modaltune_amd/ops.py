@@ -242,12 +242,16 @@ def gelu_f16_bwd(x, dy, dx, n=None):
     check(_lib.load().mt_gelu_f16_bwd(_p(x), _p(dy), _p(dx), n if n is not None else x.numel(), _s()), "gelu_f16_bwd")
 
 
-def pool_attn_fwd(q, kv, out, probs, B, N, E, heads, nq):
-    check(_lib.load().mt_pool_attn_fwd(_p(q), _p(kv), B, N, E, heads, nq, _p(out), _p(probs), _s()), "pool_attn_fwd")
+def pool_attn_workspace_floats(B, N, heads, nq) -> int:
+    return int(_lib.load().mt_pool_attn_workspace_floats(B, N, heads, nq))
 
 
-def pool_attn_bwd(q, kv, probs, dout, dkv, B, N, E, heads, nq):
-    check(_lib.load().mt_pool_attn_bwd(_p(q), _p(kv), _p(probs), _p(dout), B, N, E, heads, nq, _p(dkv), _s()), "pool_attn_bwd")
+def pool_attn_fwd(q, kv, out, scores, lse, workspace, B, N, E, heads, nq):
+    check(_lib.load().mt_pool_attn_fwd(_p(q), _p(kv), B, N, E, heads, nq, _p(out), _p(scores), _p(lse), _p(workspace), _s()), "pool_attn_fwd")
+
+
+def pool_attn_bwd(q, kv, scores, lse, out, dout, dkv, B, N, E, heads, nq):
+    check(_lib.load().mt_pool_attn_bwd(_p(q), _p(kv), _p(scores), _p(lse), _p(out), _p(dout), B, N, E, heads, nq, _p(dkv), _s()), "pool_attn_bwd")
 
 
 def titan_grid(coords, L, patch, cells, dims, err=None):

@@ -36,7 +36,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import rowmap
-from .aggregators import Aggregator, LongNetGeneAdapter, _ModelFn
+from .aggregators import Aggregator, LongNetGeneAdapter, _bridge_backward
 from .config import ModelConfig
 from .engine import Engine, F32, H16, _W16
 from .tape import Param, Var
@@ -395,7 +395,9 @@ class NativeBackbone:
         sp["dqkv16"] = (H16, (M, 3 * D)); sp["delta"] = (F32, (M, H))
         if self.pool_w:
             E = self.pool_w["E"]
-            sp["pool_kv"] = (H16, (M, 2 * E)); sp["pool_dkv"] = (H16, (M, 2 * E)); sp["pool_probs"] = (F32, (B * self.pool_w["heads"] * (Lx + 1),))
+            hp = self.pool_w["heads"]
+            sp["pool_kv"] = (H16, (M, 2 * E)); sp["pool_dkv"] = (H16, (M, 2 * E)); sp["pool_probs"] = (F32, (B * hp * (Lx + 1),))
+            sp["pool_lse"] = (F32, (B * hp,)); sp["pool_part"] = (F32, (ops.pool_attn_workspace_floats(B, Lx + 1, hp, 1),))
             for j in range(len(self.pool_w["pre"])):
                 sp[f"pool_st{j}"] = (F32, (M, 2))
                 if j > 0:
@@ -476,7 +478,7 @@ class NativeBackbone:
             cur = dst
         ops.gemm_nt(ws["u16"], p["kv"].w, ws["pool_kv"], M, 2 * E, D, bias=p["kv"].b)
         pooled = Var(tape.new(B, 1, E))
-        ops.pool_attn_fwd(p["q"], ws["pool_kv"], pooled.data, ws["pool_probs"], B, N, E, heads, 1)
+        ops.pool_attn_fwd(p["q"], ws["pool_kv"], pooled.data, ws["pool_probs"], ws["pool_lse"], ws["pool_part"], B, N, E, heads, 1)
         y = tape.linear(pooled, Param(p["wo"], None), Param(p["bo"], None))
         # the pooled row's LayerNorm may carry its own eps: launched here (frozen affine), not through tape.layernorm
         img = Var(tape.new(B, D))
@@ -496,7 +498,7 @@ class NativeBackbone:
         if pooled.grad is None:
             dh.zero_()
             return
-        ops.pool_attn_bwd(p["q"], ws["pool_kv"], ws["pool_probs"], pooled.grad, ws["pool_dkv"], B, N, E, heads, 1)
+        ops.pool_attn_bwd(p["q"], ws["pool_kv"], ws["pool_probs"], ws["pool_lse"], pooled.data, pooled.grad, ws["pool_dkv"], B, N, E, heads, 1)
         ops.gemm_nt(ws["pool_dkv"], p["kv"].wt, ws["dy16"], M, D, 2 * E)
         dcur = ws["dy16"]
         for j in range(len(p["pre"]) - 1, -1, -1):
@@ -643,8 +645,10 @@ class TitanEngine(Engine):
         super().check_inputs()
 
     def forward_slide(self, x, coords, genes, task_onehots, patch_size_lv0: int = 1024, need_grad: bool = True, fresh: bool = False,
-                      clinical=None) -> torch.Tensor:
-        """x [1, L, C] tile embeddings, coords [1, L, 2] level-0 pixels (TA:329-353) -> logits [B, output_dim]."""
+                      clinical=None, share: Optional[dict] = None) -> torch.Tensor:
+        """x [1, L, C] tile embeddings, coords [1, L, 2] level-0 pixels (TA:329-353) -> logits [B, output_dim].
+        share: see Engine.forward -- here the whole task-independent prologue (gridding, embedding, ALiBi tables) is reused by
+        the later calls of one slide."""
         bb = self.backbone
         if bb is None:
             raise RuntimeError("titan_gene_adapter needs the TITAN slide encoder: pass backbone=<VisionTransformer from the "
@@ -652,7 +656,10 @@ class TitanEngine(Engine):
         B = int(task_onehots.shape[0])
         self._need = need_grad
         x = x.to(self.device)
-        if self.native:
+        if share is not None and share.get("titan_B") == B:
+            self._tok, self._plan, self._plan_keep = share["tok"], share["plan"], share["keep"]
+            self._bias, self._mask = share.get("bias"), share.get("mask")
+        elif self.native:
             if bb.embed_w is not None:
                 x16, cells, dims, Lv = device_tokens(x, coords, patch_size_lv0, self._titan_err)
                 tok = bb.embed(x16, Lv)
@@ -669,10 +676,14 @@ class TitanEngine(Engine):
             fg, cg, bgm = preprocess_features(x, coords, patch_size_lv0)
             tok, bias, mask = bb.embed(fg, cg, bgm)
             self._tok, self._bias, self._mask = tok[0].to(F32).contiguous(), bias, mask
+            self._plan = self._plan_keep = None
+        if share is not None and share.get("titan_B") != B:
+            share.update(titan_B=B, tok=self._tok, plan=self._plan, keep=self._plan_keep, bias=getattr(self, "_bias", None),
+                         mask=getattr(self, "_mask", None))
         patches = self._tok[1:]
         if patches.shape[0] < 1:
             raise ValueError("slide has no foreground cell")
-        return self.forward(patches, None, genes, task_onehots, need_grad=need_grad, fresh=fresh, clinical=clinical)
+        return self.forward(patches, None, genes, task_onehots, need_grad=need_grad, fresh=fresh, clinical=clinical, share=share)
 
     # -- image-side hooks
     def _embed_patches(self, x, coords, ws, staged, L):
@@ -801,6 +812,10 @@ class TITANGeneAdapter(LongNetGeneAdapter):
         self._slots = [self.engine.store.slots[k] for k in self._trainable]
         self._versions = None
         self.training_grad = True
+        self._group = None
+        self._spec = self._hist = self._spec_rows = None
+        self.speculate = True
+        self._call_psz = 1024
         self.train(True)
 
     def _rebuild_backbone(self):
@@ -851,39 +866,43 @@ class TITANGeneAdapter(LongNetGeneAdapter):
         return torch.nn.modules.module._IncompatibleKeys([], [])
 
     def forward(self, x, coords, genes, task_token=None, patch_size_lv0=1024, clinical=None, **kwargs):
+        self._call_psz = int(patch_size_lv0)
         if self.is_multi:
             if task_token is None:
                 raise ValueError("task_token is required when multi_task > 1")
-            onehots = task_token.reshape(1, -1)
-        else:
-            onehots = torch.zeros(1, 1, device=self.engine.device)
-        return self.forward_tasks(x, coords, genes, onehots, clinical=clinical, patch_size_lv0=patch_size_lv0)
+            return self._forward_one_task(x, coords, genes, task_token.reshape(1, -1), clinical)
+        onehots = torch.zeros(1, 1, device=self.engine.device)
+        return self.forward_tasks(x, coords, genes, onehots, clinical=clinical)
 
-    def forward_tasks(self, x, coords, genes, task_onehots, clinical=None, patch_size_lv0=1024):
-        self._sync_weight_caches()
-        if isinstance(genes, dict):
-            genes = [genes[k] for k in sorted(genes.keys())] if all(isinstance(k, int) for k in genes) else list(genes.values())
-        need = torch.is_grad_enabled() and self.training_grad
-        if not self.CLINICAL:
-            clinical = None
-        return _TitanFn.apply(self, x, coords, genes, task_onehots.to(self.engine.device, F32), need, clinical, int(patch_size_lv0),
-                              *self._trainable.values())
+    def forward_tasks(self, x, coords, genes, task_onehots, clinical=None, patch_size_lv0=None):
+        if patch_size_lv0 is not None:
+            self._call_psz = int(patch_size_lv0)
+        return super().forward_tasks(x, coords, genes, task_onehots, clinical=clinical)
+
+    def _extra_key(self):
+        return self._call_psz
+
+    def _apply_bridge(self, x, coords, genes, onehots, need, clinical, token):
+        return _TitanFn.apply(self, x, coords, genes, onehots, need, clinical, self._call_psz, token, *self._trainable.values())
 
 
 class _TitanFn(torch.autograd.Function):
-    """Same bridge as aggregators._ModelFn with the TITAN entry point."""
+    """Same bridge as aggregators._ModelFn (chained calls of a step: aggregators._StepGroup) with the TITAN entry point."""
 
     @staticmethod
-    def forward(ctx, module, x, coords, genes, onehots, need, clinical, psz, *params):
+    def forward(ctx, module, x, coords, genes, onehots, need, clinical, psz, token, *params):
         eng = module.engine
-        logits = eng.forward_slide(x, coords, genes, onehots, patch_size_lv0=psz, need_grad=need, fresh=need, clinical=clinical)
-        ctx.module, ctx.call = module, (eng.last_call if need else None)
-        return logits.clone()
+        ctx.set_materialize_grads(False)
+        grp = module._group if need else None
+        logits = eng.forward_slide(x, coords, genes, onehots, patch_size_lv0=psz, need_grad=need, fresh=need, clinical=clinical,
+                                   share=grp.share if grp is not None else None)
+        ctx.module, ctx.call, ctx.group, ctx.has_pred = module, (eng.last_call if need else None), grp, token is not None
+        return logits.clone(), torch.zeros((), dtype=F32, device=logits.device)
 
     @staticmethod
-    def backward(ctx, dlogits):
-        grads = _ModelFn.backward(ctx, dlogits)
-        return (None,) * 8 + grads[7:]
+    def backward(ctx, dlogits, dtoken):
+        tok, grads = _bridge_backward(ctx, dlogits)
+        return (None,) * 8 + (tok,) + grads
 
 
 @Aggregator.register("titan_gene_clinical_adapter")

@@ -198,6 +198,100 @@ def test_nn_module_dropin_api_matches_reference_golden(golden_dir):
     assert torch.isfinite(l2).all() and float((l2 - logits[:1].detach()).abs().max()) > 0
 
 
+def test_module_bridge_chains_the_calls_of_a_step(golden_dir):
+    """aggregators._StepGroup: the grad-mode calls of one slide share one backward hand-over.  Whatever subset of the outputs
+    the loss uses, and whatever was abandoned before, param.grad equals the gradient of exactly what was backpropagated."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    g = np.load(os.path.join(golden_dir, "model_L37_d3.npz"))
+    L, seed, ngrids = int(g["L"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, depth=3, slide_ngrids=ngrids,
+                              interaction_indexes=[[0, 0], [1, 1], [2, 2]], dropout=0.0, drop_path_rate=0.0, multi_task=3)
+    sd = synth.synth_state_dict(model.cfg, sizes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    x, coords = torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda()
+    genes = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    w = torch.randn(3, 256, generator=torch.Generator().manual_seed(1)).cuda()
+    eye = torch.eye(3).cuda()
+    model.train()
+    model.speculate = False                   # this test is about the chain; the batched prediction has its own below
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    params = dict(model.named_parameters())
+
+    def grads():
+        torch.cuda.synchronize()
+        out = torch.cat([(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).reshape(-1).double() for k in names])
+        for k in names:
+            params[k].grad = None
+        return out
+
+    def call(t):
+        return model(x=x, coords=coords, genes=genes, clinical=[], task_token=eye[t])
+
+    single = []
+    for t in (0, 1, 2):                       # one call, one backward: three groups of one
+        (call(t) * w[t]).sum().backward()
+        single.append(grads())
+    ys = [call(t) for t in (0, 1, 2)]         # the trainer's pattern: one group, one hand-over
+    assert model._group is not None and model._group.count == 3 and "x0" in model._group.share      # patch embedding computed once
+    sum((y * w[t]).sum() for t, y in enumerate(ys)).backward()
+    assert model._group is None
+    tot = grads()
+    ref = single[0] + single[1] + single[2]
+    assert float((tot - ref).norm() / ref.norm()) < 2e-2
+    ys = [call(t) for t in (0, 1, 2)]         # only the middle output reaches the loss
+    (ys[1] * w[1]).sum().backward()
+    assert float((grads() - single[1]).norm() / single[1].norm()) < 2e-2
+    _ = [call(t) for t in (0, 1, 2)]          # a whole step abandoned (never backpropagated) ...
+    ys = [call(t) for t in (0, 1, 2)]         # ... does not leak into the next one
+    (ys[2] * w[2]).sum().backward()
+    assert float((grads() - single[2]).norm() / single[2].norm()) < 2e-2
+    with pytest.raises(RuntimeError, match="second backward"):
+        (ys[2] * w[2]).sum().backward()
+
+    # -- speculative batching (aggregators._forward_one_task): after one slide served with task ids 0, 1, 2 the next first call
+    # runs ONE B = 3 engine pass and the later calls get their rows of it; gradients are those of the per-call path
+    model.speculate = True
+    calls = {"n": 0}
+    real = model._apply_bridge
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    model._apply_bridge = counting
+    ys = [call(t) for t in (0, 1, 2)]         # learning pass: three engine calls
+    assert calls["n"] == 3 and model._spec is None
+    sum((y * w[t]).sum() for t, y in enumerate(ys)).backward()
+    assert float((grads() - ref).norm() / ref.norm()) < 2e-2
+    x2 = x.clone()                            # "the next slide"
+    calls["n"] = 0
+    ys2 = [model(x=x2, coords=coords, genes=genes, clinical=[], task_token=eye[t]) for t in (0, 1, 2)]
+    assert calls["n"] == 1 and model._spec is not None and model._spec["used"] == {0, 1, 2}
+    for a, b in zip(ys, ys2):
+        assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())      # batched passes == one-by-one (dropout off)
+    sum((y * w[t]).sum() for t, y in enumerate(ys2)).backward()
+    assert float((grads() - ref).norm() / ref.norm()) < 2e-2
+    x3 = x.clone()                            # a slide that breaks the pattern: task 1 first -> runs on its own, pattern relearnt
+    calls["n"] = 0
+    y1 = model(x=x3, coords=coords, genes=genes, clinical=[], task_token=eye[1])
+    assert calls["n"] == 1 and model._spec is None
+    (y1 * w[1]).sum().backward()
+    assert float((grads() - single[1]).norm() / single[1].norm()) < 2e-2
+    with torch.no_grad():                     # eval loops (TM:252-327) go through the same prediction
+        model.eval()
+        x4, x5 = x.clone(), x.clone()
+        e1 = [model(x=x4, coords=coords, genes=genes, task_token=eye[t]) for t in (0, 1, 2)]
+        calls["n"] = 0
+        e2 = [model(x=x5, coords=coords, genes=genes, task_token=eye[t]) for t in (0, 1, 2)]
+        assert calls["n"] == 1
+        for a, b in zip(e1, e2):
+            assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
+
+
 def test_graph_replay_matches_eager(golden_dir):
     """hipGraph replay of the whole train step reproduces the eager step (same kernels, same order; the fp32-atomic
     weight-gradient reductions make two runs agree to rounding, not bitwise, and AdamW's normalised update amplifies

@@ -132,10 +132,12 @@ def test_pool_attention_core(N, B, heads):
     kv = (0.7 * torch.randn(B * N, 2 * E, generator=g)).half()
     dout = torch.randn(B, 1, E, generator=g)
     out = torch.empty(B, 1, E, dtype=F32, device="cuda")
-    probs = torch.empty(B * heads * N, dtype=F32, device="cuda")
+    scores = torch.empty(B * heads * N, dtype=F32, device="cuda")
+    lse = torch.empty(B * heads, dtype=F32, device="cuda")
+    part = torch.empty(ops.pool_attn_workspace_floats(B, N, heads, 1), dtype=F32, device="cuda")
     dkv = torch.empty(B * N, 2 * E, dtype=H16, device="cuda")
-    ops.pool_attn_fwd(q.cuda(), kv.cuda(), out, probs, B, N, E, heads, 1)
-    ops.pool_attn_bwd(q.cuda(), kv.cuda(), probs, dout.cuda(), dkv, B, N, E, heads, 1)
+    ops.pool_attn_fwd(q.cuda(), kv.cuda(), out, scores, lse, part, B, N, E, heads, 1)
+    ops.pool_attn_bwd(q.cuda(), kv.cuda(), scores, lse, out, dout.cuda(), dkv, B, N, E, heads, 1)
     kvr = kv.double().requires_grad_(True)
     k, v = kvr[:, :E].view(B, N, heads, hd), kvr[:, E:].view(B, N, heads, hd)
     s = torch.einsum("hd,bnhd->bhn", q.double().view(heads, hd), k) / math.sqrt(hd)
