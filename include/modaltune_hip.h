@@ -264,6 +264,53 @@ int mt_pool_attn_fwd(const float* q, const mt_half* kv, int B, int N, int E, int
 int mt_pool_attn_bwd(const float* q, const mt_half* kv, const float* scores, const float* lse, const float* out,
                      const float* dout, int B, int N, int E, int heads, int nq, mt_half* dkv, mt_stream_t stream);
 
+/* ------------------------------------------------- composite launchers: one backbone layer per call ---- */
+/* The launch list of ONE frozen backbone layer behind one entry point per direction (mt_lnqkv_fwd, mt_dilated_attn_*,
+ * mt_mix_ln_outproj_*, mt_ffn_* as one sequence).  Exactly the launches listed above, in order, with the same arguments -- results
+ * are bit-identical to issuing them one by one; the host makes 2 calls per layer and step instead of ~20.
+ * LongNet EncoderLayer (ENC:121-175; DA:146-262; FFN:132-143), D = 768, F = ffn width.  Weights: fp32 LayerNorm affines and
+ * biases, fp16 [N, K] weight caches (q rows of w_qkv / b_qkv pre-scaled by MT_QK_SCALE_LOG2) and their transposes for the dX GEMMs.
+ * Buffers: saved per layer (hin, hmid fp32 [M, D]; qkv fp16 head-major; o_br fp16 [nbranch, M, D]; lse_br fp32 [nbranch, M, 16];
+ * lse_tot fp32 [M, 16]; a1 fp16 [M, F]; st1 / stin / st2 / stf fp32 [M, 2]) and transients shared by all layers.
+ * forward: pend_x / pend_branch / pend_drop: the residual stream, fp16 fc2 branch and its dropout of the layer BELOW whose add is
+ * still outstanding (hin is then written here) or NULL; defer != 0: leave this layer's fc2 add to the layer above (br16 holds the
+ * branch, `out` is not written).  backward: dh (fp32 [M, D]) in / out; dh16_valid: the layer above left fp16(dh) in dh16;
+ * feeds_lower: leave fp16(dh) (masked with drop_lower_ffn) for the layer below. */
+typedef struct {
+  const float *ln1_w, *ln1_b, *inner_ln_w, *inner_ln_b, *ln2_w, *ln2_b, *ffn_ln_w, *ffn_ln_b;
+  const float *b_qkv, *b_out, *b_fc1, *b_fc2;
+  const mt_half *w_qkv, *w_out, *w_fc1, *w_fc2;
+  const mt_half *wt_qkv, *wt_out, *wt_fc1, *wt_fc2;
+} MtLongNetLayerWeights;
+typedef struct {
+  float *hin, *hmid; mt_half *qkv, *o_br; float *lse_br, *lse_tot; mt_half* a1; float *st1, *stin, *st2, *stf;
+  mt_half *u16, *br16, *t16;
+  float* dh; mt_half *dy16, *dh16, *dt16, *da1, *dmixed, *dqkv16; float* delta; void* attn_ws;
+} MtLongNetLayerBuffers;
+int mt_longnet_layer_fwd(const MtLongNetLayerWeights* w, const MtLongNetLayerBuffers* b, const MtDilatedPlan* plan, int M, int D, int F,
+                         const float* pend_x, const mt_half* pend_branch, const MtDropout* pend_drop, int defer, float* out,
+                         const MtDropout* drop_attn, const MtDropout* drop_ffn, mt_stream_t stream);
+int mt_longnet_layer_bwd(const MtLongNetLayerWeights* w, const MtLongNetLayerBuffers* b, const MtDilatedPlan* plan, int M, int D, int F,
+                         int dh16_valid, int feeds_lower, const MtDropout* drop_attn, const MtDropout* drop_ffn,
+                         const MtDropout* drop_lower_ffn, mt_stream_t stream);
+/* Dense pre-norm ViT block of the TITAN configuration (TA:359-361: x + proj(attn(LN(x))), then + fc2(gelu(fc1(LN(.)))); layer scale
+ * folded into w_proj / w_fc2 by the caller): qkv fp16 TOKEN-major [M, 3D], o16 fp16 [M, D], lse fp32 [M, H], a1 fp16 [M, F]. */
+typedef struct {
+  const float *n1_w, *n1_b, *n2_w, *n2_b; float n1_eps, n2_eps;
+  const float *b_qkv, *b_proj, *b_fc1, *b_fc2;
+  const mt_half *w_qkv, *w_proj, *w_fc1, *w_fc2;
+  const mt_half *wt_qkv, *wt_proj, *wt_fc1, *wt_fc2;
+} MtVitBlockWeights;
+typedef struct {
+  float *hin, *hmid; mt_half *qkv, *o16; float* lse; mt_half* a1; float *st1, *st2;
+  mt_half *u16, *br16, *t16;
+  float* dh; mt_half *dy16, *dh16, *dt16, *da1, *dqkv16; float* delta;
+} MtVitBlockBuffers;
+int mt_vit_block_fwd(const MtVitBlockWeights* w, const MtVitBlockBuffers* b, const MtDensePlan* plan, int M, int D, int F,
+                     const float* pend_x, const mt_half* pend_branch, int defer, float* out, mt_stream_t stream);
+int mt_vit_block_bwd(const MtVitBlockWeights* w, const MtVitBlockBuffers* b, const MtDensePlan* plan, int M, int D, int F,
+                     int dh16_valid, int feeds_lower, mt_stream_t stream);
+
 /* ------------------------------------------------------------ adapter ops -------------------------- */
 /* Injector attention core (AM:225-229 inside AM:359-369): for each of M patch rows and 12 heads (dim 16):
  * a = softmax(q k^T / 4) v over the T modal tokens of the row's pass.  q fp16 [M,192]; k,v fp32 [B,T,192];
@@ -362,6 +409,10 @@ int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr
 int mt_scaler_update(float* scale, int* growth_tracker, int* found_inf, int* step_dev /* ++ on a clean step, or NULL */,
                      float growth, float backoff, int interval, mt_stream_t stream);
 int mt_check_finite(const float* g, long n, int* found_inf, mt_stream_t stream);
+
+/* Measurement aid (bench.py, SURVEY §8d "the builder's own MFMA micro-benchmark peak"): `workgroups` x 4 waves each issue
+ * iters x 4 independent v_mfma_f32_32x32x16_f16 on non-trivial register operands = workgroups * 4 * iters * 4 * 32768 FLOP. */
+int mt_mfma_probe(float* sink, int workgroups, int iters, mt_stream_t stream);
 
 /* ---------------------------------------------------------- module bridge / input boundary --------- */
 /* s[0] = target / max|x|, s[1] = 1 / s[0] (both 1 when the maximum is 0 or not finite): device-side rescale of the

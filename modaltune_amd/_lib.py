@@ -52,6 +52,26 @@ class MtDensePlan(C.Structure):
     _fields_ = [("N", I), ("B", I), ("H", I), ("posk", P), ("posq", P), ("nslope", P)]
 
 
+class MtLongNetLayerWeights(C.Structure):
+    _fields_ = [(n, P) for n in ("ln1_w", "ln1_b", "inner_ln_w", "inner_ln_b", "ln2_w", "ln2_b", "ffn_ln_w", "ffn_ln_b", "b_qkv", "b_out",
+                                 "b_fc1", "b_fc2", "w_qkv", "w_out", "w_fc1", "w_fc2", "wt_qkv", "wt_out", "wt_fc1", "wt_fc2")]
+
+
+class MtLongNetLayerBuffers(C.Structure):
+    _fields_ = [(n, P) for n in ("hin", "hmid", "qkv", "o_br", "lse_br", "lse_tot", "a1", "st1", "stin", "st2", "stf", "u16", "br16", "t16",
+                                 "dh", "dy16", "dh16", "dt16", "da1", "dmixed", "dqkv16", "delta", "attn_ws")]
+
+
+class MtVitBlockWeights(C.Structure):
+    _fields_ = [(n, P) for n in ("n1_w", "n1_b", "n2_w", "n2_b")] + [("n1_eps", F), ("n2_eps", F)] + \
+               [(n, P) for n in ("b_qkv", "b_proj", "b_fc1", "b_fc2", "w_qkv", "w_proj", "w_fc1", "w_fc2", "wt_qkv", "wt_proj", "wt_fc1", "wt_fc2")]
+
+
+class MtVitBlockBuffers(C.Structure):
+    _fields_ = [(n, P) for n in ("hin", "hmid", "qkv", "o16", "lse", "a1", "st1", "st2", "u16", "br16", "t16", "dh", "dy16", "dh16", "dt16",
+                                 "da1", "dqkv16", "delta")]
+
+
 RM = C.POINTER(MtRowMap)
 DR = C.POINTER(MtDropout)
 EP = C.POINTER(MtGemmEpilogue)
@@ -106,6 +126,11 @@ SIGNATURES = {
     "mt_absmax_scale": [P, L, F, P, P],
     "mt_axpy_dev": [P, P, P, P, L, P],
     "mt_coords_to_grid": [P, I, F, I, P, P, P, P],
+    "mt_mfma_probe": [P, I, I, P],
+    "mt_longnet_layer_fwd": [P, P, PL, I, I, I, P, P, DR, I, P, DR, DR, P],
+    "mt_longnet_layer_bwd": [P, P, PL, I, I, I, I, I, DR, DR, DR, P],
+    "mt_vit_block_fwd": [P, P, DP, I, I, I, P, P, I, P, P],
+    "mt_vit_block_bwd": [P, P, DP, I, I, I, I, I, P],
     "mt_alibi_pos": [P, I, P, P, P, P, P],
     "mt_dense_attn_fwd": [P, DP, P, P, P],
     "mt_dense_attn_bwd": [P, P, P, P, DP, P, P, I, P],

@@ -174,6 +174,33 @@ __global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict
   }
 }
 
+// Bare MFMA loop (bench.py: the chip's own fp16 MFMA rate next to the vendor peak): every wave issues
+// `iters` x 4 independent v_mfma_f32_32x32x16_f16 on pseudo-random register operands (the clock the chip holds depends on the
+// data: all-zero operands read ~19 % high, MI355X_MICROARCH.md "DVFS give-back"), 4 waves per workgroup = one per SIMD.
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* __restrict__ sink, int iters) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  h16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    unsigned h = (t * 9781u + e * 6271u) * 2654435761u;
+    a[e] = (h16)(((int)(h >> 20) & 1023) * (1.0f / 1024.0f) - 0.5f);
+    b[e] = (h16)(((int)(h >> 8) & 1023) * (1.0f / 1024.0f) - 0.5f);
+  }
+  f32x16 c0, c1, c2, c3;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; c2[i] = 0.f; c3[i] = 0.f; }
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, b, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  if (s == 123.456f) sink[0] = s;      // (keeps the chains alive; practically never taken)
+}
+
 }  // namespace
 
 extern "C" int mt_l2norm_rows(const float* x, float* y, int R, int O, mt_stream_t stream) {
@@ -234,6 +261,13 @@ extern "C" int mt_axpy_dev(const float* a, const float* b, const float* alpha, f
   if (!b || !alpha || !y || n <= 0) return MT_ERR_BAD_ARG;
   const int grid = (int)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
   hipLaunchKernelGGL(axpy_dev_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, alpha, y, n);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+
+extern "C" int mt_mfma_probe(float* sink, int workgroups, int iters, mt_stream_t stream) {
+  if (!sink || workgroups < 1 || iters < 1) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, sink, iters);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

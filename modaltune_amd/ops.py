@@ -12,6 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
+from ._lib import MtLongNetLayerBuffers, MtLongNetLayerWeights, MtVitBlockBuffers, MtVitBlockWeights
 from ._lib import MT_SGEMM_MAX, MtDensePlan, MtDilatedPlan, MtDropout, MtGemmEpilogue, MtRowMap, MtSgemm, check, rowmap
 
 F16, F32 = 0, 1
@@ -272,6 +273,35 @@ def titan_gather_tokens(sums, pos, L, Cc, x16):
     check(_lib.load().mt_titan_gather_tokens(_p(sums), _p(pos), L, Cc, _p(x16), _s()), "titan_gather_tokens")
 
 
+# ---- composite launchers: one frozen backbone layer per call (include/modaltune_hip.h; csrc/layer.hip)
+def struct_of(cls, **tensors):
+    """A ctypes struct of device pointers from tensors (floats pass through); the caller keeps the tensors alive."""
+    st = cls()
+    for k, v in tensors.items():
+        setattr(st, k, v.data_ptr() if torch.is_tensor(v) else v)
+    return st
+
+
+def longnet_layer_fwd(w, b, plan, M, D, Fd, out, pend=None, defer=False, drop_attn=None, drop_ffn=None):
+    px, pb, pd = (pend[0], pend[1], pend[2]) if pend is not None else (None, None, None)
+    check(_lib.load().mt_longnet_layer_fwd(C.byref(w), C.byref(b), C.byref(plan), M, D, Fd, _p(px), _p(pb), _dr(pd), int(defer), _p(out),
+                                           _dr(drop_attn), _dr(drop_ffn), _s()), "longnet_layer_fwd")
+
+
+def longnet_layer_bwd(w, b, plan, M, D, Fd, dh16_valid, feeds_lower, drop_attn=None, drop_ffn=None, drop_lower_ffn=None):
+    check(_lib.load().mt_longnet_layer_bwd(C.byref(w), C.byref(b), C.byref(plan), M, D, Fd, int(dh16_valid), int(feeds_lower), _dr(drop_attn),
+                                           _dr(drop_ffn), _dr(drop_lower_ffn), _s()), "longnet_layer_bwd")
+
+
+def vit_block_fwd(w, b, plan, M, D, Fd, out, pend=None, defer=False):
+    px, pb = (pend[0], pend[1]) if pend is not None else (None, None)
+    check(_lib.load().mt_vit_block_fwd(C.byref(w), C.byref(b), C.byref(plan), M, D, Fd, _p(px), _p(pb), int(defer), _p(out), _s()), "vit_block_fwd")
+
+
+def vit_block_bwd(w, b, plan, M, D, Fd, dh16_valid, feeds_lower):
+    check(_lib.load().mt_vit_block_bwd(C.byref(w), C.byref(b), C.byref(plan), M, D, Fd, int(dh16_valid), int(feeds_lower), _s()), "vit_block_bwd")
+
+
 def gene_snn_fwd(params, offs, sizes, goff, genes, G, latent, a1, a2, z, alpha_drop=None, passes=1):
     check(_lib.load().mt_gene_snn_fwd(_p(params), _p(offs), _p(sizes), _p(goff), _p(genes), G, latent, passes, _p(a1), _p(a2), _p(z),
                                       _dr(alpha_drop), _s()), "gene_snn_fwd")
@@ -405,6 +435,26 @@ def row_absmax(x, out, M, D):
 
 def coords_to_grid(coords, L, tile, ngrids, prow, pcol, err=None):
     check(_lib.load().mt_coords_to_grid(_p(coords), L, float(tile), ngrids, _p(prow), _p(pcol), _p(err), _s()), "coords_to_grid")
+
+
+def mfma_probe(sink, workgroups, iters):
+    check(_lib.load().mt_mfma_probe(_p(sink), workgroups, iters, _s()), "mfma_probe")
+
+
+def measured_mfma_peak_tflops(workgroups: int = 1024, iters: int = 20000, reps: int = 3) -> float:
+    """The chip's own fp16 MFMA rate on a bare register-operand loop (one wave per SIMD slot, 4 workgroups per CU's worth of
+    waves): best of `reps`, TFLOP/s.  ~60 ms of GPU time."""
+    sink = torch.zeros(4, dtype=torch.float32, device="cuda")
+    mfma_probe(sink, workgroups, 200)
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        mfma_probe(sink, workgroups, iters)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, workgroups * 4.0 * iters * 4 * 32768 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
 
 
 def scaler_update(scale, tracker, found_inf, step_dev=None, growth=2.0, backoff=0.5, interval=2000):

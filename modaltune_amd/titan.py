@@ -273,9 +273,14 @@ class NativeBackbone:
             qscale[:D] = ops.DENSE_QK_SCALE_LOG2          # q' = 64^-1/2 log2(e) q, baked before the fp16 rounding
             n1w, n1b, n1e = _ln_params(n1, dev)
             n2w, n2b, n2e = _ln_params(n2, dev)
-            self.blocks.append(dict(qkv=_Lin(qkv.weight, qkv.bias, dev, qscale), proj=_Lin(proj.weight, proj.bias, dev, gam[0]),
-                                    fc1=_Lin(fc1.weight, fc1.bias, dev), fc2=_Lin(fc2.weight, fc2.bias, dev, gam[1]),
-                                    n1w=n1w, n1b=n1b, n1e=n1e, n2w=n2w, n2b=n2b, n2e=n2e))
+            blkw = dict(qkv=_Lin(qkv.weight, qkv.bias, dev, qscale), proj=_Lin(proj.weight, proj.bias, dev, gam[0]),
+                        fc1=_Lin(fc1.weight, fc1.bias, dev), fc2=_Lin(fc2.weight, fc2.bias, dev, gam[1]),
+                        n1w=n1w, n1b=n1b, n1e=n1e, n2w=n2w, n2b=n2b, n2e=n2e)
+            blkw["cw"] = ops.struct_of(      # pointer table of the composite launcher (mt_vit_block_fwd / _bwd)
+                ops.MtVitBlockWeights, n1_w=n1w, n1_b=n1b, n2_w=n2w, n2_b=n2b, n1_eps=n1e, n2_eps=n2e, b_qkv=blkw["qkv"].b, b_proj=blkw["proj"].b,
+                b_fc1=blkw["fc1"].b, b_fc2=blkw["fc2"].b, w_qkv=blkw["qkv"].w, w_proj=blkw["proj"].w, w_fc1=blkw["fc1"].w, w_fc2=blkw["fc2"].w,
+                wt_qkv=blkw["qkv"].wt, wt_proj=blkw["proj"].wt, wt_fc1=blkw["fc1"].wt, wt_fc2=blkw["fc2"].wt)
+            self.blocks.append(blkw)
             self.H, self.F = int(heads), fc1.out_features
         if D != 768:
             raise Unsupported(f"embed dim {D}: the fused residual + LayerNorm kernel is built for 768")
@@ -433,6 +438,9 @@ class NativeBackbone:
         w, D, Fd = self.blocks[l], self.D, self.F
         u16, br16, t16 = ws["u16"], ws["br16"], ws["t16"]
         hmid, qkv, o16, lse, a1 = ws[f"hmid{l}"], ws[f"qkv{l}"], ws[f"o{l}"], ws[f"lse{l}"], ws[f"a1_{l}"]
+        if ops.TIMER is None:      # one C call (csrc/layer.hip enqueues exactly the launches spelled out below)
+            ops.vit_block_fwd(w["cw"], self._cbuf(l, ws, hin), plan, M, D, Fd, out, pend=pend, defer=defer)
+            return (hmid, br16) if defer else None
         if pend is None:
             ops.layernorm_fwd(hin, w["n1w"], w["n1b"], u16, ws[f"st1_{l}"], M, D, eps=w["n1e"])
         else:
@@ -449,10 +457,24 @@ class NativeBackbone:
         ops.gemm_nt(t16, w["fc2"].w, out, M, D, Fd, epilogue=ops.EPI_BIAS_RESID, bias=w["fc2"].b, resid=hmid, ldr=D)
         return None
 
+    def _cbuf(self, l: int, ws, hin: torch.Tensor, dh: Optional[torch.Tensor] = None):
+        """Pointer table of block l's buffers in workspace `ws` (cached in it; `dh` is known from the first backward on)."""
+        cb = ws.get(("_cb", l))
+        if cb is None:
+            cb = ws[("_cb", l)] = ops.struct_of(
+                ops.MtVitBlockBuffers, hin=hin, hmid=ws[f"hmid{l}"], qkv=ws[f"qkv{l}"], o16=ws[f"o{l}"], lse=ws[f"lse{l}"], a1=ws[f"a1_{l}"],
+                st1=ws[f"st1_{l}"], st2=ws[f"st2_{l}"], u16=ws["u16"], br16=ws["br16"], t16=ws["t16"], dy16=ws["dy16"], dh16=ws["dh16"],
+                dt16=ws["dt16"], da1=ws["da1"], dqkv16=ws["dqkv16"], delta=ws["delta"])
+        if dh is not None:
+            cb.dh = dh.data_ptr()
+        return cb
+
     def block_bwd(self, l: int, ws: Dict[str, torch.Tensor], M: int, plan, hin: torch.Tensor, dh: torch.Tensor, dh16_valid: bool, feeds_lower: bool):
         """dh (fp32 [M, D], gradient of the block's output) -> gradient of its input, in place; activation gradients only."""
         w, D, Fd = self.blocks[l], self.D, self.F
         dy16, dt16, da1, u16 = ws["dy16"], ws["dt16"], ws["da1"], ws["u16"]
+        if ops.TIMER is None:
+            return ops.vit_block_bwd(w["cw"], self._cbuf(l, ws, hin, dh), plan, M, D, Fd, dh16_valid, feeds_lower)
         if dh16_valid:
             src16 = ws["dh16"]
         else:
