@@ -486,13 +486,29 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
       // the per-query constants (query = lane: one value per lane) ride in as the INITIAL accumulators:
       // S' - L2 + log2(ln 2) and dP - delta leave the chains ready
       f32x16 s, dp;
+      // The six row fragments of the two chains are requested AHEAD of the products -- three reads up front, then one read per
+      // MFMA (sched_group_barrier: DS_READ x3, (MFMA, DS_READ) x3, MFMA x3) -- so every fragment is in flight for >= 2 MFMAs
+      // (64+ cycles) before its use.  Left alone the compiler reuses ONE fragment register: read -> s_waitcnt lgkmcnt(0) -> MFMA,
+      // six exposed LDS round trips per 32 keys (same-box A/B, tools/attn3_microbench.py: dQ 0.537 -> 0.517 ms, dK/dV 0.802 ->
+      // 0.777; requesting all six at once costs registers: dK/dV drops to 2 waves per SIMD and loses 9 %).
+      h16x8 ka[3], va[3];
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + rrd[ks]]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? nl2i : s, 0, 0, 0);
-        const h16x8 vf = *reinterpret_cast<const h16x8*>(&Vb[sub * 32 * IMG_ROW + rrd[ks]]);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], ks == 0 ? ndli : dp, 0, 0, 0);
+        ka[ks] = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + rrd[ks]]);
+        va[ks] = *reinterpret_cast<const h16x8*>(&Vb[sub * 32 * IMG_ROW + rrd[ks]]);
       }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[ks], qf[ks], ks == 0 ? nl2i : s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks], dof[ks], ks == 0 ? ndli : dp, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
       h16x8 dsf[2];
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
@@ -548,7 +564,8 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
 // MFMA chains, and q carries the softmax scale, so the elementwise block is 1 packed mul, 2 exp and 2 packed
 // converts per element pair.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
+// (launch bound: 3 waves per SIMD = 168 VGPRs; the prefetched fragments would otherwise push the kernel to 175 and a wave per SIMD less)
+__global__ __launch_bounds__(256, 3) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
                                                                   const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
                                                                   Plan p, h16* __restrict__ ws) {
   // Q and dO tiles in LDS-DMA images (attn_common.h: img_off: each read both by rows and transposed), double-buffered
@@ -647,13 +664,27 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_kv_kernel(const h16* __r
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a[e]; dp[4 * g4 + e] = b[e]; }
       }
+      // row fragments requested ahead of the products, three deep (see the dQ kernel); the full barrier keeps the constants'
+      // reads above out of the read / MFMA groups
+      __builtin_amdgcn_sched_barrier(0);
+      h16x8 qa[3], da[3];
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qb[sub * 32 * IMG_ROW + rrd[ks]]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s, 0, 0, 0);
-        const h16x8 da = *reinterpret_cast<const h16x8*>(&Db[sub * 32 * IMG_ROW + rrd[ks]]);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp, 0, 0, 0);
+        qa[ks] = *reinterpret_cast<const h16x8*>(&Qb[sub * 32 * IMG_ROW + rrd[ks]]);
+        da[ks] = *reinterpret_cast<const h16x8*>(&Db[sub * 32 * IMG_ROW + rrd[ks]]);
       }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da[ks], vf[ks], dp, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
       h16x8 pf[2], dsf[2];
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
