@@ -69,13 +69,19 @@ def test_train_step_matches_reference_golden(golden_dir, name):
     names = [str(n) for n in g["f64_grad_names"]]
     ours = np.array([float(grads[n].double().norm()) for n in names])
     ref = g["f64_grad_norms"]
-    bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > 2e-2 * r + 1e-6 * ref.max()]
+    # Tolerances (measured, tools/diag/grad_errors.py: every norm within 1 % and every full tensor within 0.4 % on all nine
+    # fixtures, with two exceptions inside the gene encoder).  The exceptions do NOT come from the fp16 gradient stream: their
+    # error is the same to three digits at loss scales 2^10 ... 2^24 -- it is the forward's fp16 operand rounding (activations
+    # off by ~3e-4, as under the reference's own autocast) seen through gradient sums that cancel almost completely.
+    loose = {"gene_encoder.mlp_mixer.2.0.fn.0.bias": 2.5e-2}
+    bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > loose.get(n, 1e-2) * r + 1e-6 * ref.max()]
     assert not bad, bad[:10]
     for k in g.files:
         if k.startswith("f64_grad/"):        # full tensors: relative L2 error
-            ours_k = grads[k[len("f64_grad/"):]].double().cpu().numpy()
+            key = k[len("f64_grad/"):]
+            ours_k = grads[key].double().cpu().numpy()
             err = np.linalg.norm(ours_k - g[k]) / (np.linalg.norm(g[k]) + 1e-300)
-            assert err < 4e-2, (k, err)      # (cancellation-heavy small tensors, e.g. pathway_compression.weight, sit at 2-3 %)
+            assert err < (3.5e-2 if key == "gene_encoder.pathway_compression.weight" else 1e-2), (k, err)
 
 
 @pytest.mark.parametrize("L", [1, 2, 7, 63, 129])
@@ -511,7 +517,7 @@ def test_two_adamw_steps_match_reference_trainer_golden(golden_dir):
         assert travelled.mean() > 0.5 * lr, key                      # (the reference really moved these weights)
         d = np.abs(got - ref)
         assert d.max() <= 2.0 * steps * lr * 1.01, (key, d.max())
-        assert np.mean(d > 0.1 * steps * lr) < 0.03, (key, float(np.mean(d > 0.1 * steps * lr)))
+        assert np.mean(d > 0.1 * steps * lr) < 0.01, (key, float(np.mean(d > 0.1 * steps * lr)))      # (measured: <= 0.13 %)
         n += 1
     assert n >= 6
 
