@@ -81,7 +81,8 @@ MT_DEVINL float sum_halves(float x) { return x + __shfl_xor(x, 32, 64); }
 
 // ------------------------------------------------------------------------------------------------ forward
 template <bool BIAS>
-__global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseArgs a, h16* __restrict__ o, float* __restrict__ lse) {
+// (launch bound: 3 waves per SIMD -- 158 VGPRs instead of 172, no spill: -4 % same-box, tools/dense_microbench.py)
+__global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16* __restrict__ o, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // K0 | K1 | V0 | V1
   __shared__ __attribute__((aligned(16))) h16 pos_s[2 * PIMG + 8];       // key a_k tiles (two buffers) + a zero chunk
   h16* const Ks = smem;
