@@ -30,8 +30,9 @@ CPU_REFERENCE = {"value": 0.0054, "unit": "slides/s", "cores": 8, "kind": "refer
                            "8-core build container: 185.6 s/slide (the reference cannot travel to the GPU box)"}
 # rocprofv3 --pmc passes of the dominant kernel cannot run inside this script (one counter group per run, gpurun refuses
 # tracing + PMC together): the committed summary file is parsed at run time instead of a literal
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_attn_bwd.txt")
-PMC_TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r01_pmc_hbm_attn_bwd.txt")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_attn_bwd.txt")
+PMC_TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r02_pmc_hbm_attn_bwd.txt")
+PMC_TRAFFIC_DENSE = os.path.join(ROOT, "profiles", "r03_pmc_dense_attn.txt")      # tools/dense_microbench.py geometry: N = 4097, 3 passes
 
 
 def parse_args():
@@ -154,12 +155,12 @@ def cpu_baseline_leg(cfg, sizes, L, seed, max_seconds=20.0):
                       f"step = 36 layer passes (3 tasks x 12 layers) -> {36 * t:.1f} s/slide"}
 
 
-def recorded_traffic(kernel: str, L: int, T: int):
+def recorded_traffic(kernel: str, L: int, T: int, paths=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/pmc_hbm.sh + tools/pmc_summary.py
     at L = 10 000, T = 65): 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, KiB -> bytes."""
-    if (L, T) != (10000, 65):
+    if paths is None and (L, T) != (10000, 65):
         return None, None
-    for path in (PMC_TRAFFIC_FILE, PMC_TRAFFIC_FALLBACK):
+    for path in (paths or (PMC_TRAFFIC_FILE, PMC_TRAFFIC_FALLBACK)):
         if not os.path.exists(path):
             continue
         vals, cur = {}, None
@@ -320,6 +321,9 @@ def main_titan(args):
     n_l, ms = summ["dense_attn_bwd_kv"]
     kv_flops = sum(2.0 * 3 * flops_per_titan_step(c, T)["attn_layer"] for c in cells_per) / len(cells_per)
     achieved = kv_flops / (ms / n_l * 1e-3) / 1e12
+    # HBM traffic of that kernel from the committed PMC summary: measured at N = 4097 tokens (the microbenchmark's geometry), which
+    # is this run's mean bag; per launch like `achieved`
+    traffic, traffic_file = recorded_traffic("dense_attn_bwd_kv_kernel", 0, 0, paths=(PMC_TRAFFIC_DENSE,))
     table = []
     for key, mult in (("dense_attn_fwd", 1.0), ("dense_attn_bwd_kv", 2.0), ("dense_attn_bwd_q", 1.5)):
         if key in summ:
@@ -340,7 +344,10 @@ def main_titan(args):
                    "cells": cells_per, "tokens": T, "parallelism": "dp1", "backbone_impl": eng.backbone.kind, "self_check": report},
         "loss": loss, "step_tflops": step_flops / 1e12, "step_mfma_frac": step_flops * value / 1e12 / PEAK_F16_MFMA_TFLOPS,
         "roofline": {"kernel": "dense_attn_bwd_kv_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms / n_l, "flops_per_launch": kv_flops,
+                     "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": traffic,
+                     "traffic_source": (f"{traffic_file}: rocprofv3 --pmc passes at N = 4097 tokens x 3 passes (tools/dense_microbench.py), "
+                                        "(2 x FETCH_SIZE + WRITE_SIZE) KiB" if traffic is not None else None),
+                     "avg_launch_ms": ms / n_l, "flops_per_launch": kv_flops,
                      "measured": f"HIP events around each launch, eager instrumented pass over the {prof_steps} bag lengths after the timed region"},
         "roofline_kernels": table, "launch": "eager",
         "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:14]},

@@ -22,4 +22,8 @@ python bench.py --api module > $out/bench_module.json 2>/dev/null
 python bench.py --config titan --patches 4096 --ragged --steps 16 --warmup 8 > $out/titan_bench.json 2> $out/titan_bench.err
 rocprofv3 --kernel-trace --stats -d $out/titan_stats -o s --output-format csv -- python3 bench.py --config titan --patches 4096 --ragged --steps 16 --warmup 8 --no-cpu-baseline > $out/titan_stats.log 2>&1
 find $out/titan_stats -name "*kernel_stats.csv" -exec cp {} $out/titan_kernel_stats.csv \;
+# SQ + HBM counters of the dense ALiBi attention kernels (TITAN configuration, N = 4097, 3 passes)
+bash tools/pmc.sh ${tag}_dense tools/dense_microbench.py
+bash tools/pmc_hbm.sh ${tag}_dense tools/dense_microbench.py
+python tools/pmc_summary.py gpurun_out/pmc_${tag}_dense dense_attn > $out/pmc_dense_attn.txt
 echo profile set done
