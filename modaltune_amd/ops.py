@@ -21,11 +21,19 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU = 0, 1, 2, 3
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()      # (ctypes converts the int for c_void_p parameters / struct fields)
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _s():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device as a raw handle.  (torch.cuda.current_stream() builds a Stream object and
+    re-validates the device on every call: a third of the host time of an eager step, tools/diag/host_profile.py.)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _dt(t: torch.Tensor) -> int:
