@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   for (int t = 0; t < nplain; ++t) tile(t, std::false_type{});
   if (tail_last) tile(ntile - 1, std::true_type{});
   if (qvalid) {
-    h16* out = ws + ws_slot(p, w, iq);
+    h16* out = ws + ws_slot(p, w, qrow);
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const h16x4 v = {(h16)dq0[4 * gq], (h16)dq0[4 * gq + 1], (h16)dq0[4 * gq + 2], (h16)dq0[4 * gq + 3]};
@@ -711,8 +711,8 @@ __global__ __launch_bounds__(256, 3) void dilated_attn_bwd_kv_kernel(const h16* 
     __syncthreads();           // ... for everybody, and everybody has left tile t
   }
   if (kvalid) {
-    h16* outk = ws + ws_slot(p, w, ik) + HD;
-    h16* outv = outk + HD;
+    h16* outk = ws + ws_slot(p, w, krow) + ws_which_stride(p, w.br);
+    h16* outv = outk + ws_which_stride(p, w.br);
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const h16x4 a = {(h16)dk0[4 * gq], (h16)dk0[4 * gq + 1], (h16)dk0[4 * gq + 2], (h16)dk0[4 * gq + 3]};
@@ -733,25 +733,25 @@ __global__ __launch_bounds__(256, 3) void dilated_attn_bwd_kv_kernel(const h16* 
 }
 
 // Sum the per-branch compact gradients into the dense fp16 dqkv [B*N, 2304] that feeds the dX GEMM.
-// 192 threads per token row: thread -> 12 consecutive columns of one (q|k|v, head).
+// 192 threads per token row: thread -> 12 consecutive columns of one (q|k|v, head).  The workspace is token-major
+// (attn_common.h: ws_slot): the heads a branch covers at a token are one contiguous run in the source AND in the dense row, so
+// the threads of a wave read consecutive addresses.
 __global__ __launch_bounds__(192) void dilated_attn_bwd_combine_kernel(const h16* __restrict__ ws, Plan p, h16* __restrict__ dqkv) {
   const long M = (long)p.B * p.N;
   const int t = threadIdx.x;
   const int col = t * 12, which = col / DM, h = (col % DM) / HD, d0 = col % HD;
   for (long m = blockIdx.x; m < M; m += gridDim.x) {
-    const int b = (int)(m / p.N), pos = (int)(m % p.N);
+    const int pos = (int)(m % p.N);
     float acc[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int br = 0; br < MT_MAX_BRANCHES; ++br) {
       if (br < p.nbranch) {
-        const int dr = p.ratio[br], sg = p.seg[br];
+        const int dr = p.ratio[br], sg = p.seg[br], hb = H / dr;
         const int j = pos / sg, loc = pos - j * sg;
-        const int r = h / (H / dr);
-        if (loc % dr == r) {
-          const int i = loc / dr;
-          const h16* src = ws + p.ws_off[br] + ((((long)b * p.nseg[br] + j) * H + h) * p.n[br] + i) * (3 * HD) + which * HD + d0;
+        if (loc % dr == h / hb) {
+          const h16* src = ws + p.ws_off[br] + ((m * 3 + which) * hb + (h % hb)) * HD + d0;
           const h16x4 a0 = *reinterpret_cast<const h16x4*>(src), a1 = *reinterpret_cast<const h16x4*>(src + 4),
                       a2 = *reinterpret_cast<const h16x4*>(src + 8);
 #pragma unroll

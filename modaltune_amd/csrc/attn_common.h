@@ -27,7 +27,7 @@ struct Plan {
   int nbranch, N, B;
   int seg[MT_MAX_BRANCHES], ratio[MT_MAX_BRANCHES], nseg[MT_MAX_BRANCHES], n[MT_MAX_BRANCHES];
   int order[MT_MAX_BRANCHES], qtiles[MT_MAX_BRANCHES], blk_off[MT_MAX_BRANCHES + 1];
-  long ws_off[MT_MAX_BRANCHES + 1];   // backward workspace: per-branch compact [pass][seg][head][i][q|k|v][48] fp16
+  long ws_off[MT_MAX_BRANCHES + 1];   // backward workspace: per-branch compact, TOKEN-major [pass][token][q|k|v][16 / ratio heads][48] fp16
   float inv_seg[MT_MAX_BRANCHES];     // 1 / seg (position -> segment index without an integer division per row)
   int qlimit[MT_MAX_BRANCHES];        // sparse entries [0, qlimit) act as queries (= n unless sequence-parallel)
 };
@@ -52,7 +52,7 @@ Plan make_plan(const MtDilatedPlan* p, int qtile) {
     d.blk_off[i + 1] = d.blk_off[i] + d.B * d.nseg[b] * H * d.qtiles[b];
   }
   d.ws_off[0] = 0;
-  for (int b = 0; b < d.nbranch; ++b) d.ws_off[b + 1] = d.ws_off[b] + (long)d.B * d.nseg[b] * H * d.n[b] * 3 * HD;
+  for (int b = 0; b < d.nbranch; ++b) d.ws_off[b + 1] = d.ws_off[b] + (long)d.B * d.N * 3 * (H / d.ratio[b]) * HD;
   return d;
 }
 
@@ -187,10 +187,18 @@ MT_DEVINL h16x8 sel8(bool ok, h16x8 v) {
   return ok ? v : z;
 }
 
-// backward workspace slot of sparse entry i of work item w: 3 x 48 halves (dq | dk | dv)
-MT_DEVINL long ws_slot(const Plan& p, const WorkItem& w, int i) {
-  return p.ws_off[w.br] + ((((long)w.b * p.nseg[w.br] + w.j) * H + w.h) * p.n[w.br] + i) * (3 * HD);
+// Backward workspace of a branch: TOKEN-major [pass][token][which = dq | dk | dv][slot][48] with slot = head % (16 / ratio): a
+// token is visited by the 16 / ratio heads of ONE group (the group whose index is the token's residue inside its segment), so
+// the (16 / ratio) x 48 halves of one `which` are exactly the contiguous run of columns that group owns in the dense row
+// [q | k | v][16 heads x 48] -- the combine pass then reads and writes contiguous runs per (token, branch, which) instead of
+// gathering 288-byte entries that lie n x 288 bytes apart (same-box A/B: 0.113 -> 0.105 ms per launch; 16-byte loads with two
+// rows per workgroup were slower: 0.118).
+// Returns the offset (halves) of `which` = 0 of (token, head); `which` advances by ws_which_stride().
+MT_DEVINL long ws_slot(const Plan& p, const WorkItem& w, long token_row) {
+  const int hb = H / p.ratio[w.br];
+  return p.ws_off[w.br] + (token_row * 3) * (hb * HD) + (w.h % hb) * HD;
 }
+MT_DEVINL int ws_which_stride(const Plan& p, int br) { return (H / p.ratio[br]) * HD; }
 
 MT_DEVINL Seq make_seq(const Plan& p, const WorkItem& w) {
   Seq q;

@@ -91,7 +91,7 @@ class SeqParallelAttention:
         self.plan_loc = ops.make_plan(br[:self.nb_loc], Lloc, B) if self.nb_loc else None
         self.ws_off = [0]
         for b in br:
-            self.ws_off.append(self.ws_off[-1] + B * b.nseg * H * b.n * 3 * HD)        # halves (attn_common.h: make_plan)
+            self.ws_off.append(self.ws_off[-1] + B * Lloc * 3 * (H // b.ratio) * HD)   # halves, token-major (attn_common.h: make_plan)
         self.groups: List[_Group] = []
         for i, (sl, dr, first, size) in enumerate(long_):
             g = next((x for x in self.groups if (x.first, x.size) == (first, size)), None)
@@ -106,12 +106,12 @@ class SeqParallelAttention:
             g.ws_bytes = ops.dilated_attn_bwd_workspace_bytes(g.plan)
             g.ws_off = [0]
             for b in gb:
-                g.ws_off.append(g.ws_off[-1] + B * H * b.n * 3 * HD)
-        # reduce-scatter payload: per long branch the compact entries [B][16][Lloc / dr][q|k|v][48] of one chunk
+                g.ws_off.append(g.ws_off[-1] + B * Ng * 3 * (H // b.ratio) * HD)
+        # exchange payload: per long branch the compact token rows [B][Lloc][q|k|v][16 / dr][48] of one chunk
         self.pay_off = [0]
         for g in self.groups:
             for i in g.branches:
-                self.pay_off.append(self.pay_off[-1] + B * H * br[i].n * 3 * HD)
+                self.pay_off.append(self.pay_off[-1] + B * Lloc * 3 * (H // br[i].ratio) * HD)
         self.pay = self.pay_off[-1]
 
     # ------------------------------------------------------------------ helpers
@@ -239,14 +239,13 @@ class SeqParallelAttention:
                 ws_g = self._new(g.ws_bytes // 2, zero=True)
                 ops.dilated_attn_bwd_phases(S, dm_g, lt_g, dl_g, g.plan, ws_g, ws_g, ops.ATTN_BWD_KV | ops.ATTN_BWD_Q)
                 for j, i in enumerate(g.branches):
-                    nq, ng = self.branches[i].n, g.plan.n[j]
-                    ent = _f32(ws_g[g.ws_off[j]:g.ws_off[j + 1]])                # entries [B * 16][ng][q|k|v][48] as 72-word rows
-                    # dq of this rank's queries (entries [0, nq) of every (pass, head)) + its own dk / dv share -> local workspace
-                    ops.copy_rows(ent, _f32(ws[self.ws_off[i]:self.ws_off[i + 1]]), B * H * nq, 72, smap=rowmap(nq, ng, 0))
-                    # dk / dv of every chunk of the group -> the owner's slot of the reduce-scatter payload
+                    wr = 3 * (H // self.branches[i].ratio) * HD // 2             # fp32 words per compact token row [q|k|v][16/dr][48]
+                    ent = _f32(ws_g[g.ws_off[j]:g.ws_off[j + 1]])                # token rows [B][Ng] of the group space
+                    # dq of this rank's queries (its rows are the first Lloc of every pass) + its own dk / dv share -> local workspace
+                    ops.copy_rows(ent, _f32(ws[self.ws_off[i]:self.ws_off[i + 1]]), B * L, wr, smap=rowmap(L, Ng, 0))
+                    # dk / dv of every chunk of the group -> the owner's slot of the exchange payload
                     for c, rc in enumerate(g.ranks):
-                        ops.copy_rows(ent, _f32(contrib[rc, self.pay_off[k]:self.pay_off[k + 1]]), B * H * nq, 72,
-                                      smap=rowmap(nq, ng, c * nq))
+                        ops.copy_rows(ent, _f32(contrib[rc, self.pay_off[k]:self.pay_off[k + 1]]), B * L, wr, smap=rowmap(L, Ng, c * L))
                     k += 1
             red = self._exchange_sum(contrib)                                    # [pay] fp32: sum over the ranks of my groups
             red16 = self._new(self.pay)
@@ -254,11 +253,11 @@ class SeqParallelAttention:
             k = 0
             for g in self.groups:
                 for i in g.branches:
-                    nq = self.branches[i].n
+                    wp = (H // self.branches[i].ratio) * HD // 2                 # words of one of q | k | v in a compact token row
                     src = _f32(red16[self.pay_off[k]:self.pay_off[k + 1]])
                     dst = _f32(ws[self.ws_off[i]:self.ws_off[i + 1]])
-                    for part in (1, 2):                                          # k and v sub-rows of every entry (24 words each)
-                        ops.copy_rows(src, dst, B * H * nq, 24, smap=rowmap(1, 3, part), dmap=rowmap(1, 3, part))
+                    # the k and v thirds of every token row (the q third of the local workspace keeps this rank's own dq)
+                    ops.copy_rows(src[wp:], dst[wp:], B * L, 2 * wp, lds=3 * wp, ldd=3 * wp)
                     k += 1
         ops.dilated_attn_bwd_phases(qkv_hm, dmixed, lse_tot, delta_br, self.plan_full, ws, dqkv, ops.ATTN_BWD_COMBINE)
         return dqkv
