@@ -201,10 +201,13 @@ class GradReducer:
                 h = torch.empty(W * s, dtype=full.dtype)
                 dist.all_gather_into_tensor(h, mine.cpu(), group=self.group)
                 full.copy_(h)
-            else:       # in place: this rank's input IS its slot of the output (the RCCL in-place form)
-                self._param_pending.append(dist.all_gather_into_tensor(full, mine, group=self.group, async_op=True))
+            else:       # gathered into a staging buffer (no aliasing of a collective's input and output), copied back in wait_params
+                stage = torch.empty(W * s, dtype=full.dtype, device=full.device)
+                work = dist.all_gather_into_tensor(stage, mine.clone(), group=self.group, async_op=True)
+                self._param_pending.append((work, full, stage))
 
     def wait_params(self):
-        for w in self._param_pending:
-            w.wait()
+        for work, full, stage in self._param_pending:
+            work.wait()
+            full.copy_(stage)
         self._param_pending.clear()
