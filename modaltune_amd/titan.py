@@ -35,7 +35,6 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import rowmap
 from .aggregators import Aggregator, LongNetGeneAdapter, _bridge_backward
 from .config import ModelConfig
 from .engine import Engine, F32, H16, _W16
