@@ -36,6 +36,7 @@ class EmbeddingExtractor:
         nt = max(1, engine.cfg.multi_task)
         self.onehots = torch.eye(nt, dtype=F32, device=self.dev)[list(task_ids)].contiguous()
         self._key = None
+        self.patch_size_lv0 = 1024          # TITAN configuration only (titan_adapter.py:335)
 
     @torch.no_grad()
     def __call__(self, x, coords, genes: Sequence[torch.Tensor], clinical=None) -> torch.Tensor:
@@ -48,6 +49,9 @@ class EmbeddingExtractor:
         L, B = x.shape[0], self.onehots.shape[0]
         if isinstance(genes, dict):
             genes = [genes[k] for k in sorted(genes.keys())]
+        if hasattr(eng, "forward_slide"):      # TITAN configuration: the token count is known only after the gridding -> eager
+            return eng.forward_slide(x, coords, list(genes), self.onehots, patch_size_lv0=self.patch_size_lv0, need_grad=False,
+                                     clinical=clinical)
         if not self.graphed:
             return eng.forward(x, coords, list(genes), self.onehots, need_grad=False, clinical=clinical)
         gflat = genes.reshape(-1) if torch.is_tensor(genes) else torch.cat([g.reshape(-1) for g in genes])

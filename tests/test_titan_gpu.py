@@ -97,7 +97,16 @@ def test_titan_gridding_and_ragged_bags(golden_dir, impl):
     assert torch.equal(fg, fg2)                      # cells shared by several patches: summed in patch order, every time
     model.eval()
     outs = {}
-    with torch.no_grad():
+    from modaltune_amd.evaluate import EmbeddingExtractor
+    with torch.no_grad():      # the eval / embedding pass (TM:252-327): 3 task passes in one batched forward == one call per task
+        ext = EmbeddingExtractor(model.engine, task_ids=(0, 1, 2))
+        xs, cs = torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda()
+        gl = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+        emb = ext(xs, cs, gl)
+        model.speculate = False
+        one = torch.cat([model(x=xs, coords=cs, genes=gl, task_token=torch.eye(3)[t].cuda()) for t in (0, 1, 2)], dim=0)
+        model.speculate = True
+        assert emb.shape == (3, 256) and float((emb - one).abs().max()) < 1e-4 * float(one.abs().max())
         for rep in range(2):
             for L in (300, 90, 520, 33):
                 inp_l = synth.synth_inputs_titan(L, sizes, seed + L, grid=24)
