@@ -178,3 +178,24 @@ def test_native_blocks_match_module_at_4096_cells_mixed_lengths():
         top = max(gt.values())
         bad = [(k, gn[k], gt[k]) for k in gt if abs(gn[k] - gt[k]) > 2e-2 * gt[k] + 1e-6 * top]
         assert not bad, (L, bad[:8])
+
+
+def test_titan_degenerate_slides(golden_dir):
+    """One foreground cell (three patches that all fall into it: the sequence is cls + 1 token), and a slide whose patches sit
+    on one grid row: native blocks == the module's torch blocks on both."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _, m_nat, sizes, inp, seed, _, _ = _model(golden_dir, "titan_L300", "native")
+    _, m_tor, _, _, _, _, _ = _model(golden_dir, "titan_L300", "torch")
+    genes = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    g = torch.Generator().manual_seed(3)
+    cases = {"one_cell": (torch.randn(1, 3, 768, generator=g), torch.tensor([[[5000, 7000], [5100, 7100], [5900, 7900]]])),
+             "one_row": (torch.randn(1, 40, 768, generator=g), torch.stack([torch.full((40,), 9000), 3000 + 1024 * torch.arange(40)], 1)[None])}
+    for name, (x, coords) in cases.items():
+        outs = []
+        for m in (m_nat, m_tor):
+            m.eval()
+            with torch.no_grad():
+                outs.append(m(x=x.cuda(), coords=coords.cuda(), genes=genes, task_token=torch.eye(3)[2].cuda()))
+        assert torch.isfinite(outs[0]).all(), name
+        assert float((outs[0] - outs[1]).abs().max()) < 1e-3 * float(outs[1].abs().max()), name
