@@ -15,13 +15,17 @@ dy = (torch.randn(M, 768, device="cuda", generator=g) * 0.1).half()
 dmixed = torch.zeros(16, M, 48, dtype=torch.float16, device="cuda"); delta = torch.zeros(5, M, 16, device="cuda")
 ws = torch.zeros(ops.dilated_attn_bwd_workspace_bytes(plan) // 2, dtype=torch.float16, device="cuda")
 dqkv = torch.zeros(M, 2304, dtype=torch.float16, device="cuda")
-def run():
-    ops.dilated_mix_ln_fwd(o_br, lse_br, plan, ln_w, ln_b, y, stats, lse_tot)
-    ops.dilated_mix_ln_bwd(dy, o_br, lse_br, lse_tot, plan, ln_w, stats, dmixed, delta)
-    ops.dilated_attn_bwd_phases(qkv, dmixed, lse_tot, delta, plan, ws, dqkv, ops.ATTN_BWD_COMBINE)
-run(); torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(5): run()
-e1.record(); torch.cuda.synchronize()
-print("mix fwd + mix bwd + combine ms", e0.elapsed_time(e1) / 5)
+def t(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+fwd = t(lambda: ops.dilated_mix_ln_fwd(o_br, lse_br, plan, ln_w, ln_b, y, stats, lse_tot))
+bwd = t(lambda: ops.dilated_mix_ln_bwd(dy, o_br, lse_br, lse_tot, plan, ln_w, stats, dmixed, delta))
+comb = t(lambda: ops.dilated_attn_bwd_phases(qkv, dmixed, lse_tot, delta, plan, ws, dqkv, ops.ATTN_BWD_COMBINE))
+print(f"mix_fwd {fwd:.4f} mix_bwd {bwd:.4f} combine {comb:.4f} ms  checksum {float(y.float().abs().sum()):.6e} {float(dmixed.float().abs().sum()):.6e} {float(delta.abs().sum()):.6e}")
