@@ -45,6 +45,7 @@ class ParamStore:
                 self.slots[k] = (off, n, shape)
                 off += (n + 3) // 4 * 4
         self.n_flat = off
+        self.sync = None                  # set by TrainStep: waits for a sharded parameter all-gather in flight (dp.GradReducer.wait_params)
         self.flat = torch.zeros(off, dtype=F32, device=device)
         self.flat_grad = torch.zeros(off, dtype=F32, device=device)
         self.tensors: Dict[str, torch.Tensor] = {}
@@ -71,6 +72,8 @@ class ParamStore:
                 t.copy_(v.to(device=self.device, dtype=F32))
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        if self.sync is not None:
+            self.sync()               # a sharded optimiser step's parameter all-gather may still be in flight (dp.GradReducer)
         return {k: v.detach().clone() for k, v in self.tensors.items()}
 
     def param(self, k: str) -> Param:
@@ -339,6 +342,8 @@ class Engine:
         task-independent patch embedding in it (`x0`: input cast + patch-embed GEMM + positional term, LVA:232-242), the later
         ones take it from there instead of recomputing it (the reference recomputes it for every task id)."""
         cfg, dev, t = self.cfg, self.device, self.store.tensors
+        if self.store.sync is not None:
+            self.store.sync()         # parameters complete on this rank before anything reads them (no-op when nothing is pending)
         if not self._caches_ready:
             self._build_caches()
         if staged:

@@ -66,6 +66,7 @@ class TrainStep:
         self._nint = nint
         self.reducer = dp.GradReducer(engine.store.flat_grad, dp.grad_buckets(engine.store.slots, nint, n), process_group,
                                       flat_param=engine.store.flat)
+        engine.store.sync = self.reducer.wait_params      # state_dict() / a forward outside the step see complete parameters
         # captured graphs: LRU over bag geometries (real data has a new length almost every slide: a geometry is captured
         # only once it has been seen `capture_after` times, everything else runs the eager schedule)
         self.graph_cache_size, self.capture_after = int(graph_cache_size), int(capture_after)

@@ -46,7 +46,9 @@ def trainstep(rank, world, out):
     losses = []
     for _ in range(STEPS):
         losses.append(float(ts.step_graphed(x, coords, genes, text)))
+    sd = eng.store.state_dict()      # what a checkpoint would hold: waits for the sharded parameter all-gather of the last step
     torch.cuda.synchronize()
+    assert all(torch.equal(sd[k], eng.store.tensors[k]) for k in sd)
     nseg = max(len(s) for s in ts._graphs) if ts._graphs else 0
     np.savez(out, flat=eng.store.flat.cpu().numpy(), losses=np.array(losses), replays=ts.graph_replays, nseg=nseg,
              steps=int(ts.step_dev), buckets=len(ts.reducer.buckets))
