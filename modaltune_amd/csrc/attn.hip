@@ -617,16 +617,18 @@ __global__ __launch_bounds__(256, 3) void dilated_attn_bwd_kv_kernel(const h16* 
   auto issue = [&](int t) {
     dma_tile(Qx + (t & 1) * IMG_HALVES, tile_rsrc(qseq, t * tile_bytes, valid_bytes), dl);
     dma_tile(Dx + (t & 1) * IMG_HALVES, tile_rsrc(dseq, t * tile_bytes, valid_bytes), dl);
-    if (tid < 64) {
-      const int i = t * 64 + lane;
-      const long off = (long)min(i, nvq - 1) * sq.dr * H;
-      const bool ok = i < nvq;
-      rl2 = ok ? fmaf(-lbase[off], LOG2E, LOG2_LN2) : 0.f;      // (Q = dO = 0 there: P' is multiplied by zeros)
-      rdl = ok ? -dbase[off] : 0.f;
+    if (tid < 64) {      // RAW loads only: the arithmetic on them waits in publish(), at the END of the tile (a use here parks wave 0
+      const long off = (long)min(t * 64 + lane, nvq - 1) * sq.dr * H;      // on s_waitcnt vmcnt(0) -- the DMA just issued included)
+      rl2 = lbase[off];
+      rdl = dbase[off];
     }
   };
   auto publish = [&](int t) {      // constants of tile t into their buffer (written by wave 0, read after the barrier)
-    if (tid < 64) { L2s[t & 1][tid] = rl2; Dls[t & 1][tid] = rdl; }
+    if (tid < 64) {
+      const bool ok = t * 64 + lane < nvq;      // (Q = dO = 0 past the end: P' is multiplied by zeros)
+      L2s[t & 1][tid] = ok ? fmaf(-rl2, LOG2E, LOG2_LN2) : 0.f;
+      Dls[t & 1][tid] = ok ? -rdl : 0.f;
+    }
   };
 
   f32x16 dk0, dk1, dv0, dv1;

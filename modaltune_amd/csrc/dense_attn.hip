@@ -421,15 +421,19 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kv_kernel(DenseArgs a, con
     dma_tile64(Dx + (t & 1) * IMG_HALVES, tile_rsrc(dseq, t * 64L * drow_bytes, dvalid_bytes), dld);
     if (tid < 64) {
       if (BIAS) dma_pos(pos_s + (t & 1) * PIMG, a.posq, t, N, lane);
-      const int i = t * 64 + lane;
-      const long off = (long)min(i, N - 1) * a.H;
-      const bool ok = i < N;
-      rl2 = ok ? fmaf(-lbase[off], LOG2E, LOG2_LN2) : 0.f;      // (Q = dO = 0 past the end: P' meets zeros)
-      rdl = ok ? -dbase[off] : 0.f;
+      // RAW loads only; the arithmetic waits in publish() at the end of the tile (a use here parks wave 0 on s_waitcnt vmcnt(0),
+      // the DMA just issued included: attn.hip, dK/dV kernel)
+      const long off = (long)min(t * 64 + lane, N - 1) * a.H;
+      rl2 = lbase[off];
+      rdl = dbase[off];
     }
   };
   auto publish = [&](int t) {
-    if (tid < 64) { L2s[t & 1][tid] = rl2; Dls[t & 1][tid] = rdl; }
+    if (tid < 64) {
+      const bool ok = t * 64 + lane < N;      // (Q = dO = 0 past the end: P' meets zeros)
+      L2s[t & 1][tid] = ok ? fmaf(-rl2, LOG2E, LOG2_LN2) : 0.f;
+      Dls[t & 1][tid] = ok ? -rdl : 0.f;
+    }
   };
 
   f32x16 dk0 = splat16(0.f), dk1 = splat16(0.f), dv0 = splat16(0.f), dv1 = splat16(0.f);

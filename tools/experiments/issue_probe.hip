@@ -58,6 +58,10 @@ extern "C" int issue_probe(int which, float* sink, int wgs, int iters, void* str
     CASE(5, 0, 0, 58, true)        // plain VALU only
     CASE(6, 28, 0, 58, true)       // MFMA + plain VALU
     CASE(7, 28, 32, 0, true)       // MFMA + exp
+    CASE(8, 14, 0, 0, true)        // the forward tile: 14 MFMA
+    CASE(9, 0, 32, 52, true)       //                   32 exp + 52 plain
+    CASE(10, 14, 32, 52, true)     //                   both, phased
+    CASE(11, 14, 32, 52, false)    //                   both, scheduler free
     default: return -1;
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -5,12 +5,12 @@ lib = ctypes.CDLL(os.path.join(ROOT, "build_variants", "issue_probe.so"))
 lib.issue_probe.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 sink = torch.zeros(16, device="cuda")
 ncu = torch.cuda.get_device_properties(0).multi_processor_count
-names = ["mfma28", "exp32+valu58", "mfma28|exp32+valu58 phased", "same, scheduler free", "exp32", "valu58", "mfma28|valu58", "mfma28|exp32"]
+names = ["mfma28", "exp32+valu58", "mfma28|exp32+valu58 phased", "same, scheduler free", "exp32", "valu58", "mfma28|valu58", "mfma28|exp32", "fwd: mfma14", "fwd: exp32+valu52", "fwd: phased", "fwd: free"]
 iters = 4000
 clk = 2.4e9
 for occ in (1, 2, 3):
     row = []
-    for which in range(8):
+    for which in range(len(names)):
         st = torch.cuda.current_stream().cuda_stream
         lib.issue_probe(which, sink.data_ptr(), ncu * occ, 200, st); torch.cuda.synchronize()
         best = 1e9
