@@ -74,6 +74,8 @@ class TrainStep:
         self._visits: Dict[tuple, int] = {}        # eager visits of not-yet-captured geometries (never evicts a capture)
         self._ggen = -1
         self._opt_graph = None
+        self._pool = None                   # graph memory pool shared by all captures (see _capture)
+        self._cap_stream = None
         self._cap = None                    # state of a segmented capture in progress
         self._static_key = None
         self.graph_replays = 0
@@ -293,9 +295,17 @@ class TrainStep:
     def _capture(self, ent: _Captured, fwd_bwd, world: int):
         torch.cuda.synchronize()
         main = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
+        if self._cap_stream is None:          # ONE capture stream: the allocator hands a freed block only to the stream it was
+            self._cap_stream = torch.cuda.Stream()      # allocated on, and torch.cuda.Stream() walks a ring of 32 streams
+        side = self._cap_stream
         side.wait_stream(main)
-        pool = torch.cuda.graph_pool_handle()
+        # ONE private pool for every capture of this TrainStep: the graphs never run concurrently, so a later capture may reuse the
+        # blocks an evicted (or still cached) geometry's temporaries occupied.  A fresh pool per capture left every evicted graph's
+        # segments reserved-but-unusable until the allocator's out-of-memory sweep: +0.24 GiB per recapture at L ~ 4 000 when more
+        # lengths rotate than the LRU holds (tools/soak.py).
+        if self._pool is None or not (self._opt_graph is not None or any(e.segs for e in self._gcache.values())):
+            self._pool = torch.cuda.graph_pool_handle()      # (a pool dies with the last graph captured into it: take a fresh handle)
+        pool = self._pool
         segs = []
         with torch.cuda.stream(side):
             g = torch.cuda.CUDAGraph()          # (thread_local: RCCL's watchdog thread must not invalidate the capture)

@@ -578,6 +578,41 @@ def test_ragged_lengths_through_one_trainstep():
     eng.check_inputs()
 
 
+def test_graph_lru_thrash_keeps_reserved_memory_flat_and_losses_right():
+    """More bag lengths in rotation than the graph LRU holds: every step evicts one captured geometry and captures another.  All
+    captures share one memory pool, so the evicted graphs' memory is reused -- with a pool per capture the reserved memory grew by
+    one step's temporaries per recapture (tools/soak.py: +0.24 GiB per step at L ~ 4 000) -- and a geometry's replay after other
+    geometries were captured into the same pool still gives that slide's loss."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    seed, ngrids = 43, 64
+    sizes = synth.toy_group_sizes()
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)), slide_ngrids=ngrids)
+    sd = synth.synth_state_dict(cfg, sizes, seed)
+    lengths = [900, 333, 1200, 640, 1029]
+    slides = []
+    for L in lengths:
+        inp = synth.synth_inputs(L, sizes, seed + L, grid=ngrids)
+        slides.append((torch.from_numpy(inp["x"]).cuda().half().reshape(L, -1), torch.from_numpy(inp["coords"]).cuda(),
+                       [torch.from_numpy(a).cuda() for a in inp["genes"]], torch.from_numpy(inp["text"]).cuda()))
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(sd)
+    ts = TrainStep(eng, lr=0.0, weight_decay=0.0, capture_after=1, graph_cache_size=2)
+    ts.set_projector(synth.projector_state(seed))
+    want = [float(ts.step(*s, update=True)) for s in slides]                    # eager reference (lr 0: the weights never move)
+    rows, reserved = [], []
+    for rnd in range(8):
+        rows.append([float(ts.step_graphed(*s)) for s in slides])
+        torch.cuda.synchronize()
+        reserved.append(torch.cuda.memory_reserved())
+    for row in rows:
+        assert np.allclose(row, want, rtol=2e-4, atol=0), (row, want)
+    assert ts.graph_replays >= 5 * 6 and len(ts._graphs) <= 2                   # rounds 2.. recapture every step
+    assert reserved[-1] <= reserved[3] + (8 << 20), [r >> 20 for r in reserved]
+
+
 def test_lr_schedule_reaches_captured_graphs_and_eager_steps(golden_dir):
     """the learning rate is a device scalar.  The reference steps GradualWarmupScheduler + CosineAnnealingLR every
     epoch (TM:151-154,242): set_lr() between replays must change the update of an already captured graph."""
