@@ -49,10 +49,13 @@ class _StepGroup:
     the engine runs their backward nodes last-call-first and the FIRST call's node runs last; every node replays its tape into
     the same flat gradient buffer and only that last node hands the (unscaled) sum to autograd -- one zero / unscale / hand-over
     per step instead of one per call, and every parameter's AccumulateGrad (and DDP reducer hook) fires exactly once."""
-    __slots__ = ("key", "token", "count", "limit", "scale", "started", "share")
+    __slots__ = ("key", "count", "limit", "scale", "started", "share")
 
     def __init__(self, key, limit: int):
-        self.key, self.token, self.count, self.limit = key, None, 0, max(1, int(limit))
+        # (the chain token itself lives on the module, `_token`: a group is reachable from its calls' autograd nodes, and a token
+        # kept here would close a reference cycle node -> group -> token -> node that only the cyclic collector frees -- with it
+        # the calls' tapes and leased workspaces of several steps stayed alive at once)
+        self.key, self.count, self.limit = key, 0, max(1, int(limit))
         self.scale, self.started, self.share = None, False, {}
 
 
@@ -89,9 +92,12 @@ def _bridge_backward(ctx, dlogits):
             eng.grad_ready_hook = hook
     ctx.call = None                                                # the tape and its private workspace are dead from here
     if ctx.has_pred:       # an earlier call of the group runs after this node and delivers
+        ctx.group = None
         return torch.zeros((), dtype=F32, device=store.flat_grad.device), (None,) * nparams
     if module._group is grp:
-        module._group = None
+        module._group = module._token = None
+    ctx.group = None
+    grp.share.clear()                                              # (the slide's shared patch embedding and workspace leases)
     if not grp.started:
         return None, (None,) * nparams
     out = torch.empty_like(store.flat_grad)
@@ -142,7 +148,7 @@ class LongNetGeneAdapter(Aggregator):
         self._slots = [self.engine.store.slots[k] for k in self._trainable]      # (offset, numel, shape) in the flat buffers
         self._versions = None
         self.training_grad = True
-        self._group = None
+        self._group = self._token = None
         self._spec = self._hist = self._spec_rows = None      # speculative batching of the per-task calls (_forward_one_task)
         self.speculate = True                                 # (False: every call runs on its own; the calls of a step still share one hand-over)
         self.train(True)
@@ -152,15 +158,15 @@ class LongNetGeneAdapter(Aggregator):
         grad-mode calls on the same slide tensors, at most `multi_task` of them (what one step of the reference makes)."""
         key = _slide_key(x, coords)
         grp = self._group
-        if grp is not None and grp.key == key and grp.count < grp.limit and grp.token is not None:
-            return grp.token
-        self._group = _StepGroup(key, self.cfg.multi_task)
+        if grp is not None and grp.key == key and grp.count < grp.limit and self._token is not None:
+            return self._token
+        self._group, self._token = _StepGroup(key, self.cfg.multi_task), None
         return None
 
     def _close_call(self, need, out):
         logits, tok = out
         if need and self._group is not None:
-            self._group.token, self._group.count = tok, self._group.count + 1
+            self._token, self._group.count = tok, self._group.count + 1
         return logits
 
     def train(self, mode: bool = True):

@@ -80,6 +80,21 @@ class ParamStore:
         return Param(self.tensors[k], self.grads.get(k))
 
 
+class _Lease:
+    """Hands a fresh call's workspace store back to the engine's pool when the last holder (workspace dict, tape, share dict) dies."""
+    __slots__ = ("pool", "store")
+
+    def __init__(self, pool: list, store: dict):
+        self.pool, self.store = pool, store
+
+    def __del__(self):
+        try:
+            if len(self.pool) < 8:
+                self.pool.append(self.store)
+        except Exception:       # interpreter shutdown
+            pass
+
+
 QK_SCALE_LOG2 = 0.14433756729740643 * 1.4426950408889634      # 48^-1/2 * log2(e) (include/modaltune_hip.h: MT_QK_SCALE_LOG2)
 
 
@@ -165,6 +180,7 @@ class Engine:
         self.rng = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._drop_now = False
         self._fresh_calls, self._site_base = 0, 0
+        self._fresh_pool: Dict[int, list] = {}      # B -> free workspace stores of the module API's per-call workspaces
         dpr = np.linspace(0.0, float(cfg.drop_path_rate), cfg.depth) if cfg.depth > 1 else np.zeros(1)
         self._layer_path_p = [float(v) for v in dpr]          # ENC:37-41
 
@@ -284,7 +300,25 @@ class Engine:
             return n
 
         if fresh:
-            return {k: torch.empty(shape, dtype=dt, device=dev) for k, (dt, shape) in spec(L).items()}
+            # A private workspace, RECYCLED: exact-size allocations per call (every slide has its own length) fragment the caching
+            # allocator -- the reserved memory crept up by ~1 GiB per 100 slides under the reference loop (tools/soak_ragged.py).
+            # A call leases one flat store sized for the largest bag seen (grown by >= 25 %); the lease rides on the call's tape,
+            # on the slide's `share` dict and on the workspace itself, and hands the store back when the last of them is gone.
+            want = spec(L)
+            pool = self._fresh_pool.setdefault(B, [])
+            fit = [st for st in pool if st["cap"] >= L and all(k in st["flat"] for k in want)]
+            if fit:
+                store = min(fit, key=lambda st: st["cap"])
+                pool.remove(store)
+            else:
+                small = [st for st in pool if all(k in st["flat"] for k in want)]
+                cap = max([L] + [st["cap"] + st["cap"] // 4 for st in small])
+                if small:                       # replace the largest of the too-small stores instead of piling up
+                    pool.remove(max(small, key=lambda st: st["cap"]))
+                store = {"cap": cap, "flat": {k: torch.empty(numel(shape), dtype=dt, device=dev) for k, (dt, shape) in spec(cap).items()}}
+            w = {k: store["flat"][k][:numel(shape)].view(shape) for k, (dt, shape) in want.items()}
+            w["_lease"] = _Lease(pool, store)
+            return w
         store = self._ws_store.get(B)
         if store is None or L > store["cap"] or (self.stochastic and "x0d" not in store["flat"]):
             cap = L if store is None else max(L, store["cap"] + store["cap"] // 4)
@@ -359,6 +393,10 @@ class Engine:
         # arena captured graphs point into -- is put back before returning
         self.tape = Tape(self.device) if fresh else self._main_tape
         tape = self.tape
+        if fresh:
+            tape.lease = ws["_lease"]             # the backward closures read views of the leased store
+            if share is not None:
+                share.setdefault("_leases", []).append(ws["_lease"])      # (x0 of the first call serves the later calls of the slide)
         tape.grad_enabled = need_grad
         tape.reset()
         self._drop_now = bool(self.stochastic and need_grad)

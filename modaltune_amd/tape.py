@@ -65,6 +65,7 @@ class Tape:
         self.back: List[Callable[[], None]] = []
         self._ones = torch.ones(4096, device=device)
         self.grad_enabled = True
+        self.lease = None         # (Engine: keeps a recycled per-call workspace alive as long as this tape's closures may read it)
         # Zero-initialised gradient storage: one flat buffer cleared with ONE fill per step instead of a fill launch per
         # gradient (~150 per step).  It is sized from the demand of the previous step (the first step falls back to
         # individual fills); a captured step therefore must be preceded by two eager ones, which the trainer does.

@@ -833,7 +833,7 @@ class TITANGeneAdapter(LongNetGeneAdapter):
         self._slots = [self.engine.store.slots[k] for k in self._trainable]
         self._versions = None
         self.training_grad = True
-        self._group = None
+        self._group = self._token = None
         self._spec = self._hist = self._spec_rows = None
         self.speculate = True
         self._call_psz = 1024
