@@ -16,7 +16,22 @@ inp = synth.synth_inputs(Lmax, sizes, seed=1, grid=128)
 X = torch.from_numpy(inp["x"]).to(dev).half().reshape(Lmax, -1).contiguous(); C = torch.from_numpy(inp["coords"]).to(dev).reshape(-1, 2)
 genes = [torch.from_numpy(a).to(dev) for a in inp["genes"]]; text = torch.from_numpy(inp["text"]).to(dev)
 rss = lambda: resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20
-if mode == "trainstep":
+if mode == "titan":
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+    import titan_standin, bench
+    from modaltune_amd.titan import NativeBackbone, TitanEngine, titan_model_config
+    vit = titan_standin.VisionTransformer(mlp_ratio=4.0); titan_standin.init_standin(vit, 0)
+    tcfg = titan_model_config(bench.TITAN_JSON, 3, False, 6)
+    inp_t = synth.synth_inputs_titan(Lmax, sizes, seed=3, grid=96)
+    Xt = torch.from_numpy(inp_t["x"]).to(dev).reshape(Lmax, -1).contiguous(); Ct = torch.from_numpy(inp_t["coords"]).to(dev).reshape(Lmax, 2)
+    gt = [torch.from_numpy(a).to(dev) for a in inp_t["genes"]]; tt = torch.from_numpy(inp_t["text"]).to(dev)
+    eng = TitanEngine(tcfg, sizes, NativeBackbone(vit, dev), dev)
+    eng.load_state_dict(synth.synth_state_dict(tcfg, sizes, seed=0)); eng.set_stochastic(True, seed=3)
+    ts = TrainStep(eng); ts.set_projector(synth.projector_state(0))
+    def one(L):
+        return ts.step(Xt[:L], Ct[:L], gt, tt, update=True)
+    val = lambda: ts.loss_value()
+elif mode == "trainstep":
     eng = Engine(cfg, sizes, dev); eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed=0)); eng.set_stochastic(True, 7)
     ts = TrainStep(eng); ts.set_projector(synth.projector_state(0))
     def one(L):
