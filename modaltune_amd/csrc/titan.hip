@@ -52,29 +52,32 @@ __global__ __launch_bounds__(1024) void titan_grid_kernel(const float* __restric
 MT_DEVINL int cell_key(const int* cells, int i) { return (cells[2 * i] << 16) | cells[2 * i + 1]; }
 
 // Patches that share a cell form a chain in patch order: first[i] = no earlier patch has i's cell; next[i] = the next later
-// patch of the same cell (or -1).  One thread per patch, the keys of all patches streamed through LDS: O(L^2) integer compares
-// (L = 10^4: 10^8), no sort, no atomics -- the sums below come out in patch order, bitwise reproducible (index_add_ on the
-// CPU adds in that order).
-__global__ __launch_bounds__(256) void titan_chain_kernel(const int* __restrict__ cells, int L, int* __restrict__ first, int* __restrict__ next) {
-  __shared__ int keys[1024];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// patch of the same cell (or -1).  O(L^2) integer compares (L = 10^4: 10^8), no sort, no global atomics -- the sums below come out
+// in patch order, bitwise reproducible (index_add_ on the CPU adds in that order).  One workgroup = 64 patches (one per lane) x 16
+// waves, wave w scanning the w-th sixteenth of the keys (wave-uniform index: the keys come through the scalar cache); the sixteen
+// partial answers meet in LDS.  (One thread per patch scanning all L keys left 26 workgroups on the chip at L = 6 500: 220-350 us;
+// this form: L / 64 x 16 waves.)
+__global__ __launch_bounds__(1024) void titan_chain_kernel(const int* __restrict__ cells, int L, int* __restrict__ first, int* __restrict__ next) {
+  __shared__ int s_first[64], s_next[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   const int mine = i < L ? cell_key(cells, i) : -1;
+  if (wave == 0) { s_first[lane] = 1; s_next[lane] = 0x7fffffff; }
+  __syncthreads();
+  const int seg = (L + 15) / 16, j0 = __builtin_amdgcn_readfirstlane(wave * seg), j1 = min(L, j0 + seg);
   bool fst = true;
-  int nxt = -1;
-  for (int base = 0; base < L; base += 1024) {
-    __syncthreads();
-    for (int k = threadIdx.x; k < 1024; k += 256) keys[k] = base + k < L ? cell_key(cells, base + k) : -2;
-    __syncthreads();
-    const int n = min(1024, L - base);
-    for (int k = 0; k < n; ++k) {
-      const int j = base + k;
-      if (keys[k] == mine) {
-        if (j < i) fst = false;
-        else if (j > i && nxt < 0) nxt = j;
-      }
+  int nxt = 0x7fffffff;
+  for (int j = j0; j < j1; ++j) {
+    const int kj = cell_key(cells, j);          // uniform address
+    if (kj == mine) {
+      if (j < i) fst = false;
+      else if (j > i) nxt = min(nxt, j);
     }
   }
-  if (i < L) { first[i] = fst ? 1 : 0; next[i] = nxt; }
+  if (!fst) s_first[lane] = 0;                  // (racing stores of the same value)
+  if (nxt != 0x7fffffff) atomicMin(&s_next[lane], nxt);
+  __syncthreads();
+  if (wave == 0 && i < L) { first[i] = s_first[lane]; next[i] = s_next[lane] == 0x7fffffff ? -1 : s_next[lane]; }
 }
 
 // sums[i, :] = sum of the feature rows along i's chain (i the first patch of its cell), nz[i] = any(sum != 0): the reference's
@@ -299,7 +302,7 @@ extern "C" int mt_titan_cell_sums(const float* feat, long ldf, const int* cells,
                                   mt_stream_t stream) {
   if (!feat || !cells || !first || !next || !sums || !nz || L < 1 || C < 4 || (C & 3) || (ldf & 3)) return MT_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(titan_chain_kernel, dim3((L + 255) / 256), dim3(256), 0, s, cells, L, first, next);
+  hipLaunchKernelGGL(titan_chain_kernel, dim3((L + 63) / 64), dim3(1024), 0, s, cells, L, first, next);
   hipLaunchKernelGGL(titan_cell_sum_kernel, dim3(L), dim3(256), 0, s, feat, ldf, L, C, (const int*)first, (const int*)next, sums, nz);
   MT_CHECK_LAUNCH();
   return MT_OK;
