@@ -33,3 +33,33 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         _lib.load()
+
+
+_NULL_PROBE = r'''
+import sys
+sys.path.insert(0, %r)
+from modaltune_amd import _lib
+lib = _lib.load()
+for name, sig in _lib.SIGNATURES.items():
+    if name in ("mt_version", "mt_status_string", "mt_pool_attn_workspace_floats"):      # (plain value functions)
+        continue
+    args = [0 if t in (_lib.I, _lib.L) else 0.0 if t is _lib.F else None for t in sig]
+    print(name, getattr(lib, name)(*args), flush=True)
+'''
+
+
+def test_every_launcher_rejects_null_arguments_without_touching_the_device():
+    """Error convention (SURVEY §8b): launchers return a negative MtStatus, nothing crosses the C boundary as an exception or a
+    fault.  Every entry point called with null pointers and zero sizes -- in a child process, so a fault would fail this test and
+    not the runner -- answers MT_ERR_BAD_ARG / MT_ERR_UNSUPPORTED before any HIP call (there is no GPU here)."""
+    import subprocess
+    import sys
+    import __graft_entry__ as ge
+    ge.build()
+    p = subprocess.run([sys.executable, "-c", _NULL_PROBE % ROOT], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-400:] + p.stderr[-400:]
+    rows = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("mt_")]
+    from modaltune_amd import _lib
+    assert len(rows) == len(_lib.SIGNATURES) - 3
+    wrong = [(n, rc) for n, rc in rows if int(rc) >= 0]
+    assert not wrong, wrong
