@@ -54,6 +54,37 @@ def trainstep(rank, world, out):
              steps=int(ts.step_dev), buckets=len(ts.reducer.buckets))
 
 
+def ragged(rank, world, out):
+    """Ragged data-parallel steps: every rank walks the bag lengths in its OWN order with a two-entry graph LRU, so in the same
+    step one rank replays a captured geometry while another captures or runs eager -- the collectives must still pair up (same
+    buckets, same order) and every rank must end with the same weights."""
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    sizes = synth.toy_group_sizes()
+    cfg = _cfg()
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, SEED))
+    dp.broadcast_params_(eng.store.flat)
+    ts = TrainStep(eng, lr=1e-3, capture_after=1, graph_cache_size=2)
+    ts.set_projector(synth.projector_state(SEED))
+    lengths = [150, 97, 230, 150, 64, 97]
+    slides = {}
+    for Lx in set(lengths):
+        inp = synth.synth_inputs(Lx, sizes, seed=700 + 31 * rank + Lx, grid=NGRIDS)
+        slides[Lx] = (torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda(), [torch.from_numpy(a).cuda() for a in inp["genes"]],
+                      torch.from_numpy(inp["text"]).cuda())
+    losses, modes = [], []
+    for i in range(18):
+        Lx = lengths[(i + 2 * rank) % len(lengths)] if i % 5 != 4 or rank == 0 else lengths[(i * 3 + 1) % len(lengths)]
+        before = ts.graph_replays
+        losses.append(float(ts.step_graphed(*slides[Lx])))
+        modes.append(int(ts.graph_replays > before))
+    sd = eng.store.state_dict()
+    torch.cuda.synchronize()
+    np.savez(out, flat=eng.store.flat.cpu().numpy(), losses=np.array(losses), modes=np.array(modes), steps=int(ts.step_dev),
+             sharded=int(ts.reducer.sharded), keys=len(sd))
+
+
 def ddp_module(rank, world, out):
     """The reference's own multi-GPU form (utils/base_trainer.py:205-211): DistributedDataParallel around the nn.Module,
     3 forward calls, loss.backward().  Dumps the local (unwrapped) gradients and the DDP-averaged ones."""
@@ -104,6 +135,6 @@ if __name__ == "__main__":
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        {"trainstep": trainstep, "ddp_module": ddp_module}[mode](rank, world, out)
+        {"trainstep": trainstep, "ddp_module": ddp_module, "ragged": ragged}[mode](rank, world, out)
     finally:
         dist.destroy_process_group()

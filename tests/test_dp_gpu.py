@@ -62,6 +62,24 @@ def test_two_rank_trainstep_matches_gradient_averaging(tmp_path):
     _check_trainstep(_run_ranks("trainstep", tmp_path))
 
 
+def _check_ragged(res):
+    assert all(int(r["sharded"]) == 1 and int(r["steps"]) == 18 for r in res)
+    assert np.isfinite(res[0]["losses"]).all() and np.isfinite(res[1]["losses"]).all()
+    assert (res[0]["modes"] != res[1]["modes"]).any(), "the ranks never disagreed on replay vs capture / eager: the test lost its point"
+    assert np.array_equal(res[0]["flat"], res[1]["flat"])          # same averaged gradients, same updates: bit-identical weights
+
+
+def test_two_rank_ragged_steps_with_rank_local_capture_decisions(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _check_ragged(_run_ranks("ragged", tmp_path))
+
+
+def test_two_rank_ragged_steps_over_rccl(tmp_path):
+    _need_gpus(2)
+    _check_ragged(_run_ranks("ragged", tmp_path, backend="nccl"))
+
+
 def test_two_rank_trainstep_over_rccl(tmp_path):
     """(a) over RCCL, one rank per GPU: GradReducer's async collectives between segmented hipGraph replays on RCCL's stream."""
     _need_gpus(2)
