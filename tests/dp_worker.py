@@ -85,6 +85,36 @@ def ragged(rank, world, out):
              sharded=int(ts.reducer.sharded), keys=len(sd))
 
 
+def titan(rank, world, out):
+    """The TITAN configuration under the data-parallel TrainStep (eager schedule: every slide has its own token count): bucketed
+    collectives from inside the backward through the native ViT blocks, sharded last bucket; the ranks end bit-identical."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import titan_standin
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_titan_cpu import TITAN_JSON
+    from modaltune_amd.titan import NativeBackbone, TitanEngine, titan_model_config
+    from modaltune_amd.trainer import TrainStep
+    sizes = synth.toy_group_sizes()
+    vit = titan_standin.VisionTransformer()
+    titan_standin.init_standin(vit, SEED)
+    cfg = titan_model_config(TITAN_JSON, 3, False, len(sizes))
+    eng = TitanEngine(cfg, sizes, NativeBackbone(vit, "cuda"), "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, SEED))
+    dp.broadcast_params_(eng.store.flat)
+    ts = TrainStep(eng, lr=1e-3)
+    ts.set_projector(synth.projector_state(SEED))
+    losses = []
+    for i in range(5):
+        Lx = 220 + 40 * ((i + rank) % 3)
+        inp = synth.synth_inputs_titan(Lx, sizes, seed=300 + 17 * rank + i, grid=24)
+        losses.append(float(ts.step(torch.from_numpy(inp["x"]).cuda().reshape(Lx, -1), torch.from_numpy(inp["coords"]).cuda().reshape(Lx, 2),
+                                    [torch.from_numpy(a).cuda() for a in inp["genes"]], torch.from_numpy(inp["text"]).cuda(), update=True)))
+    eng.store.state_dict()
+    torch.cuda.synchronize()
+    np.savez(out, flat=eng.store.flat.cpu().numpy(), losses=np.array(losses), steps=int(ts.step_dev), sharded=int(ts.reducer.sharded),
+             impl=eng.backbone.kind)
+
+
 def ddp_module(rank, world, out):
     """The reference's own multi-GPU form (utils/base_trainer.py:205-211): DistributedDataParallel around the nn.Module,
     3 forward calls, loss.backward().  Dumps the local (unwrapped) gradients and the DDP-averaged ones."""
@@ -135,6 +165,6 @@ if __name__ == "__main__":
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        {"trainstep": trainstep, "ddp_module": ddp_module, "ragged": ragged}[mode](rank, world, out)
+        {"trainstep": trainstep, "ddp_module": ddp_module, "ragged": ragged, "titan": titan}[mode](rank, world, out)
     finally:
         dist.destroy_process_group()

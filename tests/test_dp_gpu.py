@@ -80,6 +80,16 @@ def test_two_rank_ragged_steps_over_rccl(tmp_path):
     _check_ragged(_run_ranks("ragged", tmp_path, backend="nccl"))
 
 
+def test_two_rank_titan_trainstep(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    res = _run_ranks("titan", tmp_path)
+    assert all(int(r["sharded"]) == 1 and int(r["steps"]) == 5 and str(r["impl"]) == "native" for r in res)
+    assert np.isfinite(res[0]["losses"]).all() and np.isfinite(res[1]["losses"]).all()
+    assert np.array_equal(res[0]["flat"], res[1]["flat"])
+    assert not np.array_equal(res[0]["losses"], res[1]["losses"])      # (different slides per rank)
+
+
 def test_two_rank_trainstep_over_rccl(tmp_path):
     """(a) over RCCL, one rank per GPU: GradReducer's async collectives between segmented hipGraph replays on RCCL's stream."""
     _need_gpus(2)
