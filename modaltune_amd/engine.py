@@ -180,6 +180,7 @@ class Engine:
         self.rng = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._drop_now = False
         self._fresh_calls, self._site_base = 0, 0
+        self._fresh_tick = 0
         self._fresh_pool: Dict[int, list] = {}      # B -> free workspace stores of the module API's per-call workspaces
         dpr = np.linspace(0.0, float(cfg.drop_path_rate), cfg.depth) if cfg.depth > 1 else np.zeros(1)
         self._layer_path_p = [float(v) for v in dpr]          # ENC:37-41
@@ -305,7 +306,10 @@ class Engine:
             # A call leases one flat store sized for the largest bag seen (grown by >= 25 %); the lease rides on the call's tape,
             # on the slide's `share` dict and on the workspace itself, and hands the store back when the last of them is gone.
             want = spec(L)
-            pool = self._fresh_pool.setdefault(B, [])
+            self._fresh_tick += 1
+            for pl in self._fresh_pool.values():          # stores nobody asked for in the last 64 calls go back to the allocator
+                pl[:] = [st for st in pl if self._fresh_tick - st.get("tick", 0) <= 64]      # (e.g. the B = 1 stores of the step that
+            pool = self._fresh_pool.setdefault(B, [])                                          # taught the speculative batching its rows)
             fit = [st for st in pool if st["cap"] >= L and all(k in st["flat"] for k in want)]
             if fit:
                 store = min(fit, key=lambda st: st["cap"])
@@ -316,6 +320,7 @@ class Engine:
                 if small:                       # replace the largest of the too-small stores instead of piling up
                     pool.remove(max(small, key=lambda st: st["cap"]))
                 store = {"cap": cap, "flat": {k: torch.empty(numel(shape), dtype=dt, device=dev) for k, (dt, shape) in spec(cap).items()}}
+            store["tick"] = self._fresh_tick
             w = {k: store["flat"][k][:numel(shape)].view(shape) for k, (dt, shape) in want.items()}
             w["_lease"] = _Lease(pool, store)
             return w
