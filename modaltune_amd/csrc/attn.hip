@@ -457,8 +457,10 @@ __global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __re
   const h16* const vseq = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
   const DmaLane dl(tid, row_bytes);
   auto dma = [&](int t) {
-    dma_tile(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), dl);
-    dma_tile(Vs + (t & 1) * IMG_HALVES, tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl);
+    // (both images of a tile under one exec mask per piece, wave-uniform LDS destinations: dQ -1.6 %; the same form is
+    // neutral in the forward and costs the dK/dV kernel 2 %, so those keep the two-call form)
+    dma_tile_pair(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), Vs + (t & 1) * IMG_HALVES,
+                  tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl, __builtin_amdgcn_readfirstlane(tid >> 6));
   };
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   int rrd[3];

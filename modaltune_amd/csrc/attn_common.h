@@ -252,6 +252,18 @@ MT_DEVINL void dma_tile(h16* img, __amdgpu_buffer_rsrc_t rs, const DmaLane& d) {
     if (d.act[i])
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + d.lds_halves[i]), 16, d.voff[i], 0, 0, 0);
 }
+// The two images of a tile (K | V, Q | dO) in one go: piece i of BOTH images under ONE exec mask (two masked blocks per tile
+// instead of four), the LDS destinations wave-uniform (`wave_u` = readfirstlane(tid >> 6): the M0 setup of a piece is then a
+// scalar add, not a VALU add + v_readfirstlane + wait state).
+MT_DEVINL void dma_tile_pair(h16* img_a, __amdgpu_buffer_rsrc_t ra, h16* img_b, __amdgpu_buffer_rsrc_t rb, const DmaLane& d, int wave_u) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (d.act[i]) {
+      const int off = (2 * wave_u + i) * 512;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(img_a + off), 16, d.voff[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(img_b + off), 16, d.voff[i], 0, 0, 0);
+    }
+}
 MT_DEVINL void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Per-thread staging slots of a 64-row x 48-col fp16 tile = 384 chunks of 16 B.
