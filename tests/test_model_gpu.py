@@ -613,6 +613,39 @@ def test_graph_lru_thrash_keeps_reserved_memory_flat_and_losses_right():
     assert reserved[-1] <= reserved[3] + (8 << 20), [r >> 20 for r in reserved]
 
 
+def test_module_api_recycles_its_per_call_workspaces():
+    """The reference loop on the drop-in module over never-repeating bag lengths: every call leases its workspace from the engine's
+    pool and the lease comes back when the step's backward has run (no reference cycle keeps a step's tapes alive, no exact-size
+    allocations per call) -- the allocated device memory at the end of a step stops moving after the first steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    seed, ngrids = 47, 64
+    sizes = synth.toy_group_sizes()
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, depth=3, slide_ngrids=ngrids,
+                              interaction_indexes=[[0, 0], [1, 1], [2, 2]], multi_task=3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(model.cfg, sizes, seed).items()}, strict=True)
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    inp = synth.synth_inputs(1400, sizes, seed, grid=ngrids)
+    X, C = torch.from_numpy(inp["x"]).cuda().reshape(1400, -1), torch.from_numpy(inp["coords"]).cuda().reshape(1400, 2)
+    genes = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    eye = torch.eye(3, device="cuda")
+    alloc = []
+    for i, L in enumerate([700, 1333, 410, 1200, 999, 640, 1400, 520, 1111, 860, 777, 1250]):
+        x, c = X[:L].unsqueeze(0), C[:L].unsqueeze(0)
+        logits = torch.cat([model(x=x, coords=c, genes=genes, task_token=eye[t]) for t in range(3)])
+        logits.square().sum().backward()
+        opt.step()
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        alloc.append(torch.cuda.memory_allocated())
+        pool = model.engine._fresh_pool
+        assert sum(len(v) for v in pool.values()) <= 5, {b: len(v) for b, v in pool.items()}
+    assert max(alloc[7:]) <= max(alloc[3:7]) + (32 << 20), [a >> 20 for a in alloc]
+
+
 def test_lr_schedule_reaches_captured_graphs_and_eager_steps(golden_dir):
     """the learning rate is a device scalar.  The reference steps GradualWarmupScheduler + CosineAnnealingLR every
     epoch (TM:151-154,242): set_lr() between replays must change the update of an already captured graph."""
