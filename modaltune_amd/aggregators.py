@@ -18,7 +18,7 @@ from typing import Any, Dict, Iterator, Sequence, Tuple
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import init, ops
 from .config import ModelConfig
 from .engine import Engine, F32
 
@@ -67,15 +67,20 @@ def _slide_key(x, coords):
 
 def _bridge_backward(ctx, dlogits):
     """Shared by the LongNet and TITAN bridges: returns (gradient of the chain token input or None, tuple of parameter
-    gradients or Nones)."""
+    gradients or Nones).  A node reached WITHOUT a gradient for its logits (only the chain token's) passes the chain on and keeps
+    its tape: a trainer that backpropagates the task losses one by one (`loss_t.backward()` per task instead of the reference's
+    single `loss.backward()`) meets the node again later with its own gradient, and every such pass hands over exactly what it
+    replayed (param.grad accumulates across the passes as with any module)."""
     module, eng, grp = ctx.module, ctx.module.engine, ctx.group
     store = eng.store
     nparams = len(module._slots)
-    if ctx.call is None:
-        raise RuntimeError("backward through a forward that ran with gradients disabled (or a second backward through the same call)")
     if dlogits is not None:
+        if ctx.call is None:
+            raise RuntimeError("backward through a forward that ran with gradients disabled (or a second backward through the same call"
+                               + ("; the task passes of this slide were batched into ONE call -- set model.speculate = False to "
+                                  "backpropagate the task losses one by one" if ctx.batched else "") + ")")
         # The tape runs an fp16 activation-gradient stream: rescale the incoming gradients to max |.| = 2^10 on the DEVICE (no
-        # read-back; the factor of a group's first backward serves the whole group), run the tapes, undo the scale once when
+        # read-back; the factor of a pass's first node serves the whole pass), run the tapes, undo the scale once when
         # the flat gradient is handed over.
         dl = dlogits.to(F32).contiguous()
         if not grp.started:
@@ -90,13 +95,11 @@ def _bridge_backward(ctx, dlogits):
             eng.backward(scaled, call=ctx.call)
         finally:
             eng.grad_ready_hook = hook
-    ctx.call = None                                                # the tape and its private workspace are dead from here
+        ctx.call = None                                            # the tape and its private workspace are dead from here
     if ctx.has_pred:       # an earlier call of the group runs after this node and delivers
-        ctx.group = None
         return torch.zeros((), dtype=F32, device=store.flat_grad.device), (None,) * nparams
     if module._group is grp:
         module._group = module._token = None
-    ctx.group = None
     grp.share.clear()                                              # (the slide's shared patch embedding and workspace leases)
     if not grp.started:
         return None, (None,) * nparams
@@ -121,6 +124,7 @@ class _ModelFn(torch.autograd.Function):
         logits = eng.forward(x, coords, genes, onehots, need_grad=need, fresh=need, clinical=clinical,
                              share=grp.share if grp is not None else None)
         ctx.module, ctx.call, ctx.group, ctx.has_pred = module, (eng.last_call if need else None), grp, token is not None
+        ctx.batched = module.is_multi and logits.shape[0] > 1
         return logits.clone(), torch.zeros((), dtype=F32, device=logits.device)
 
     @staticmethod
@@ -134,13 +138,24 @@ class LongNetGeneAdapter(Aggregator):
     """LongNet-ViT + Modal Adapter (reference LongNetGeneAdapter, longvit_adapter.py:30-347) on the HIP engine."""
     CLINICAL = False
 
-    def __init__(self, gene_group_defination: Dict[Any, Sequence[str]] = None, multi_task: int = 1, device="cuda", **kwargs):
+    def __init__(self, gene_group_defination: Dict[Any, Sequence[str]] = None, multi_task: int = 1, device="cuda",
+                 weights_location: str = None, init_seed: int = None, **kwargs):
         super().__init__()
         gene_group_defination = gene_group_defination or {}
         cfg = ModelConfig.from_json(kwargs, multi_task=multi_task, clinical=self.CLINICAL)
         self.cfg = cfg
         self.is_multi = multi_task > 1                       # longvit_adapter.py:88 (read at TM:174)
-        self.engine = Engine(cfg, [len(v) for v in gene_group_defination.values()], device)
+        sizes = [len(v) for v in gene_group_defination.values()]
+        self.engine = Engine(cfg, sizes, device)
+        # The reference's constructor leaves a TRAINABLE model behind (longvit_adapter.py:162,176-203: every adapter / gene / head
+        # module initialised, gamma = init_values) on a backbone loaded from {GIGAPATH_WEIGHT_LOC}/slide_encoder.pth when
+        # `pretrained` (longvit_adapter.py:75-77; a missing file warns and keeps the random init, slide_encoder.py:317-322).
+        # `weights_location` / $GIGAPATH_WEIGHT_LOC override the reference's constant; `init_seed` None = one draw from torch's
+        # global RNG, i.e. torch.manual_seed() in front of the constructor fixes the model as it does for the reference.
+        state = init.init_state_dict(cfg, sizes, init_seed)
+        frozen = [k for k, _, _, train in self.engine.store.specs if not train]
+        self.pretrained_report = init.load_slide_encoder(state, frozen, cfg.pretrained, weights_location)
+        self.engine.load_state_dict(state)
         self._params: "OrderedDict[str, nn.Parameter]" = OrderedDict()
         for k, shape, kind, train in self.engine.store.specs:
             self._params[k] = nn.Parameter(self.engine.store.tensors[k], requires_grad=bool(train))
@@ -262,13 +277,16 @@ class LongNetGeneAdapter(Aggregator):
             if hist is not None:
                 r = hist["rows"]
                 self._spec_rows = list(r) if (len(r) >= 2 and len(set(r)) == len(r)) else None
-            self._hist = {"key": key, "rows": [row]}
+            # (`hold`: the keyed objects stay alive as long as the key is compared against, so neither the caching allocator nor
+            # CPython can hand their addresses / ids to another slide's tensors)
+            hold = (x, coords, genes, clinical)
+            self._hist = {"key": key, "rows": [row], "hold": hold}
             self._spec = None
             rows = self._spec_rows
             if rows and row == rows[0]:
                 eye = torch.eye(self.cfg.multi_task, dtype=F32, device=self.engine.device)[rows]
                 logits = self.forward_tasks(x, coords, genes, eye, clinical=clinical)
-                self._spec = {"key": key, "rows": rows, "used": {row}, "logits": logits}
+                self._spec = {"key": key, "rows": rows, "used": {row}, "logits": logits, "hold": hold}
                 return logits[0:1]
         return self.forward_tasks(x, coords, genes, onehot, clinical=clinical)
 

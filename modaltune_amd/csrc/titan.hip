@@ -32,7 +32,7 @@ __global__ __launch_bounds__(1024) void titan_grid_kernel(const float* __restric
   int g0m = 0, g1m = 0;
   for (int i = tid; i < L; i += 1024) {
     const float f0 = floorf((coords[2 * i] - m0) / patch), f1 = floorf((coords[2 * i + 1] - m1) / patch);
-    const bool ok = f0 >= 0.f && f1 >= 0.f && f0 < 65536.f && f1 < 65536.f;
+    const bool ok = f0 >= 0.f && f1 >= 0.f && f0 < 32768.f && f1 < 32768.f;      // cell_key = (row << 16) | col stays a non-negative int, disjoint from the -1 / 0x7fffffff sentinels
     bad |= !ok;
     const int g0 = ok ? (int)f0 : 0, g1 = ok ? (int)f1 : 0;
     cells[2 * i] = g0; cells[2 * i + 1] = g1;

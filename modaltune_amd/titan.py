@@ -34,7 +34,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import init, ops
 from .aggregators import Aggregator, LongNetGeneAdapter, _bridge_backward
 from .config import ModelConfig
 from .engine import Engine, F32, H16, _W16
@@ -238,6 +238,12 @@ class NativeBackbone:
         if not blocks:
             raise Unsupported("no blocks")
         self.depth = len(blocks)
+        # The native blocks are deterministic; the reference keeps the frozen backbone's stochastic layers alive in train mode
+        # (SURVEY fact 3).  A module that HAS such layers with p > 0 is not what the kernels implement.
+        for nm, m in vit.named_modules():
+            p = getattr(m, "p", None) if isinstance(m, (nn.Dropout, nn.AlphaDropout)) else getattr(m, "drop_prob", None)
+            if isinstance(p, (int, float)) and p > 0:
+                raise Unsupported(f"{nm}: {type(m).__name__}(p = {p}) inside the backbone (the native blocks have no stochastic layers)")
         D = None
         self.blocks: List[dict] = []
         for l, blk in enumerate(blocks):
@@ -296,7 +302,12 @@ class NativeBackbone:
         self.report: Dict[str, Any] = {"blocks": "native", "embed": "native" if self.embed_w else "torch",
                                        "pool": "native" if self.pool_w else "torch"}
         if self_check:
-            self._self_check()
+            was_training = vit.training
+            vit.eval()                      # the probe compares against the module's DETERMINISTIC arithmetic
+            try:
+                self._self_check()
+            finally:
+                vit.train(was_training)
 
     # -- structure discovery
     def _derive_slopes(self) -> torch.Tensor:
@@ -812,9 +823,22 @@ class TITANGeneAdapter(LongNetGeneAdapter):
     CLINICAL = False
 
     def __init__(self, gene_group_defination: Dict[Any, Sequence[str]] = None, multi_task: int = 1, backbone: Optional[nn.Module] = None,
-                 device="cuda", backbone_impl: str = "auto", **kwargs):
+                 device="cuda", backbone_impl: str = "auto", init_seed: Optional[int] = None, **kwargs):
         nn.Module.__init__(self)
         gene_group_defination = gene_group_defination or {}
+        self.backbone_source = "backbone= argument"
+        if backbone is None:
+            # The reference IS the snapshot's VisionTransformer (TA:42: it inherits from it): it imports the class from
+            # TITAN_CODE_PATH / TITAN_SNAPSHOT_ID, builds it from TitanConfig().vision_config and loads model.safetensors when
+            # `pretrained` (TA:16-37,88-107,233-247).  Same route here ($TITAN_CODE_PATH / $TITAN_SNAPSHOT_ID override the
+            # reference's constants); `backbone=` is the extra door for a module the caller already holds.
+            try:
+                backbone = init.build_titan_backbone(bool(kwargs.get("pretrained", True)), device)
+                self.backbone_source = "TITAN snapshot package"
+            except (ImportError, FileNotFoundError) as e:
+                warnings.warn(f"titan_gene_adapter: no slide encoder attached -- {e}.  The adapter side is initialised; forward() raises "
+                              f"until a backbone is given.")
+                self.backbone_source = None
         depth = len(backbone.blocks.modules_list) if backbone is not None else 6
         cfg = titan_model_config(kwargs, multi_task, self.CLINICAL, depth)
         self.cfg = cfg
@@ -823,7 +847,10 @@ class TITANGeneAdapter(LongNetGeneAdapter):
             backbone = backbone.to(device)
         object.__setattr__(self, "_backbone_module", backbone)
         object.__setattr__(self, "_backbone_impl_req", backbone_impl)
-        self.engine = TitanEngine(cfg, [len(v) for v in gene_group_defination.values()], None, device)
+        sizes = [len(v) for v in gene_group_defination.values()]
+        self.engine = TitanEngine(cfg, sizes, None, device)
+        # trainable side initialised as the reference's constructor leaves it (TA:195-203: same families as the LongNet adapter)
+        self.engine.load_state_dict(init.init_state_dict(cfg, sizes, init_seed, trainable_only=True), strict=False)
         self._rebuild_backbone()
         self._params = OrderedDict()
         for k, shape, kind, train in self.engine.store.specs:
@@ -838,6 +865,15 @@ class TITANGeneAdapter(LongNetGeneAdapter):
         self.speculate = True
         self._call_psz = 1024
         self.train(True)
+
+    def train(self, mode: bool = True):
+        """The reference adapter IS the backbone module (TA:42), so model.train() / .eval() reach its blocks; here the module is
+        held outside nn.Module's registry, so the mode is forwarded by hand (it matters to the TorchBackbone path)."""
+        super().train(mode)
+        bb = getattr(self, "_backbone_module", None)
+        if bb is not None:
+            bb.train(mode)
+        return self
 
     def _rebuild_backbone(self):
         """(Re)derive the backbone implementation from the module's CURRENT weights (the fp16 caches of the native path are
@@ -918,6 +954,7 @@ class _TitanFn(torch.autograd.Function):
         logits = eng.forward_slide(x, coords, genes, onehots, patch_size_lv0=psz, need_grad=need, fresh=need, clinical=clinical,
                                    share=grp.share if grp is not None else None)
         ctx.module, ctx.call, ctx.group, ctx.has_pred = module, (eng.last_call if need else None), grp, token is not None
+        ctx.batched = module.is_multi and logits.shape[0] > 1
         return logits.clone(), torch.zeros((), dtype=F32, device=logits.device)
 
     @staticmethod

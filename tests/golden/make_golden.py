@@ -415,6 +415,53 @@ def titan_case(name, L, seed, clinical=False, grid=24):
     np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
 
 
+def init_case():
+    """What the REFERENCE's constructor leaves behind (longvit_adapter.py:75-77,162,176-203): per state_dict key the mean / std /
+    min / max of a fresh model (both registry names, the shipped JSON with depth / ngrids reduced), and the outcome of its
+    `pretrained=True` path on a slide_encoder.pth we write (synth backbone weights + one unexpected key, one key left out):
+    which keys end up equal to the file.  The statistics pin modaltune_amd/init.py's families; no weights are stored."""
+    import tempfile
+    import models.aggregators.longvit_adapter as LVA
+    out = {}
+    sizes = synth.toy_group_sizes(6)
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    for name, clinical in (("longnetvit_gene_adapter", False), ("longnetvit_gene_clinical_adapter", True)):
+        cfg_kw = dict(REF_CFG)
+        cfg_kw.update(slide_ngrids=128, pretrained=False)
+        torch.manual_seed(0)
+        model = Aggregator.create(name, gene_group_defination=groups, **cfg_kw, multi_task=3)
+        stats = {}
+        for k, v in model.state_dict().items():
+            v = v.double()
+            stats[k] = [float(v.mean()), float(v.std()) if v.numel() > 1 else 0.0, float(v.min()), float(v.max()), int(v.numel())]
+        out[name] = {"stats": stats, "trainable": [k for k, p in model.named_parameters() if p.requires_grad]}
+    # pretrained=True against a file
+    cfg_kw = dict(REF_CFG)
+    cfg_kw.update(slide_ngrids=128, pretrained=True)
+    cfg = ModelConfig.from_json(cfg_kw, multi_task=3)
+    sd = synth.synth_state_dict(cfg, sizes, 31)
+    frozen = [k for k, _, _, t in synth.param_specs(cfg, sizes) if not t]
+    left_out = "encoder.layers.3.ffn.fc1.bias"
+    with tempfile.TemporaryDirectory() as d:
+        blob = {k: tt(sd[k], torch.float32) for k in frozen if k != left_out}
+        blob["some.unexpected.key"] = torch.zeros(3)
+        torch.save({"model": blob}, os.path.join(d, "slide_encoder.pth"))
+        old = LVA.GIGAPATH_WEIGHT_LOC
+        LVA.GIGAPATH_WEIGHT_LOC = d
+        try:
+            torch.manual_seed(0)
+            model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, **cfg_kw, multi_task=3)
+        finally:
+            LVA.GIGAPATH_WEIGHT_LOC = old
+    msd = model.state_dict()
+    out["pretrained"] = {"seed": 31, "left_out": left_out,
+                         "equal_to_file": [k for k in frozen if k != left_out and bool((msd[k] == tt(sd[k], torch.float32)).all())],
+                         "left_out_equals_file": bool((msd[left_out] == tt(sd[left_out], torch.float32)).all()),
+                         "requires_grad_frozen": sorted({bool(p.requires_grad) for k, p in model.named_parameters() if k in set(frozen)})}
+    json.dump(out, open(os.path.join(HERE, "init_stats.json"), "w"))
+    print("wrote init_stats.json:", {k: len(v.get("stats", v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["adapter", "layer", "gene", "m37", "m1500", "m512", "clin"]
@@ -422,6 +469,8 @@ if __name__ == "__main__":
         model_case("L37_d3_clin", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=14, clinical=True)
         model_case("L37_d3_clin_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=15, clinical=True, token_agg="cat")
         model_case("L37_d3_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=16, token_agg="cat")
+    if "init" in which:    # constructor-time state of the reference (init families, pretrained loading)
+        init_case()
     if "titan" in which:   # TITAN configuration (BASELINE config 4 family) on the stand-in backbone
         titan_case("titan_L300", 300, seed=21)
         titan_case("titan_L170_clin", 170, seed=22, clinical=True, grid=16)

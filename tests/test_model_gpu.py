@@ -732,3 +732,104 @@ def test_captured_graphs_are_retired_when_their_buffers_move(golden_dir):
         def forward_tasks(self, x, coords, genes, onehots, clinical=None):
             return onehots
     assert multitask_forward(_M(), task_ids=None, x=0, coords=0, genes=0).shape == (3, 3)
+
+
+def test_fresh_constructor_trains_under_the_reference_loop(tmp_path, monkeypatch):
+    """SURVEY §8b "train_modaltune.py drops them in": Aggregator.create with the SHIPPED JSON unmodified (pretrained: true ->
+    {GIGAPATH_WEIGHT_LOC}/slide_encoder.pth, written here from synth) and NO load_state_dict, driven by the reference trainer's own
+    loop (TM:123-149,195-240: 3 model calls under autocast, KL loss, GradScaler, torch.optim.AdamW): finite, decreasing loss."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from modaltune_amd.aggregators import Aggregator
+    from test_init_cpu import SHIPPED_JSON
+    sizes = synth.toy_group_sizes(6)
+    groups = {i: ["g%d_%d" % (i, j) for j in range(n)] for i, n in enumerate(sizes)}
+    cfg = ModelConfig.from_json(SHIPPED_JSON, multi_task=3)
+    sd = synth.synth_state_dict(cfg, sizes, 41)
+    frozen = [k for k, _, _, t in synth.param_specs(cfg, sizes) if not t]
+    torch.save({"model": {k: torch.from_numpy(sd[k]) for k in frozen}}, tmp_path / "slide_encoder.pth")
+    monkeypatch.setenv("GIGAPATH_WEIGHT_LOC", str(tmp_path))
+    torch.manual_seed(0)
+    model = Aggregator.create(subclass_name="longnetvit_gene_adapter", gene_group_defination=groups, **SHIPPED_JSON, multi_task=3).to("cuda")
+    assert model.pretrained_report == ([], [])
+    msd = model.state_dict()
+    assert torch.equal(msd["encoder.layers.11.ffn.fc2.weight"].cpu(), torch.from_numpy(sd["encoder.layers.11.ffn.fc2.weight"]))
+    params = [{"params": list(filter(lambda p: p.requires_grad, model.parameters())), "lr": 1e-3}]         # TM:139-149 (lr raised: 4 steps)
+    opt = torch.optim.AdamW(params, weight_decay=0.01, betas=(0.9, 0.999))
+    scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=2.0 ** 15)                              # TM:107
+    inp = synth.synth_inputs(700, sizes, 5, grid=128)
+    images, coords = torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda()
+    gene_data = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    text = torch.from_numpy(inp["text"]).cuda()[:, :256]
+    text = text / text.norm(dim=-1, keepdim=True)
+    loss_fn, eye = nn.KLDivLoss(reduction="sum"), torch.eye(3).cuda()
+    model.train()
+    losses = []
+    for _ in range(4):
+        with torch.autocast("cuda", enabled=True):
+            logit = torch.cat([model(x=images, coords=coords, genes=gene_data, clinical=[], task_token=eye[t]) for t in (0, 1, 2)], dim=0)
+            logit = logit / logit.norm(dim=-1, keepdim=True)
+            loss = loss_fn(F.log_softmax(logit, dim=1), F.softmax(text[[0, 1, 3], :], dim=1)) * 10
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(v) for v in losses), losses
+    assert losses[-1] < losses[0] and losses[1] < losses[0], losses
+    # gamma left its init (0): the Injector path receives gradients from the first step on (adapter_modules.py:357,367)
+    assert float(model.state_dict()["interactions.0.injector.gamma"].abs().max()) > 0
+
+
+def test_three_forwards_then_three_separate_backwards(golden_dir):
+    """A trainer that backpropagates the task losses one by one (not the reference's single loss.backward()): every pass hands
+    over exactly what it replayed and param.grad accumulates, as with independent calls."""
+    from modaltune_amd.aggregators import Aggregator
+    g = np.load(os.path.join(golden_dir, "model_L37_d3.npz"))
+    L, seed, ngrids = int(g["L"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, depth=3, slide_ngrids=ngrids, pretrained=False,
+                              interaction_indexes=[[0, 0], [1, 1], [2, 2]], dropout=0.0, drop_path_rate=0.0, multi_task=3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(model.cfg, sizes, seed).items()}, strict=True)
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    x, coords = torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda()
+    genes = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    w = torch.randn(3, 256, generator=torch.Generator().manual_seed(1)).cuda()
+    eye = torch.eye(3).cuda()
+    model.train()
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    params = dict(model.named_parameters())
+
+    def grads():
+        torch.cuda.synchronize()
+        out = torch.cat([(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).reshape(-1).double() for k in names])
+        for k in names:
+            params[k].grad = None
+        return out
+
+    model.speculate = False
+    for _ in range(2):
+        ys = [model(x=x, coords=coords, genes=genes, clinical=[], task_token=eye[t]) for t in (0, 1, 2)]
+        sum((y * w[t]).sum() for t, y in enumerate(ys)).backward()
+        ref = grads()
+        ys = [model(x=x, coords=coords, genes=genes, clinical=[], task_token=eye[t]) for t in (0, 1, 2)]
+        for t in (2, 0, 1):                    # any order, one backward per task
+            (ys[t] * w[t]).sum().backward(retain_graph=True)
+        got = grads()
+        assert float((got - ref).norm() / ref.norm()) < 2e-2
+        with pytest.raises(RuntimeError, match="second backward"):
+            (ys[1] * w[1]).sum().backward()
+        grads()
+    # speculative batching answers the three calls with ONE engine pass: its single tape serves a single backward, and the
+    # error says how to run per-task backwards
+    model.speculate = True
+    for _ in range(2):
+        ys = [model(x=x, coords=coords, genes=genes, clinical=[], task_token=eye[t]) for t in (0, 1, 2)]
+        sum((y * w[t]).sum() for t, y in enumerate(ys)).backward()
+        assert float((grads() - ref).norm() / ref.norm()) < 2e-2
+    ys = [model(x=x, coords=coords, genes=genes, clinical=[], task_token=eye[t]) for t in (0, 1, 2)]
+    (ys[0] * w[0]).sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="speculate = False"):
+        (ys[1] * w[1]).sum().backward()
+    grads()
