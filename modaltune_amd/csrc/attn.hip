@@ -399,378 +399,7 @@ __global__ __launch_bounds__(256) void mix_ln_bwd_kernel(const h16* __restrict__
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// backward, kernel Q: dQ.  Same decomposition as the forward (query = lane).
-//   P'^T = exp2(S'^T - L2[q] + log2(ln 2))     (S' = K . Q'^T with the pre-scaled q'; L2 = lse_tot * log2e; P' = ln2 w_b P_b)
-//   dP^T[key,q] = V . dO^T                      V rows from LDS, dO^T in registers
-//   dS^T = P'^T (dP^T - delta_b[q])             (= dL/dS': the ln 2 rides inside P')
-//   dQ^T[d,q] += K^T[d,key] . dS^T              K^T via transposed LDS reads
-// The elementwise block is written with packed fp32 ops (v_pk_fma/add/mul_f32): these kernels issue about as many
-// VALU cycles as MFMA cycles, and the two did not overlap (PMC: VALU 49 %, MFMA 37 % busy before this form).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dilated_attn_bwd_q_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
-                                                                 const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
-                                                                 Plan p, h16* __restrict__ ws) {
-  // K and V tiles in LDS-DMA images (attn_common.h: img_off), double-buffered, one barrier per tile; the K image serves
-  // both the row reads (S) and the transposed reads (dQ): one image instead of two, no staging stores
-  __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // K0 | K1 | V0 | V1
-  h16* const Ks = smem;
-  h16* const Vs = smem + 2 * IMG_HALVES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 5, l31 = lane & 31;
-  const WorkItem w = decode(p, blockIdx.x);
-  const Seq sq = make_seq(p, w);
-  const long M = (long)p.B * p.N;
-  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  // padded queries get no gradient; padded keys have K = 0 and add nothing to dQ: neither is computed
-  const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
-  const int nvq = min(nv, p.qlimit[w.br]);
-  if (w.qt * 128 >= nvq) return;
-
-  {   // constant chunks 6, 7 (zeros, read as d rows 48..63 of K^T) of both K images; written once
-    const int buf = tid >> 7, row = (tid >> 1) & 63, which = 6 + (tid & 1);
-    *reinterpret_cast<h16x8*>(&Ks[buf * IMG_HALVES + img_off(row, which)]) = zero8;
-  }
-
-  const int iq = w.qt * 128 + wave * 32 + l31;
-  const bool qvalid = sq.valid(iq) && iq < nvq;
-  const long qrow = sq.row_clamped(iq);
-  h16x8 qf[3], dof[3];
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) {
-    qf[ks] = sel8(qvalid, ldg8(hm_ptr(qkv, M, w.h, qrow) + ks * 16 + hh * 8));
-    dof[ks] = sel8(qvalid, ldg8(hm_ptr(dmixed, M, w.h, qrow) + ks * 16 + hh * 8));
-  }
-  // invalid queries: -L2 = -big -> P' = 0
-  const float L2raw = lse_tot[qrow * H + w.h], dlraw = delta_br[((long)w.br * M + qrow) * H + w.h];
-  const float nl2 = qvalid ? fmaf(-L2raw, LOG2E, LOG2_LN2) : -1.0e30f;
-  const float ndl = qvalid ? -dlraw : 0.f;
-  f32x16 nl2i, ndli;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { nl2i[i] = nl2; ndli[i] = ndl; }
-
-  const int ntile = (nv + 63) >> 6;      // tiles holding at least one real key
-  const int row_bytes = sq.dr * HD * 2;
-  const long valid_bytes = (long)(nv - 1) * row_bytes + HD * 2;     // entries [0, nv) are real rows; the rest read as zeros
-  const long tile_bytes = 64L * row_bytes;
-  const h16* const kseq = hm_ptr(qkv, M, H + w.h, sq.row(0));
-  const h16* const vseq = hm_ptr(qkv, M, 2 * H + w.h, sq.row(0));
-  const DmaLane dl(tid, row_bytes);
-  auto dma = [&](int t) {
-    // (both images of a tile under one exec mask per piece, wave-uniform LDS destinations: dQ -1.6 %; the same form is
-    // neutral in the forward and costs the dK/dV kernel 2 %, so those keep the two-call form)
-    dma_tile_pair(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), Vs + (t & 1) * IMG_HALVES,
-                  tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl, __builtin_amdgcn_readfirstlane(tid >> 6));
-  };
-  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  int rrd[3];
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) rrd[ks] = img_off(l31, 2 * ks + hh);
-  const int kc = 2 * (grp & 1) + (tp >> 1), ko = 4 * (tp & 1);
-  const int ka0 = img_off(4 * hh + tq, kc) + ko, ka1 = img_off(4 * hh + tq, kc + 4) + ko;
-  const int kb0 = img_off(4 * hh + tq + 8, kc) + ko, kb1 = img_off(4 * hh + tq + 8, kc + 4) + ko;
-
-  f32x16 dq0, dq1;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { dq0[i] = 0.f; dq1[i] = 0.f; }
-  dma(0);
-  dma_wait_all();
-  __syncthreads();
-  // tail_tag: the tile holds keys >= n (tile padding, excluded)
-  auto tile = [&](int t, auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    const int kb = t * 64;
-    const h16* Kb = Ks + (t & 1) * IMG_HALVES;
-    const h16* Vb = Vs + (t & 1) * IMG_HALVES;
-    if (t + 1 < ntile) dma(t + 1);
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      // the per-query constants (query = lane: one value per lane) ride in as the INITIAL accumulators:
-      // S' - L2 + log2(ln 2) and dP - delta leave the chains ready
-      f32x16 s, dp;
-      // The six row fragments of the two chains are requested AHEAD of the products -- three reads up front, then one read per
-      // MFMA (sched_group_barrier: DS_READ x3, (MFMA, DS_READ) x3, MFMA x3) -- so every fragment is in flight for >= 2 MFMAs
-      // (64+ cycles) before its use.  Left alone the compiler reuses ONE fragment register: read -> s_waitcnt lgkmcnt(0) -> MFMA,
-      // six exposed LDS round trips per 32 keys (same-box A/B, tools/attn3_microbench.py: dQ 0.537 -> 0.517 ms, dK/dV 0.802 ->
-      // 0.777; requesting all six at once costs registers: dK/dV drops to 2 waves per SIMD and loses 9 %).
-      h16x8 ka[3], va[3];
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        ka[ks] = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + rrd[ks]]);
-        va[ks] = *reinterpret_cast<const h16x8*>(&Vb[sub * 32 * IMG_ROW + rrd[ks]]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[ks], qf[ks], ks == 0 ? nl2i : s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks], dof[ks], ks == 0 ? ndli : dp, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
-      h16x8 dsf[2];
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]});
-        if (TAIL) {
-          const int kidx = kb + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (kidx >= sq.n) pt[0] = 0.f;
-          if (kidx + 1 >= sq.n) pt[1] = 0.f;
-        }
-        const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
-        dsf[i >> 3][i & 7] = (h16)d[0];
-        dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const h16* kblk = Kb + (sub * 32 + s2 * 16) * IMG_ROW;
-        const h16x8 k0 = cat8(lds_tr4(kblk + ka0), lds_tr4(kblk + kb0));
-        const h16x8 k1 = cat8(lds_tr4(kblk + ka1), lds_tr4(kblk + kb1));
-        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, dsf[s2], dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, dsf[s2], dq1, 0, 0, 0);
-      }
-    }
-    dma_wait_all();
-    __syncthreads();
-  };
-  const bool tail_last = ntile * 64 > sq.n;      // the last processed tile contains keys >= n
-  const int nplain = tail_last ? ntile - 1 : ntile;
-  for (int t = 0; t < nplain; ++t) tile(t, std::false_type{});
-  if (tail_last) tile(ntile - 1, std::true_type{});
-  if (qvalid) {
-    h16* out = ws + ws_slot(p, w, qrow);
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const h16x4 v = {(h16)dq0[4 * gq], (h16)dq0[4 * gq + 1], (h16)dq0[4 * gq + 2], (h16)dq0[4 * gq + 3]};
-      *reinterpret_cast<h16x4*>(out + 8 * gq + 4 * hh) = v;
-    }
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-      const h16x4 v = {(h16)dq1[4 * gq], (h16)dq1[4 * gq + 1], (h16)dq1[4 * gq + 2], (h16)dq1[4 * gq + 3]};
-      *reinterpret_cast<h16x4*>(out + 32 + 8 * gq + 4 * hh) = v;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward, kernel KV: dK, dV.  One workgroup = 128 keys (key = lane) of one (pass, branch, segment, head),
-// sweeping the queries of the same sparse sequence in tiles of 64.
-//   S[q,key]  = Q . K^T            Q rows from LDS, K^T in registers
-//   dP[q,key] = dO . V^T           dO rows from LDS, V^T in registers
-//   P' = exp2(S' - L2[q] + log2(ln 2)) ; dS = P' (dP - delta[q])          (S' = Q' . K^T, q pre-scaled; P' = ln2 P~)
-//   dV^T[d,key] += dO^T[d,q] . P'  (rescaled by 1 / ln 2 once at the end) ; dK^T[d,key] += Q'^T[d,q] . dS
-// LDS holds -L2 + log2(ln 2) and -delta per query; they are read straight into the S / dP accumulators before the
-// MFMA chains, and q carries the softmax scale, so the elementwise block is 1 packed mul, 2 exp and 2 packed
-// converts per element pair.
-// ------------------------------------------------------------------------------------------------
-// (launch bound: 3 waves per SIMD = 168 VGPRs; the prefetched fragments would otherwise push the kernel to 175 and a wave per SIMD less)
-__global__ __launch_bounds__(256, 3) void dilated_attn_bwd_kv_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dmixed,
-                                                                  const float* __restrict__ lse_tot, const float* __restrict__ delta_br,
-                                                                  Plan p, h16* __restrict__ ws) {
-  // Q and dO tiles in LDS-DMA images (attn_common.h: img_off: each read both by rows and transposed), double-buffered
-  // together with the per-query constants; one barrier per tile
-  __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // Q0 | Q1 | D0 | D1
-  __shared__ __attribute__((aligned(16))) float L2s[2][64];
-  __shared__ __attribute__((aligned(16))) float Dls[2][64];
-  h16* const Qx = smem;
-  h16* const Dx = smem + 2 * IMG_HALVES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 5, l31 = lane & 31;
-  const WorkItem w = decode(p, blockIdx.x);
-  const Seq sq = make_seq(p, w);
-  const long M = (long)p.B * p.N;
-  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  // padded keys get no gradient; padded queries read as Q = dO = 0 (range check of the DMA descriptor) and add nothing
-  const int nv = __builtin_amdgcn_readfirstlane(sq.nvalid());
-  if (w.qt * 128 >= nv) return;
-
-  {   // the zero columns d = 48..63 (logical chunks 6, 7) of all four images, written once: 4 x 64 x 2 chunks, two per thread
-    const int img = tid >> 6, row = tid & 63;
-    *reinterpret_cast<h16x8*>(&smem[img * IMG_HALVES + img_off(row, 6)]) = zero8;
-    *reinterpret_cast<h16x8*>(&smem[img * IMG_HALVES + img_off(row, 7)]) = zero8;
-  }
-
-  // this lane's key: K^T / V^T fragments (B operands), element j of k-step ks = K[key][16 ks + 8 hh + j]
-  const int ik = w.qt * 128 + wave * 32 + l31;
-  const bool kvalid = sq.valid(ik);
-  const long krow = sq.row_clamped(ik);
-  h16x8 kf[3], vf[3];
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) {
-    kf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, H + w.h, krow) + ks * 16 + hh * 8));
-    vf[ks] = sel8(kvalid, ldg8(hm_ptr(qkv, M, 2 * H + w.h, krow) + ks * 16 + hh * 8));
-  }
-
-  const int nvq = min(nv, p.qlimit[w.br]);   // entries that act as queries (sequence-parallel plans: a prefix)
-  const int ntile = (nvq + 63) >> 6;     // tiles holding at least one real query
-  const int row_bytes = sq.dr * HD * 2;
-  const long valid_bytes = (long)(nvq - 1) * row_bytes + HD * 2;
-  const long tile_bytes = 64L * row_bytes;
-  const h16* const qseq = hm_ptr(qkv, M, w.h, sq.row(0));
-  const h16* const dseq = hm_ptr(dmixed, M, w.h, sq.row(0));
-  const DmaLane dl(tid, row_bytes);
-  // per-query constants of a tile: wave 0 loads them (one query per lane), neutral values past the end of the sequence
-  const float* const lbase = lse_tot + sq.row(0) * H + w.h;
-  const float* const dbase = delta_br + ((long)w.br * M + sq.row(0)) * H + w.h;
-  float rl2 = 0.f, rdl = 0.f;
-  auto issue = [&](int t) {
-    dma_tile(Qx + (t & 1) * IMG_HALVES, tile_rsrc(qseq, t * tile_bytes, valid_bytes), dl);
-    dma_tile(Dx + (t & 1) * IMG_HALVES, tile_rsrc(dseq, t * tile_bytes, valid_bytes), dl);
-    if (tid < 64) {      // RAW loads only: the arithmetic on them waits in publish(), at the END of the tile (a use here parks wave 0
-      const long off = (long)min(t * 64 + lane, nvq - 1) * sq.dr * H;      // on s_waitcnt vmcnt(0) -- the DMA just issued included)
-      rl2 = lbase[off];
-      rdl = dbase[off];
-    }
-  };
-  auto publish = [&](int t) {      // constants of tile t into their buffer (written by wave 0, read after the barrier)
-    if (tid < 64) {
-      const bool ok = t * 64 + lane < nvq;      // (Q = dO = 0 past the end: P' is multiplied by zeros)
-      L2s[t & 1][tid] = ok ? fmaf(-rl2, LOG2E, LOG2_LN2) : 0.f;
-      Dls[t & 1][tid] = ok ? -rdl : 0.f;
-    }
-  };
-
-  f32x16 dk0, dk1, dv0, dv1;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
-  const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  // per-lane offsets into the images: row reads of chunk 2 ks + hh, transposed reads of rows 4 hh + tq (a) and + 8 (b),
-  // column blocks d 0..31 (0) and 32..63 (1); the sub / s2 row-block offsets are multiples of 16 rows (img_f unchanged)
-  int rrd[3];
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) rrd[ks] = img_off(l31, 2 * ks + hh);
-  const int trc = 2 * (grp & 1) + (tp >> 1), tro = 4 * (tp & 1);
-  const int tr_a0 = img_off(4 * hh + tq, trc) + tro, tr_a1 = img_off(4 * hh + tq, trc + 4) + tro;
-  const int tr_b0 = img_off(4 * hh + tq + 8, trc) + tro, tr_b1 = img_off(4 * hh + tq + 8, trc + 4) + tro;
-
-  issue(0);
-  publish(0);
-  dma_wait_all();
-  __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const h16* Qb = Qx + (t & 1) * IMG_HALVES;
-    const h16* Db = Dx + (t & 1) * IMG_HALVES;
-    const float* L2b = L2s[t & 1];
-    const float* Dlb = Dls[t & 1];
-    if (t + 1 < ntile) issue(t + 1);
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      // row constants ride in as the INITIAL accumulators (rows of the accumulators are queries:
-      // row(i) = (i&3) + 8 (i>>2) + 4 hh): S' - L2 + log2(ln 2), dP' = dO.V^T - delta
-      f32x16 s, dp;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&L2b[sub * 32 + 8 * g4 + 4 * hh]);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&Dlb[sub * 32 + 8 * g4 + 4 * hh]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a[e]; dp[4 * g4 + e] = b[e]; }
-      }
-      // row fragments requested ahead of the products, three deep (see the dQ kernel); the full barrier keeps the constants'
-      // reads above out of the read / MFMA groups
-      __builtin_amdgcn_sched_barrier(0);
-      h16x8 qa[3], da[3];
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        qa[ks] = *reinterpret_cast<const h16x8*>(&Qb[sub * 32 * IMG_ROW + rrd[ks]]);
-        da[ks] = *reinterpret_cast<const h16x8*>(&Db[sub * 32 * IMG_ROW + rrd[ks]]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da[ks], vf[ks], dp, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
-      h16x8 pf[2], dsf[2];
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const f32x2 pt = pk_exp2((f32x2){s[i], s[i + 1]});
-        const f32x2 d = pt * (f32x2){dp[i], dp[i + 1]};
-        pf[i >> 3][i & 7] = (h16)pt[0]; pf[i >> 3][(i & 7) + 1] = (h16)pt[1];
-        dsf[i >> 3][i & 7] = (h16)d[0]; dsf[i >> 3][(i & 7) + 1] = (h16)d[1];
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int rb = (sub * 32 + s2 * 16) * IMG_ROW;      // rows rb + 4 hh + tq and + 8; cols d 0..31 / 32..63
-        const h16x8 d0 = cat8(lds_tr4(&Db[rb + tr_a0]), lds_tr4(&Db[rb + tr_b0]));
-        const h16x8 d1 = cat8(lds_tr4(&Db[rb + tr_a1]), lds_tr4(&Db[rb + tr_b1]));
-        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, pf[s2], dv0, 0, 0, 0);
-        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, pf[s2], dv1, 0, 0, 0);
-        const h16x8 q0 = cat8(lds_tr4(&Qb[rb + tr_a0]), lds_tr4(&Qb[rb + tr_b0]));
-        const h16x8 q1 = cat8(lds_tr4(&Qb[rb + tr_a1]), lds_tr4(&Qb[rb + tr_b1]));
-        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, dsf[s2], dk0, 0, 0, 0);
-        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, dsf[s2], dk1, 0, 0, 0);
-      }
-    }
-    if (t + 1 < ntile) publish(t + 1);
-    dma_wait_all();            // tile t + 1 has landed ...
-    __syncthreads();           // ... for everybody, and everybody has left tile t
-  }
-  if (kvalid) {
-    h16* outk = ws + ws_slot(p, w, krow) + ws_which_stride(p, w.br);
-    h16* outv = outk + ws_which_stride(p, w.br);
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const h16x4 a = {(h16)dk0[4 * gq], (h16)dk0[4 * gq + 1], (h16)dk0[4 * gq + 2], (h16)dk0[4 * gq + 3]};
-      const h16x4 b = {(h16)(dv0[4 * gq] * INV_LN2), (h16)(dv0[4 * gq + 1] * INV_LN2), (h16)(dv0[4 * gq + 2] * INV_LN2),
-                       (h16)(dv0[4 * gq + 3] * INV_LN2)};
-      *reinterpret_cast<h16x4*>(outk + 8 * gq + 4 * hh) = a;
-      *reinterpret_cast<h16x4*>(outv + 8 * gq + 4 * hh) = b;
-    }
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-      const h16x4 a = {(h16)dk1[4 * gq], (h16)dk1[4 * gq + 1], (h16)dk1[4 * gq + 2], (h16)dk1[4 * gq + 3]};
-      const h16x4 b = {(h16)(dv1[4 * gq] * INV_LN2), (h16)(dv1[4 * gq + 1] * INV_LN2), (h16)(dv1[4 * gq + 2] * INV_LN2),
-                       (h16)(dv1[4 * gq + 3] * INV_LN2)};
-      *reinterpret_cast<h16x4*>(outk + 32 + 8 * gq + 4 * hh) = a;
-      *reinterpret_cast<h16x4*>(outv + 32 + 8 * gq + 4 * hh) = b;
-    }
-  }
-}
-
-// Sum the per-branch compact gradients into the dense fp16 dqkv [B*N, 2304] that feeds the dX GEMM.
-// 192 threads per token row: thread -> 12 consecutive columns of one (q|k|v, head).  The workspace is token-major
-// (attn_common.h: ws_slot): the heads a branch covers at a token are one contiguous run in the source AND in the dense row, so
-// the threads of a wave read consecutive addresses.
-__global__ __launch_bounds__(192) void dilated_attn_bwd_combine_kernel(const h16* __restrict__ ws, Plan p, h16* __restrict__ dqkv) {
-  const long M = (long)p.B * p.N;
-  const int t = threadIdx.x;
-  const int col = t * 12, which = col / DM, h = (col % DM) / HD, d0 = col % HD;
-  for (long m = blockIdx.x; m < M; m += gridDim.x) {
-    const int pos = (int)(m % p.N);
-    float acc[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int br = 0; br < MT_MAX_BRANCHES; ++br) {
-      if (br < p.nbranch) {
-        const int dr = p.ratio[br], sg = p.seg[br], hb = H / dr;
-        const int j = pos / sg, loc = pos - j * sg;
-        if (loc % dr == h / hb) {
-          const h16* src = ws + p.ws_off[br] + ((m * 3 + which) * hb + (h % hb)) * HD + d0;
-          const h16x4 a0 = *reinterpret_cast<const h16x4*>(src), a1 = *reinterpret_cast<const h16x4*>(src + 4),
-                      a2 = *reinterpret_cast<const h16x4*>(src + 8);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { acc[e] += (float)a0[e]; acc[4 + e] += (float)a1[e]; acc[8 + e] += (float)a2[e]; }
-        }
-      }
-    }
-    h16* dst = dqkv + m * QKV_LD + col;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const h16x4 o = {(h16)acc[4 * k], (h16)acc[4 * k + 1], (h16)acc[4 * k + 2], (h16)acc[4 * k + 3]};
-      *reinterpret_cast<h16x4*>(dst + 4 * k) = o;
-    }
-  }
-}
+// (backward kernels: attn_bwd_q.hip, attn_bwd_kv.hip, attn_combine.hip -- one translation unit per LLVM scheduling strategy)
 
 }  // namespace
 
@@ -829,19 +458,11 @@ extern "C" int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, co
                                    const float* delta_br, const MtDilatedPlan* plan, void* workspace, mt_half* dqkv,
                                    int phases, mt_stream_t stream) {
   if (!qkv || !dmixed || !lse_tot || !delta_br || !workspace || !dqkv || !plan_ok(plan) || !(phases & 7)) return MT_ERR_BAD_ARG;
-  const Plan p = make_plan(plan, 128);
-  const int nblk = p.blk_off[p.nbranch];
   hipStream_t s = (hipStream_t)stream;
   // every (branch, position, head) slot of the workspace is written exactly once by each of the two kernels
-  if (phases & MT_ATTN_BWD_KV)
-    hipLaunchKernelGGL(dilated_attn_bwd_kv_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
-                       delta_br, p, (h16*)workspace);
-  if (phases & MT_ATTN_BWD_Q)
-    hipLaunchKernelGGL(dilated_attn_bwd_q_kernel, dim3(nblk), dim3(256), 0, s, (const h16*)qkv, (const h16*)dmixed, lse_tot,
-                       delta_br, p, (h16*)workspace);
-  const long M = (long)p.B * p.N;
-  if (phases & MT_ATTN_BWD_COMBINE)
-    hipLaunchKernelGGL(dilated_attn_bwd_combine_kernel, dim3((int)min(M, 16384L)), dim3(192), 0, s, (const h16*)workspace, p, (h16*)dqkv);
+  if (phases & MT_ATTN_BWD_KV) mt_attn::launch_bwd_kv(qkv, dmixed, lse_tot, delta_br, plan, workspace, s);
+  if (phases & MT_ATTN_BWD_Q) mt_attn::launch_bwd_q(qkv, dmixed, lse_tot, delta_br, plan, workspace, s);
+  if (phases & MT_ATTN_BWD_COMBINE) mt_attn::launch_bwd_combine(workspace, plan, dqkv, s);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

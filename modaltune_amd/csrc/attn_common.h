@@ -294,3 +294,14 @@ struct StageRow {       // eight lanes per row
 };
 
 }  // namespace
+
+// The backward's three kernels live in their own translation units (attn_bwd_q.hip, attn_bwd_kv.hip, attn_combine.hip): LLVM's
+// AMDGPU scheduling strategy is a per-module option (`-mllvm -amdgpu-sched-strategy=...`, __graft_entry__.py: FLAGS_PER_FILE) and
+// each kernel wants its own (tools/experiments/README.md, round 3: dQ -2.5 % under iterative-ilp, combine -7 % under max-ilp, the
+// dK/dV kernel only under the default).  mt_dilated_attn_bwd (attn.hip) calls these launchers.
+namespace mt_attn {
+// (C-ABI types only: the device-side Plan lives in each unit's anonymous namespace and has no linkage)
+void launch_bwd_kv(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot, const float* delta_br, const MtDilatedPlan* plan, void* ws, hipStream_t s);
+void launch_bwd_q(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot, const float* delta_br, const MtDilatedPlan* plan, void* ws, hipStream_t s);
+void launch_bwd_combine(const void* ws, const MtDilatedPlan* plan, mt_half* dqkv, hipStream_t s);
+}  // namespace mt_attn

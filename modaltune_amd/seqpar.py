@@ -141,6 +141,17 @@ class SeqParallelAttention:
             self.dist.all_gather_into_tensor(out.view(-1), t.reshape(-1), group=self.group)
         return out
 
+    def _all_to_all(self, send: torch.Tensor, sizes: List[int]) -> torch.Tensor:
+        """Symmetric all-to-all of one flat payload (`sizes[r]` elements to and from rank r)."""
+        recv = torch.empty_like(send)
+        if self._host_staged():
+            hs, hr = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
+            self.dist.all_to_all_single(hr, hs, sizes, sizes, group=self.group)
+            recv.copy_(hr)
+        else:
+            self.dist.all_to_all_single(recv, send, sizes, sizes, group=self.group)
+        return recv
+
     def _exchange_plan(self):
         """Who gets which slices of the dK / dV payload: rank rc receives, for every long branch k whose group holds both of
         us, my partial sums for ITS chunk.  Groups are symmetric, so what I send to rc is as long as what rc sends to me."""
@@ -163,13 +174,7 @@ class SeqParallelAttention:
         ranks, nothing sent to ranks outside the segment -- followed by an fp32 sum on the receiver)."""
         per_dst, sizes = self._exchange_plan()
         send = torch.cat([contrib[rc, self.pay_off[k]:self.pay_off[k + 1]] for rc in range(self.W) for k in per_dst[rc]])
-        recv = torch.empty_like(send)
-        if self._host_staged():
-            hs, hr = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
-            self.dist.all_to_all_single(hr, hs, sizes, sizes, group=self.group)
-            recv.copy_(hr)
-        else:
-            self.dist.all_to_all_single(recv, send, sizes, sizes, group=self.group)
+        recv = self._all_to_all(send, sizes)
         red = self._new(self.pay, dtype=F32, zero=True)
         tmp = self._new(self.pay, dtype=F32)
         off = 0

@@ -85,6 +85,45 @@ def _worker(rank, world, port, n):
         flag = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
         red.sync_flag_(flag)
         assert int(flag) == 1
+        # The DEVICE-tensor branches (what RCCL runs: asynchronous reduce_scatter_tensor / all_reduce / all_gather_into_tensor with
+        # work handles waited for later, no host staging; dp.py `else:` arms) -- gloo executes the same calls on CPU tensors, so
+        # they are driven here with the host-staging switch forced off.  Same expectations as above.
+        st.flat_grad.copy_(g0)
+        st.flat.copy_(p0)
+        red = dp.GradReducer(st.flat_grad, buckets, flat_param=st.flat)
+        red._host = False
+        red.start(1)
+        assert red.pending and all(hasattr(w, "wait") for w in red.pending)           # async work handles, nothing waited for yet
+        red.start_rest()
+        n_async = len(red.pending)
+        assert n_async == sum(len(v) for v in red.views[:-1]) + len(red._rs) + len(red._tails)
+        assert red.wait() == world and not red.pending
+        for o, k in red.adam_pieces(st.n_flat):
+            assert torch.allclose(st.flat_grad[o:o + k], total[o:o + k], rtol=1e-6, atol=1e-6)
+            st.flat[o:o + k] -= 0.1 * st.flat_grad[o:o + k]
+        red.start_param_gather()
+        assert len(red._param_pending) == len(red._rs)                                # staged, asynchronous: copied back in wait_params
+        red.wait_params()
+        assert not red._param_pending and torch.allclose(st.flat, p0 - 0.1 * total, rtol=1e-6, atol=1e-6)
+        # sequence-parallel collectives (seqpar.py `else:` arms: all_gather_into_tensor / all_to_all_single on the tensors as they are)
+        from modaltune_amd import seqpar
+        sp = seqpar.SeqParallelAttention.__new__(seqpar.SeqParallelAttention)
+        sp.dist, sp.group, sp.W = dist, None, world
+        for staged in (True, False):
+            sp._host_staged = lambda staged=staged: staged
+            t = torch.arange(6, dtype=torch.float16).reshape(2, 3) + 10 * rank
+            got = sp._all_gather(t)
+            assert got.shape == (world, 2, 3) and all(torch.equal(got[r], torch.arange(6, dtype=torch.float16).reshape(2, 3) + 10 * r) for r in range(world))
+            sizes = [3, 5] if rank == 0 else [5, 2]          # symmetric: what I send to r is as long as what r sends to me
+            send = torch.arange(sum(sizes), dtype=torch.float16) + 100 * rank
+            recv = sp._all_to_all(send, sizes)
+            other = 1 - rank
+            o_sizes = [3, 5] if other == 0 else [5, 2]
+            o_send = torch.arange(sum(o_sizes), dtype=torch.float16) + 100 * other
+            mine_from_me = send[:sizes[0]] if rank == 0 else send[sizes[0]:]
+            from_other = o_send[sum(o_sizes[:rank]):sum(o_sizes[:rank + 1])]
+            want_recv = torch.cat([mine_from_me, from_other]) if rank == 0 else torch.cat([from_other, mine_from_me])
+            assert torch.equal(recv, want_recv), (rank, staged, recv, want_recv)
     finally:
         dist.destroy_process_group()
 
