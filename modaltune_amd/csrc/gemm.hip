@@ -12,6 +12,9 @@
 
 #include "common.h"
 
+// gemm_ps.hip: persistent form for the backbone shapes (returns MT_ERR_UNSUPPORTED for shapes it does not serve)
+int mt_gemm_ps_launch(const void* A, long lda, const void* W, int M, int N, int K, int epilogue, const float* bias, void* C, long ldc, hipStream_t s);
+
 namespace {
 
 constexpr int BK = 64;
@@ -881,6 +884,14 @@ extern "C" int mt_gemm_nt_f16(const mt_half* A, long lda, const MtRowMap* amap, 
   a.C = C; a.ldc = ldc; a.cmap = make_rowmap(cmap);
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = out_dtype == MT_OUT_F32;
+  // the frozen backbone's big-M shapes (and their dX counterparts) run on the persistent one-wave-per-SIMD kernel (gemm_ps.hip), which
+  // declines (MT_ERR_UNSUPPORTED) what it does not serve or would serve badly (few tiles per CU).  MT_GEMM_PS=0 switches it off (A/B runs).
+  const char* ps_env = getenv("MT_GEMM_PS");
+  if (!(ps_env && ps_env[0] == '0') && !f32 && (epilogue == MT_EPI_BIAS || epilogue == MT_EPI_QKV_HM) && a.amap.seg_rows <= 0 &&
+      a.cmap.seg_rows <= 0 && (ldc % 8) == 0 && !((uintptr_t)C & 15) && (epilogue != MT_EPI_QKV_HM || a.bias) && !a.drop.active()) {
+    const int rc = mt_gemm_ps_launch(A, lda, W, M, N, K, epilogue, a.bias, C, ldc, s);
+    if (rc != MT_ERR_UNSUPPORTED) return rc;
+  }
   switch (epilogue) {
     case MT_EPI_BIAS:
       return f32 ? launch_nt_bn<MT_EPI_BIAS, float>(a, s) : launch_nt_bn<MT_EPI_BIAS, h16>(a, s);

@@ -117,6 +117,39 @@ def test_gemm_nt_256x256_tile(ops, N, K):
     assert rel(out, A.double() @ W.double().t() + bias.double()) < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(30003, 3072, 768, "bias"), (30003, 768, 3072, "bias"), (30003, 2304, 768, "qkv"), (30003, 768, 768, "bias"),
+                                        (30003, 768, 2304, "none"), (29953, 768, 768, "none"), (12291, 3072, 768, "bias"), (24579, 2304, 1536, "qkv")])
+def test_gemm_nt_persistent_kernel_backbone_shapes(ops, M, N, K, kind, monkeypatch):
+    """The backbone's big-M shapes take the persistent one-wave-per-SIMD kernel (csrc/gemm_ps.hip: 192 x 256 tiles walked by one
+    workgroup per CU, the finished tile drained under the next one): ragged last row tile, bias as the first slice's C operand,
+    head-major q|k|v stores, the dX form without bias.  Checked against fp64 and against the ping-pong kernel on the same operands
+    (MT_GEMM_PS=0), which it must reproduce to fp16 rounding of the same fp32 sums."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).half()
+    bias = torch.randn(N, device=DEV, generator=g) if kind != "none" else None
+    epi = ops.EPI_QKV_HM if kind == "qkv" else ops.EPI_BIAS
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MT_GEMM_PS", mode)
+        out = torch.full((M * N,), float("nan"), dtype=torch.float16, device=DEV)
+        ops.gemm_nt(A, W, out, M, N, K, bias=bias, epilogue=epi)
+        torch.cuda.synchronize()
+        outs.append(out)
+    ref = A.double() @ W.double().t()
+    if bias is not None:
+        ref += bias.double()
+    if kind == "qkv":
+        ref = ref.view(M, N // 48, 48).permute(1, 0, 2)
+        got = [o.view(N // 48, M, 48) for o in outs]
+    else:
+        got = [o.view(M, N) for o in outs]
+    assert int(torch.isnan(outs[0]).sum()) == 0
+    assert rel(got[0], ref) < 2e-3 and rel(got[1], ref) < 2e-3
+    # same products, same fp32 accumulation width, one fp16 rounding: the two kernels differ by summation order only
+    assert float((got[0].float() - got[1].float()).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("M", [333, 2600, 8300])
 def test_gemm_nt_head_major_qkv_epilogue(ops, M):
     g = rng(19)
