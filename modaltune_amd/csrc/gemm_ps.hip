@@ -376,6 +376,11 @@ int mt_gemm_ps_launch(const void* A, long lda, const void* W, int M, int N, int 
   const int rounds = cdiv(ntiles, ncu);
   if (2 * ntiles < 3 * ncu || 5L * ntiles < 4L * rounds * ncu) return MT_ERR_UNSUPPORTED;
   if (ldc != N && epilogue != MT_EPI_QKV_HM) return MT_ERR_UNSUPPORTED;      // (the store descriptor spans M * N contiguous halves)
+  // K = 3072 (fc2, dX of fc1): the A operand is 184 MB that the previous kernel has just written; with operands from HBM the issue of
+  // the LDS-DMA pieces itself backs up (stamps: the slice body 1000 -> 1560 cycles, the vmcnt wait unchanged) and a wave that is alone on
+  // its SIMD has nobody to run MFMAs meanwhile.  tools/gemm_cold_bench.py: 175 vs 161 us cold, 124 vs 133 warm; in the step: 3.82 vs 3.83 ms
+  // for the 24 launches.  A five-slot ring (DMA four slices ahead, all 160 KB of LDS) changed neither.  Left to the ping-pong kernel.
+  if (K > 2304) return MT_ERR_UNSUPPORTED;
   int grid = min(ncu, ntiles);
   grid = max(8, grid / 8 * 8);
   if ((long)M * K * 2 >= (1L << 32) || (long)M * N * 2 >= (1L << 32) || (long)N * K * 2 >= (1L << 32)) return MT_ERR_UNSUPPORTED;   // 32-bit byte offsets

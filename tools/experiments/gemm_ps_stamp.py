@@ -12,7 +12,10 @@ C = torch.zeros(M, N, device="cuda", dtype=torch.float16)
 bias = torch.randn(N, device="cuda") if os.environ.get("PS_BIAS") else None
 st = torch.zeros(256 * 8, device="cuda", dtype=torch.int64)
 assert lib.mt_gemm_ps_set_stamps(ctypes.c_void_p(st.data_ptr())) == 0
-for _ in range(3):
+junk = torch.empty(1 << 28, dtype=torch.float32, device="cuda") if os.environ.get("PS_COLD") else None
+for it in range(3):
+    if junk is not None:
+        junk.fill_(float(it))          # evict L2 / MALL: operands come from HBM, as after the previous kernels of a train step
     rc = lib.mt_gemm_ps_stamp_launch(ctypes.c_void_p(A.data_ptr()), ctypes.c_long(K), ctypes.c_void_p(W.data_ptr()), M, N, K, ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, ctypes.c_void_p(C.data_ptr()), ctypes.c_long(N))
     assert rc == 0
 torch.cuda.synchronize()
