@@ -419,7 +419,10 @@ def test_full_size_properties_L10000():
         batched = eng.forward(x, inp["coords"], genes, oh, need_grad=False).clone()
         single = torch.cat([eng.forward(x, inp["coords"], genes, oh[t:t + 1], need_grad=False).clone() for t in range(3)])
     assert torch.isfinite(batched).all()
-    assert _rel(batched.cpu().numpy(), single.cpu().numpy()) < 1e-5
+    # (B = 3 and B = 1 pick different GEMM kernels for some shapes -- M = 30 003 runs the persistent kernel, which takes the bias as the
+    # first slice's C operand, M = 10 001 partly the ping-pong kernel, which adds it last: the same fp32 products in another order, one
+    # fp16 rounding apart here and there.  Before gemm_ps.hip both sides ran identical arithmetic and this read 0.)
+    assert _rel(batched.cpu().numpy(), single.cpu().numpy()) < 2e-4
     # (b) directional derivative along the gradient
     loss0 = float(ts.step(x, inp["coords"], genes, text, update=False))
     assert int(ts.found_inf) == 0
