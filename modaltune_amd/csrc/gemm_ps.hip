@@ -50,6 +50,7 @@ struct GemmPsArgs {
   h16* C; long ldc;
   int M, N, K;
   int nbm, nbn;            // tiles along M / N
+  int gc;                  // column tiles per group of the tile order (see tile_of)
 };
 
 #ifdef PS_STAMP      // diagnostic build (tools/experiments/gemm_ps_stamp.py): phase durations of the steady-state slice, wave 0 of every workgroup
@@ -77,6 +78,18 @@ MT_DEVINL void ps_dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff,
 }
 MT_DEVINL __amdgpu_buffer_rsrc_t ps_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// Tile order: column tiles in groups of `gc`; inside a group row-major (row tile, then the group's columns).  The tiles in flight on
+// an XCD at one time are a run of this order: with gc * 256 rows of W (gc * K * 512 bytes) instead of all of W they keep hitting the
+// XCD's 4 MB L2, and every A row block is still shared by gc workgroups while it is hot.
+template <typename Args>
+MT_DEVINL void tile_of(const Args& g, int idx, int& mt, int& nt) {
+  const int per = g.nbm * g.gc;
+  const int cg = idx / per, rem = idx - cg * per;
+  const int w = min(g.gc, g.nbn - cg * g.gc);      // (the last group may be narrower)
+  mt = rem / w;
+  nt = cg * g.gc + (rem - mt * w);
 }
 
 // (all operand / output extents are below 4 GiB: byte offsets are 32-bit, the bases live in buffer descriptors / scalar registers)
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int d_tile = 0, d_ks = 0;                    // tile (index into my list) and slice of the next DMA group
   auto dma_tile_setup = [&](int t) {
     const int idx = t_begin + slot_id + min(t, my_tiles - 1) * nslot;
-    const int mt = idx / g.nbn, nt = idx - mt * g.nbn;
+    int mt, nt; tile_of(g, idx, mt, nt);
 #pragma unroll
     for (int p = 0; p < 3; ++p) voffA[p] = (unsigned)min(mt * PS_BM + wave * 48 + p * 16 + prow, g.M - 1) * lda2 + lchunk * 16;
     soffW = (unsigned)(nt * PS_BN + wave * 64) * K2;
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the conversions -- left free, the scheduler starts them above the conversions and the allocator has to find 192 more registers.)
     {
       const int idx = t_begin + slot_id + t * nslot;
-      const int mt = idx / g.nbn, nt = idx - mt * g.nbn;
+      int mt, nt; tile_of(g, idx, mt, nt);
       const int m = mt * PS_BM + wr * 96 + fq, n = nt * PS_BN + wc * 128 + fr * 8;
       held_rows_left = g.M - m;
       held_off = EPI == MT_EPI_QKV_HM ? (unsigned)(((n / 48) * g.M + m) * 48 + n % 48) * 2u
@@ -370,6 +383,13 @@ int mt_gemm_ps_launch(const void* A, long lda, const void* W, int M, int N, int 
   g.A = (const h16*)A; g.lda = lda; g.W = (const h16*)W; g.bias = bias; g.C = (h16*)C; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K;
   g.nbm = cdiv(M, PS_BM); g.nbn = N / PS_BN;
+  {
+    const char* e = getenv("MT_GEMM_GC");      // experiments: column tiles per group of the tile order (0 / unset: the default below)
+    const int want = e ? atoi(e) : 0;
+    // default: all columns when there are at most four column tiles; otherwise groups whose W rows (gc * 256 * K * 2 bytes) stay
+    // around 1.5 MB -- tools/gemm_gc_sweep.py, operands from HBM: N = 3072, K = 768: 170 us row-major, 153 in groups of 4; N = 2304: 130 / 118
+    g.gc = want > 0 ? min(want, g.nbn) : (g.nbn <= 4 ? g.nbn : max(2, min(g.nbn, 3072 / K)));
+  }
   const int ntiles = g.nbm * g.nbn;
   // Worth it only when every CU walks at least a tile and a half on average and the last round is not mostly idle (the tiles are of
   // equal size and statically assigned): M = 30 003 gives 1884 / 1413 / 471 tiles for N = 3072 / 2304 / 768 = 92 % of 8 / 6 / 2 rounds.

@@ -1,22 +1,26 @@
-"""gemm_nt at the backbone shapes with the operands COLD (a 1 GiB fill between launches evicts L2 / MALL, as the previous kernels of a
-train step do) and warm (back-to-back), persistent kernel (MT_GEMM_PS=1) vs ping-pong (MT_GEMM_PS=0) in one process."""
+"""Tile-order sweep of the persistent GEMMs: MT_GEMM_GC column tiles per group (see tile_of in csrc/gemm_ps.hip), warm and cold operands."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from modaltune_amd import ops
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 30003
-shapes = [(3072, 768, "bias"), (768, 3072, "bias"), (2304, 768, "qkv"), (768, 768, "bias"), (768, 2304, "none")]
+M = 30003
+shapes = [(3072, 768, "bias"), (2304, 768, "qkv"), (768, 768, "bias"), (768, 2304, "none"), (768, 3072, "none")]
 g = torch.Generator(device="cuda").manual_seed(0)
 junk = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+kern = "ps"
+os.environ["MT_GEMM_PS"] = "1"
 for N, K, kind in shapes:
     A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).half()
     W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).half()
     bias = torch.randn(N, device="cuda", generator=g) if kind != "none" else None
     C = torch.zeros(M * N, device="cuda", dtype=torch.float16)
     epi = ops.EPI_QKV_HM if kind == "qkv" else ops.EPI_BIAS
-    res = {}
-    for mode in ("0", "1", "0", "1"):        # 0: ping-pong, 1: persistent one-wave-per-SIMD
-        os.environ["MT_GEMM_PS"] = mode
+    out = []
+    for gc in (0, 1, 2, 3, 4, 6):
+        if gc > N // 256:
+            continue
+        os.environ["MT_GEMM_GC"] = str(gc)
+        r = []
         for cold in (True, False):
             ts = []
             for it in range(8):
@@ -27,6 +31,6 @@ for N, K, kind in shapes:
                 torch.cuda.synchronize()
                 if it >= 2:
                     ts.append(e0.elapsed_time(e1) * 1e3)
-            res.setdefault((mode, cold), []).append(sum(ts) / len(ts))
-    fmt = lambda k: "/".join(f"{v:.0f}" for v in res[k])
-    print(f"M={M} N={N} K={K} {kind}: cold  pp {fmt(('0', True))}  ps {fmt(('1', True))} us | warm  pp {fmt(('0', False))}  ps {fmt(('1', False))}", flush=True)
+            r.append(sum(ts) / len(ts))
+        out.append(f"gc={gc or 'all'}: {r[0]:.0f}/{r[1]:.0f}")
+    print(f"{kern} N={N} K={K} (cold/warm us): " + "  ".join(out), flush=True)
