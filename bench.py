@@ -326,12 +326,18 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
                        [torch.from_numpy(a).to(dev) for a in inp["genes"]], torch.from_numpy(inp["text"]).to(dev)))
         cells_per.append(L - L // 16)
 
-    def run(n, first=0):
+    graphed = not args.eager
+    ts.graph_cache_size = max(ts.graph_cache_size, len(slides))
+
+    def run(n, first=0, eager=False):
         for i in range(first, first + n):
             x, coords, genes, text = slides[i % len(slides)]
-            ts.step(x, coords, genes, text, update=True)
+            if graphed and not eager:
+                ts.step_graphed(x, coords, genes, text)      # gridding + token-count read-back eager, the rest replayed per (patches, tokens)
+            else:
+                ts.step(x, coords, genes, text, update=True)
 
-    nwarm = max(warmup, len(slides))
+    nwarm = max(warmup, len(slides) * (ts.capture_after + 1 if graphed else 1))      # every bag length visited eagerly, then captured
     run(nwarm)
     eng.check_inputs()
     torch.cuda.synchronize()
@@ -341,8 +347,9 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
     dt = time.perf_counter() - t0
     loss = float(ts.loss)
     prof_steps = len(slides)
+    replays = ts.graph_replays
     ops.TIMER = {}
-    run(prof_steps, first=0)
+    run(prof_steps, first=0, eager=True)
     torch.cuda.synchronize()
     timer, ops.TIMER = ops.TIMER, None
     summ = ops.timer_summary(timer)
@@ -372,7 +379,7 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
         "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"BASELINE config 4: TITAN-geometry ViT (768-d, 6 blocks, 12 heads x 64, MLP 3072, 2-D ALiBi in-kernel, attentional pooling; "
                                f"random init, stand-in for the absent MahmoodLab/TITAN snapshot: backbone parity UNPINNED) + Modal Adapter, "
-                               f"{T - 1} gene tokens + 1 task token, 3 task passes batched, fp16 operands / fp32 accumulate, eager schedule, "
+                               f"{T - 1} gene tokens + 1 task token, 3 task passes batched, fp16 operands / fp32 accumulate, "
                                + ("train mode (DropPath 0.2 on the Extractor FFN, gene-encoder dropouts), " if not args.no_dropout else "dropout off, ") +
                                f"foreground cells per slide: " + "/".join(str(c) for c in cells_per) + (" in rotation (mixed bag lengths)" if ragged else ""),
                    "cells": cells_per, "tokens": T, "parallelism": "dp1", "backbone_impl": eng.backbone.kind, "self_check": report},
@@ -383,7 +390,9 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
                                         "(2 x FETCH_SIZE + WRITE_SIZE) KiB" if traffic is not None else None),
                      "avg_launch_ms": ms / n_l, "flops_per_launch": kv_flops,
                      "measured": f"HIP events around each launch, eager instrumented pass over the {prof_steps} bag lengths after the timed region"},
-        "roofline_kernels": table, "launch": "eager",
+        "roofline_kernels": table,
+        "launch": ("hipGraph replay per (patches, tokens) geometry -- the gridding kernels and the token-count read-back stay eager; a bag length "
+                   "that has not been seen three times runs the eager schedule" if graphed else "eager"), "graph_replays": replays,
         "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:14]},
     }
     if cpu_baseline and not args.no_cpu_baseline:

@@ -82,6 +82,54 @@ def preprocess_features(features: torch.Tensor, coords, patch_size_lv0: int):
 
 
 # ------------------------------------------------------------------------------------------------ feature gridding (device)
+class GridStage:
+    """Static buffers of the on-device gridding for hipGraph replay (TrainStep.step_graphed): the five gridding kernels and the one
+    host read-back (the token count) run eagerly into these; the captured step starts at the token gather and reads them.  Sized
+    for the largest bag seen (grown by >= 25 %; the owner bumps its generation when they move)."""
+
+    def __init__(self, device):
+        self.dev, self.cap, self.C = device, 0, 0
+        self.L = self.Lv = 0
+
+    def ensure(self, L: int, C: int) -> bool:
+        if L <= self.cap and C == self.C:
+            return False
+        cap = max(L, self.cap + self.cap // 4)
+        dev = self.dev
+        self.f = torch.empty(cap, C, dtype=F32, device=dev)
+        self.c = torch.empty(cap, 2, dtype=F32, device=dev)
+        self.cells, self.cells_tok = torch.empty(cap, 2, dtype=I32, device=dev), torch.empty(cap, 2, dtype=I32, device=dev)
+        self.dims, self.count = torch.empty(2, dtype=I32, device=dev), torch.empty(1, dtype=I32, device=dev)
+        self.first, self.nxt, self.nz, self.pos = (torch.empty(cap, dtype=I32, device=dev) for _ in range(4))
+        self.sums = torch.empty(cap, C, dtype=F32, device=dev)
+        self.cap, self.C = cap, C
+        return True
+
+    def run(self, features: torch.Tensor, coords, patch_size_lv0, err: Optional[torch.Tensor]) -> int:
+        """Gridding of one slide (eager) -> token count (one host read-back, as device_tokens)."""
+        f = features.reshape(-1, features.shape[-1])
+        L, C = f.shape
+        c = (coords if torch.is_tensor(coords) else torch.as_tensor(np.asarray(coords))).reshape(-1, 2)
+        if c.shape[0] != L:
+            raise ValueError(f"coords has {c.shape[0]} rows for {L} patches")
+        self.f[:L].copy_(f, non_blocking=True)
+        self.c[:L].copy_(c.to(self.dev, non_blocking=True))
+        ops.titan_grid(self.c, L, float(patch_size_lv0), self.cells, self.dims, err)
+        ops.titan_cell_sums(self.f, self.cells, L, C, self.first, self.nxt, self.sums, self.nz)
+        ops.titan_token_order(self.cells, self.first, self.nz, L, self.pos, self.cells_tok, self.count)
+        Lv = int(self.count)
+        if Lv < 1:
+            raise ValueError("slide has no foreground cell")
+        self.L, self.Lv = L, Lv
+        return Lv
+
+    def tokens(self):
+        """Capturable half: gather the staged slide's tokens (fresh fp16 operand) -> (x16, cells [Lv, 2], dims, Lv)."""
+        x16 = torch.empty(self.Lv, self.C, dtype=H16, device=self.dev)
+        ops.titan_gather_tokens(self.sums, self.pos, self.L, self.C, x16)
+        return x16, self.cells_tok[:self.Lv], self.dims, self.Lv
+
+
 def device_tokens(features: torch.Tensor, coords, patch_size_lv0, err: Optional[torch.Tensor] = None):
     """The tokens of one slide without the H x W grid (csrc/titan.hip): occupied cells in row-major order, each the sum of its
     patches' features in patch order -- exactly the rows `x[bg_mask]` keeps of the reference's gridded tensor (TA:295-327,
@@ -676,8 +724,20 @@ class TitanEngine(Engine):
             raise ValueError("TITAN slide: non-finite / out-of-range coordinates, or a grid wider than 2049 cells (ALiBi tables)")
         super().check_inputs()
 
+    def stage_slide(self, x, coords, patch_size_lv0: int = 1024) -> int:
+        """Eager half of a hipGraph-replayed step: the slide's gridding into static buffers and the one host read-back -> token count
+        (the key of the captured geometry).  forward_slide(..., staged=True) continues from the token gather."""
+        if self.backbone is None or not self.native or self.backbone.embed_w is None:
+            raise NotImplementedError("hipGraph replay of the TITAN configuration needs the native backbone with its native embedding")
+        if getattr(self, "_grid_stage", None) is None:
+            self._grid_stage = GridStage(self.device)
+        x = x.reshape(-1, x.shape[-1])
+        if self._grid_stage.ensure(x.shape[0], x.shape[1]):
+            self.generation += 1            # captured graphs read the old buffers
+        return self._grid_stage.run(x.to(self.device), coords, patch_size_lv0, self._titan_err)
+
     def forward_slide(self, x, coords, genes, task_onehots, patch_size_lv0: int = 1024, need_grad: bool = True, fresh: bool = False,
-                      clinical=None, share: Optional[dict] = None) -> torch.Tensor:
+                      clinical=None, share: Optional[dict] = None, staged: bool = False) -> torch.Tensor:
         """x [1, L, C] tile embeddings, coords [1, L, 2] level-0 pixels (TA:329-353) -> logits [B, output_dim].
         share: see Engine.forward -- here the whole task-independent prologue (gridding, embedding, ALiBi tables) is reused by
         the later calls of one slide."""
@@ -687,13 +747,17 @@ class TitanEngine(Engine):
                                "MahmoodLab/TITAN snapshot> (its source is not part of ModalTune; parity unpinned)")
         B = int(task_onehots.shape[0])
         self._need = need_grad
-        x = x.to(self.device)
+        if not staged:
+            x = x.to(self.device)
         if share is not None and share.get("titan_B") == B:
             self._tok, self._plan, self._plan_keep = share["tok"], share["plan"], share["keep"]
             self._bias, self._mask = share.get("bias"), share.get("mask")
         elif self.native:
             if bb.embed_w is not None:
-                x16, cells, dims, Lv = device_tokens(x, coords, patch_size_lv0, self._titan_err)
+                if staged:          # stage_slide() has run the gridding: start at the token gather (capturable)
+                    x16, cells, dims, Lv = self._grid_stage.tokens()
+                else:
+                    x16, cells, dims, Lv = device_tokens(x, coords, patch_size_lv0, self._titan_err)
                 tok = bb.embed(x16, Lv)
             else:          # the module's own embedding (dense grid), then the cells of the kept tokens
                 fg, cg, bgm = preprocess_features(x, coords, patch_size_lv0)

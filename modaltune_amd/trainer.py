@@ -141,9 +141,9 @@ class TrainStep:
             ops.rng_advance(eng.rng)          # a fresh set of dropout / DropPath masks per step
         target = self.project_text(text)
         eng.store.flat_grad.zero_()
-        if staged_geometry is None and hasattr(eng, "forward_slide"):      # TITAN configuration: gridding + backbone embed first
+        if hasattr(eng, "forward_slide"):      # TITAN configuration: gridding + backbone embed first (staged: gridding already done)
             logits = eng.forward_slide(x, coords, genes, self.onehots, patch_size_lv0=self.patch_size_lv0, need_grad=True,
-                                       clinical=clinical)
+                                       clinical=clinical, staged=staged_geometry is not None)
         elif staged_geometry is None:
             logits = eng.forward(x, coords, genes, self.onehots, need_grad=True, clinical=clinical)
         else:
@@ -217,9 +217,7 @@ class TrainStep:
         first.  With world_size > 1 the capture is cut where a gradient bucket becomes final: the reducer starts that
         bucket's all-reduce between two replays, and the optimiser graph runs after the wait."""
         eng = self.engine
-        if hasattr(eng, "forward_slide"):
-            raise NotImplementedError("the TITAN configuration runs the eager schedule (TrainStep.step): every slide has its own "
-                                      "token count, known only after the on-device gridding")
+        titan = hasattr(eng, "forward_slide")
         if not eng._caches_ready:
             eng._build_caches()
         x = x.reshape(-1, x.shape[-1])
@@ -233,7 +231,14 @@ class TrainStep:
             self._stext = torch.empty(tuple(text.shape), dtype=F32, device=self.dev)
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
             self._gcache.clear()
-        eng.stage_inputs(x, coords, B=B)          # (may grow the workspace: bumps eng.generation)
+        if titan:
+            # TITAN configuration: the gridding kernels and the one host read-back (the token count: every shape downstream depends
+            # on it) run eagerly; the captured part starts at the token gather and is keyed on (patches, TOKENS).
+            Lv = eng.stage_slide(x, coords, self.patch_size_lv0)
+            eng._workspace(B, Lv)                 # (may grow the workspace: bumps eng.generation)
+        else:
+            Lv = L
+            eng.stage_inputs(x, coords, B=B)      # (may grow the workspace: bumps eng.generation)
         self.reducer.wait_params()                # last step's sharded parameter all-gather ran under the staging above
         self._sgenes.copy_(gflat, non_blocking=True)
         self._stext.copy_(text, non_blocking=True)
@@ -245,11 +250,11 @@ class TrainStep:
                 e.segs = e.logits = None
             self._opt_graph = None
             self._ggen = eng.generation
-        key = (L, world, bool(eng.stochastic))
+        key = (L, Lv, world, bool(eng.stochastic))
         ent = self._gcache.get(key)
 
         def fwd_bwd():
-            self._fwd_bwd(None, None, self._sgenes, self._stext, self._sclin, staged_geometry=(B, L))
+            self._fwd_bwd(None, None, self._sgenes, self._stext, self._sclin, staged_geometry=(B, Lv))
 
         # Visit counts live OUTSIDE the LRU: on ragged data almost every slide has a new length, and a stream of one-off
         # lengths must neither evict the captured graphs of a hot geometry nor reset its count.

@@ -199,3 +199,42 @@ def test_titan_degenerate_slides(golden_dir):
                 outs.append(m(x=x.cuda(), coords=coords.cuda(), genes=genes, task_token=torch.eye(3)[2].cuda()))
         assert torch.isfinite(outs[0]).all(), name
         assert float((outs[0] - outs[1]).abs().max()) < 1e-3 * float(outs[1].abs().max()), name
+
+
+def test_titan_graph_replay_matches_eager_over_mixed_bag_lengths():
+    """TrainStep.step_graphed on the TITAN configuration: the gridding and the token-count read-back stay eager, the rest of the
+    step is captured per (patches, tokens) geometry and replayed.  Two engines with the same weights walk the same rotation of three
+    bag lengths -- one eagerly, one through step_graphed: same losses and the same parameters after every step up to the run-to-run noise of
+    the atomically accumulated weight gradients (dropout off), and the rotation's later visits are replays."""
+    from modaltune_amd.titan import NativeBackbone, TitanEngine, titan_model_config
+    from modaltune_amd.trainer import TrainStep
+    seed = 6
+    sizes = synth.toy_group_sizes()
+    engs, steps = [], []
+    for _ in range(2):
+        vit = titan_standin.VisionTransformer()
+        titan_standin.init_standin(vit, seed)
+        cfg = titan_model_config(dict(TITAN_JSON, drop_path_rate=0.0), 3, False, 6)
+        eng = TitanEngine(cfg, sizes, NativeBackbone(vit, "cuda"), "cuda")
+        eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed))
+        ts = TrainStep(eng, lr=1e-5)
+        ts.set_projector(synth.projector_state(seed))
+        engs.append(eng); steps.append(ts)
+    slides = []
+    for j, L in enumerate((900, 520, 1300)):
+        inp = synth.synth_inputs_titan(L, sizes, seed + j, grid=40)
+        slides.append((torch.from_numpy(inp["x"]).cuda().reshape(L, -1), torch.from_numpy(inp["coords"]).cuda().reshape(L, 2),
+                       [torch.from_numpy(a).cuda() for a in inp["genes"]], torch.from_numpy(inp["text"]).cuda()))
+    for i in range(12):
+        x, coords, genes, text = slides[i % 3]
+        le = float(steps[0].step(x, coords, genes, text, update=True))
+        lg = float(steps[1].step_graphed(x, coords, genes, text))
+        assert np.isfinite(le) and abs(le - lg) <= 1e-3 * abs(le), (i, le, lg)      # (fp32 atomics in the weight-gradient kernels: not bit-stable,
+        #                                                                                       and AdamW's first steps are +-lr per element)
+        a, b = engs[0].store.flat, engs[1].store.flat
+        # AdamW turns the sign of a near-zero gradient into a +-lr step: compare as test_two_adamw_steps_... does -- almost every
+        # element within a tenth of the distance the optimiser has moved it
+        far = float(((a - b).abs() > 0.1 * 1e-5 * (i + 1)).float().mean())
+        assert far < 1e-2, (i, far)
+    assert steps[1].graph_replays >= 3 and steps[1].eager_steps == 6      # two eager visits per bag length, then capture + replays
+    engs[1].check_inputs()
