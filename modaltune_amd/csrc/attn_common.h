@@ -295,10 +295,10 @@ struct StageRow {       // eight lanes per row
 
 }  // namespace
 
-// The backward's three kernels live in their own translation units (attn_bwd_q.hip, attn_bwd_kv.hip, attn_combine.hip): LLVM's
-// AMDGPU scheduling strategy is a per-module option (`-mllvm -amdgpu-sched-strategy=...`, __graft_entry__.py: FLAGS_PER_FILE) and
-// each kernel wants its own (tools/experiments/README.md, round 3: dQ -2.5 % under iterative-ilp, combine -7 % under max-ilp, the
-// dK/dV kernel only under the default).  mt_dilated_attn_bwd (attn.hip) calls these launchers.
+// The backward's three kernels live in their own translation units (attn_bwd_q.hip, attn_bwd_kv.hip, attn_combine.hip) so that each
+// can carry its own LLVM scheduling strategy (a per-module option: __graft_entry__.py, FLAGS_PER_FILE).  Measured after the split
+// (round 4): none of the strategies beats the default any more -- the table is empty; the units stay separate (13 s instead of 30 s to
+// rebuild one kernel).  mt_dilated_attn_bwd (attn.hip) calls these launchers.
 namespace mt_attn {
 // (C-ABI types only: the device-side Plan lives in each unit's anonymous namespace and has no linkage)
 void launch_bwd_kv(const mt_half* qkv, const mt_half* dmixed, const float* lse_tot, const float* delta_br, const MtDilatedPlan* plan, void* ws, hipStream_t s);
