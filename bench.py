@@ -30,9 +30,10 @@ CPU_REFERENCE = {"value": 0.0054, "unit": "slides/s", "cores": 8, "kind": "refer
                            "8-core build container: 185.6 s/slide (the reference cannot travel to the GPU box)"}
 # rocprofv3 --pmc passes of the dominant kernel cannot run inside this script (one counter group per run, gpurun refuses
 # tracing + PMC together): the committed summary file is parsed at run time instead of a literal
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_attn_bwd.txt")
-PMC_TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r02_pmc_hbm_attn_bwd.txt")
-PMC_TRAFFIC_DENSE = os.path.join(ROOT, "profiles", "r03_pmc_dense_attn.txt")      # tools/dense_microbench.py geometry: N = 4097, 3 passes
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_hbm_attn_bwd.txt")
+PMC_TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r03_pmc_hbm_attn_bwd.txt")
+PMC_TRAFFIC_DENSE = os.path.join(ROOT, "profiles", "r04_pmc_dense_attn.txt")
+PMC_TRAFFIC_DENSE_FALLBACK = os.path.join(ROOT, "profiles", "r03_pmc_dense_attn.txt")      # tools/dense_microbench.py geometry: N = 4097, 3 passes
 
 
 def parse_args():
@@ -364,7 +365,7 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
     achieved = kv_flops / (ms / n_l * 1e-3) / 1e12
     # HBM traffic of that kernel from the committed PMC summary: measured at N = 4097 tokens (the microbenchmark's geometry), which
     # is this run's mean bag; per launch like `achieved`
-    traffic, traffic_file = recorded_traffic("dense_attn_bwd_kv_kernel", 0, 0, paths=(PMC_TRAFFIC_DENSE,))
+    traffic, traffic_file = recorded_traffic("dense_attn_bwd_kv_kernel", 0, 0, paths=(PMC_TRAFFIC_DENSE, PMC_TRAFFIC_DENSE_FALLBACK))
     table = []
     for key, mult in (("dense_attn_fwd", 1.0), ("dense_attn_bwd_kv", 2.0), ("dense_attn_bwd_q", 1.5)):
         if key in summ:
@@ -501,7 +502,7 @@ def _brief(rec):
     return {k: rec[k] for k in keep if k in rec}
 
 
-def leg_pcie(ts, eng, sizes, L, resident_value, steps=12):
+def leg_pcie(ts, eng, sizes, L, resident_value, steps=20):
     """The same train step with the slide arriving as the reference hands it over (train_modaltune.py:198-210): fp32 features
     [L, 1536] in HOST memory -> pinned staging -> async H2D on a copy stream -> fp16 cast on the device, one case ahead
     (modaltune_amd.data.CasePrefetcher), hipGraph replay.  Never the headline `value`."""
@@ -517,7 +518,7 @@ def leg_pcie(ts, eng, sizes, L, resident_value, steps=12):
         for i in range(n):
             yield host[i % len(host)]
     r0 = ts.graph_replays
-    for s in data.CasePrefetcher(stream(3)):
+    for s in data.CasePrefetcher(stream(4)):
         ts.step_graphed(s.x, s.coords, s.genes, s.text)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -526,7 +527,7 @@ def leg_pcie(ts, eng, sizes, L, resident_value, steps=12):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"metric": "slides/sec (train step), slide streamed from host memory per step (fp32 features, PCIe-inclusive)", "value": 1.0 / dt,
-            "unit": "slides/s", "steps": steps, "warmup": 3, "ms_per_step": 1e3 * dt, "host_bytes_per_slide": L * 1536 * 4,
+            "unit": "slides/s", "steps": steps, "warmup": 4, "ms_per_step": 1e3 * dt, "host_bytes_per_slide": L * 1536 * 4,
             "vs_resident": (1.0 / dt) / resident_value, "graph_replays": ts.graph_replays - r0,
             "how": "CasePrefetcher: pinned staging, H2D on a copy stream one case ahead of the running step, fp32 -> fp16 cast on the device"}
 

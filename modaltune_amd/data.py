@@ -86,6 +86,16 @@ class StagedCase:
         self.x, self.coords, self.genes, self.text, self.clinical, self.case_id, self.ready = x, coords, genes, text, clinical, case_id, ready
 
 
+def _host_copy(dst: torch.Tensor, src: torch.Tensor):
+    """Pageable -> pinned staging copy on the CALLING thread (one memcpy through numpy).  torch's own CPU copy fans a 61 MB slide out over
+    every core the machine reports (128 OpenMP threads on a GPU box whose cgroup grants 16): the workers then spin on the cores the launch
+    thread needs, and the step that should hide the staging got 3-6 ms longer (tools/pipeline_bench.py: 45-48 ms against 42.5 resident)."""
+    if src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous() and not src.requires_grad:
+        np.copyto(dst.numpy(), src.numpy())
+    else:
+        dst.copy_(src)
+
+
 class CasePrefetcher:
     """Iterates host-side cases `{features|x, coords, genes, text, clinical?, case_id?}` and yields them resident in HBM
     (x as fp16 [L, C]) with the NEXT case's upload already in flight.  `depth` staging slots; every slot owns its pinned
@@ -111,14 +121,14 @@ class CasePrefetcher:
                 pin = self._pinned[slot]
                 if pin is None or pin.numel() < n or pin.dtype != torch.float16:
                     pin = self._pinned[slot] = torch.empty(n, dtype=torch.float16).pin_memory()
-                pin[:n].copy_(feats.reshape(-1))
+                _host_copy(pin[:n], feats.reshape(-1))
                 x = torch.empty(L, C, dtype=torch.float16, device=self.device)
                 x.view(-1).copy_(pin[:n], non_blocking=True)
             else:
                 pin = self._pinned[slot]
                 if pin is None or pin.numel() < n or pin.dtype != torch.float32:
                     pin = self._pinned[slot] = torch.empty(n, dtype=torch.float32).pin_memory()
-                pin[:n].copy_(feats.reshape(-1))
+                _host_copy(pin[:n], feats.reshape(-1))
                 d32 = self._dev32[slot]
                 if d32 is None or d32.numel() < n:
                     d32 = self._dev32[slot] = torch.empty(n, dtype=torch.float32, device=self.device)

@@ -27,8 +27,8 @@ tiles = s[:, 7]
 plain = tiles * (S - 12)                     # plain slices per workgroup (the stamped ones)
 names = ["vmcnt wait", "barrier", "48 MFMAs + riders", "-", "-", "stamp cost"]
 per = s[:, :6] / plain[:, None]
-print(f"N={N} K={K}: tiles/WG min {tiles.min():.0f} max {tiles.max():.0f}; s_memtime ticks (100 MHz) per plain slice, mean over workgroups:")
+print(f"N={N} K={K}: tiles/WG min {tiles.min():.0f} max {tiles.max():.0f}; s_memtime ticks (= core-clock cycles) per plain slice, mean over workgroups:")
 for i, n in enumerate(names):
     print(f"  {n:22s} {per[:, i].mean():8.2f}  (min {per[:, i].min():.2f} max {per[:, i].max():.2f})")
 tot = per[:, :3].sum(1) - 3 * per[:, 5]
-print(f"  slice total (stamps subtracted) {tot.mean():.2f} ticks = {tot.mean() * 10:.0f} ns; kernel {s[:, 6].max() / 100:.1f} us; MFMA floor 768 cycles")
+print(f"  slice total (stamps subtracted) {tot.mean():.2f} cycles; whole kernel {s[:, 6].max():.0f} cycles; MFMA floor 768 cycles per slice")
