@@ -69,6 +69,12 @@ MT_DEVINL unsigned long long ps_now() {
 #define PS_ACC(slot, a, b)
 #endif
 
+#ifdef PS_GELU_EPI    // TIMING ONLY (tools/experiments): erf-GELU applied where the finished tile is converted -- what folding the FFN's
+#define PS_OUT(x) gelu_erf(x)      // activation into fc1 would cost inside this kernel
+#else
+#define PS_OUT(x) (x)
+#endif
+
 template <int N> MT_DEVINL void ps_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 MT_DEVINL void ps_barrier() { asm volatile("s_barrier" ::: "memory"); }
 // one LDS-DMA piece: 64 lanes x 16 B from (descriptor base + per-lane voff + uniform soff) to LDS bytes [dst, dst + 1024); lanes whose
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        held[i0 + r][j] = (h16x4){(h16)acc[i0 + r][j][0], (h16)acc[i0 + r][j][1], (h16)acc[i0 + r][j][2], (h16)acc[i0 + r][j][3]};
+        held[i0 + r][j] = (h16x4){(h16)PS_OUT(acc[i0 + r][j][0]), (h16)PS_OUT(acc[i0 + r][j][1]), (h16)PS_OUT(acc[i0 + r][j][2]), (h16)PS_OUT(acc[i0 + r][j][3])};
   };
 
   // ---- prologue: slices 0, 1, 2 in flight; slice 0 awaited and published; its first fragments fetched
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (MODE == 2) {
           if (n >= 16) {
             const int ci = (n - 16) >> 3, cj = (n - 16) & 7;
-            held[ci][cj] = (h16x4){(h16)acc[ci][cj][0], (h16)acc[ci][cj][1], (h16)acc[ci][cj][2], (h16)acc[ci][cj][3]};
+            held[ci][cj] = (h16x4){(h16)PS_OUT(acc[ci][cj][0]), (h16)PS_OUT(acc[ci][cj][1]), (h16)PS_OUT(acc[ci][cj][2]), (h16)PS_OUT(acc[ci][cj][3])};
           }
         }
         __builtin_amdgcn_sched_barrier(0);
