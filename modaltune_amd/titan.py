@@ -15,8 +15,9 @@ The TITAN snapshot's source and weights (HF MahmoodLab/TITAN @ b2fb4f47, utils/c
 tree: its arithmetic cannot be restated from source, so BACKBONE PARITY IS UNPINNED against the real snapshot.  What replaces the
 pin: `NativeBackbone` reads the structure off the module the user supplies, derives the ALiBi slopes from the module's own
 `get_alibi`, and at construction runs every native piece (embedding, each block, pooling) against that module's torch code on a
-probe slide; anything that does not reproduce it falls back -- loudly (`warnings.warn`, `backbone_impl` says which) -- to
-`TorchBackbone`: the module's own torch code between our kernels, gradients by `torch.autograd.grad` on the recorded call.
+probe slide; anything that does not reproduce it RAISES (`backbone_impl="native"`, the default since round 4).  The module's own
+torch code between our kernels (`TorchBackbone`, gradients by `torch.autograd.grad` on the recorded call) is an explicit opt-in:
+`backbone_impl="torch"`, or "auto" (native, else torch with a `warnings.warn` naming the reason).
 tests/test_titan_gpu.py pins the adapter flow against the REFERENCE's titan_adapter.py run on a stand-in backbone
 (tests/golden/titan_standin.py) with either implementation of the frozen blocks.
 
@@ -870,7 +871,8 @@ def make_backbone(vit: Optional[nn.Module], device, impl: str = "auto"):
         return NativeBackbone(vit, device)
     except Unsupported as e:
         if impl == "native":
-            raise
+            raise Unsupported(f"{e} -- pass backbone_impl=\"torch\" to run the module's own blocks between the HIP kernels (slower; "
+                              f"the adapter side is unaffected)") from e
         warnings.warn(f"modaltune_amd.titan: the supplied backbone runs as its own torch code between the HIP kernels "
                       f"(NativeBackbone: {e})")
         return TorchBackbone(vit)
@@ -881,13 +883,16 @@ class TITANGeneAdapter(LongNetGeneAdapter):
     """Drop-in for the reference's TITANGeneAdapter (TA:42-438): same registry name, ctor kwargs (keys of
     model_configs/modaltune_titan_config.json + gene_group_defination, multi_task), forward signature
     (x, coords, genes, task_token, patch_size_lv0), `is_multi`.  `backbone`: the TITAN VisionTransformer instance
-    (required to run; see the module docstring); `backbone_impl`: "auto" | "native" | "torch" (`.backbone_impl` afterwards says
+    (required to run; see the module docstring); `backbone_impl`: "native" (default since round 4: the frozen blocks run on the HIP
+    kernels, and a module the native path does not implement or reproduce RAISES, saying which check failed -- no silent second
+    path), "torch" (explicit opt-in: the module's own torch code between our kernels), "auto" (native, else torch with a warning);
+    `.backbone_impl` afterwards says
     which one runs).  state_dict holds the adapter-side keys under the reference's names; the backbone's own tensors are exposed
     un-prefixed after them, as in the reference (which inherits from the backbone)."""
     CLINICAL = False
 
     def __init__(self, gene_group_defination: Dict[Any, Sequence[str]] = None, multi_task: int = 1, backbone: Optional[nn.Module] = None,
-                 device="cuda", backbone_impl: str = "auto", init_seed: Optional[int] = None, **kwargs):
+                 device="cuda", backbone_impl: str = "native", init_seed: Optional[int] = None, **kwargs):
         nn.Module.__init__(self)
         gene_group_defination = gene_group_defination or {}
         self.backbone_source = "backbone= argument"
