@@ -84,25 +84,39 @@ class ModelConfig:
         return self.multi_task > 1
 
     @property
-    def num_tokens(self) -> int:           # T = final_groups + task token (+ clinical token) (longvit_adapter.py:152-154,475-477)
-        return self.gene.final_groups + int(self.is_multi) + int(self.clinical)
+    def has_gene_cls(self) -> bool:        # prompt_agg == "cls": a learned token in front of the gene tokens (longvit_adapter.py:146,259-261)
+        return self.prompt_agg == "cls"
+
+    @property
+    def num_tokens(self) -> int:           # T = final_groups (+ gene_cls) + task token (+ clinical token) (longvit_adapter.py:146-154,470-477)
+        return self.gene.final_groups + int(self.has_gene_cls) + int(self.is_multi) + int(self.clinical)
+
+    @property
+    def first_interaction_layer(self) -> int:   # layers below it run on the embedded slide before any adapter (longvit_adapter.py:269-281)
+        return int(self.interaction_indexes[0][0])
 
     def validate(self):
         if self.embed_dim != 768 or self.head_dim != 48:
             raise ValueError("the HIP path is built for the Prov-GigaPath geometry (768-d, 16 heads x 48)")
-        if self.prompt_agg != "avg" or self.token_agg not in ("sum", "cat"):
-            raise NotImplementedError("prompt_agg must be 'avg'; token_agg 'sum' or 'cat'")
-        if not (self.with_cffn and self.use_prompt_sa and self.add_prompt_feature and self.freeze_vit):
-            raise NotImplementedError("only the shipped ModalTune configuration family is supported")
-        if self.interaction_indexes[0][0] != 0:
-            raise NotImplementedError("interaction_indexes must start at layer 0 (both shipped configs do)")
-        last = -1
+        if self.prompt_agg not in ("avg", "cls") or self.token_agg not in ("sum", "cat"):
+            raise NotImplementedError("prompt_agg must be 'avg' or 'cls'; token_agg 'sum' or 'cat' (the reference raises for anything else too)")
+        if not self.add_prompt_feature:
+            raise ValueError("add_prompt_feature=False: the reference's own forward fails on this configuration (`outcome` is only bound "
+                             "inside `if self.add_prompt_feature`, longvit_adapter.py:315-346): there is no behaviour to reproduce")
+        if not self.with_cffn:
+            raise NotImplementedError("with_cffn=False widens the adapter attention to 768 (12 heads x 64): the adapter kernels are built "
+                                      "for cffn_ratio 0.25 (12 x 16), as in both shipped ModalTune configurations")
+        if not self.freeze_vit:
+            raise NotImplementedError("freeze_vit=False: the backbone's weight gradients are not computed (selective backward)")
+        last = self.first_interaction_layer - 1
+        if last < -1:
+            raise ValueError("interaction_indexes must start at a layer >= 0")
         for a, b in self.interaction_indexes:
             if a != last + 1 or b < a:
                 raise ValueError("interaction_indexes must tile the layers contiguously")
             last = b
         if last != self.depth - 1:
-            raise ValueError("interaction_indexes must cover all layers")
+            raise ValueError("interaction_indexes must cover the layers up to depth - 1")
 
     @staticmethod
     def from_json(path_or_dict, **overrides) -> "ModelConfig":

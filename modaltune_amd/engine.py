@@ -357,6 +357,8 @@ class Engine:
                 sp[f"{st}_{l}"] = (F32, (M, 2))
         for i in range(len(cfg.interaction_indexes)):
             sp[f"hout{i}"] = (F32, (M, D))
+        if cfg.first_interaction_layer > 0:
+            sp["hpre"] = (F32, (M, D))          # [cls; patches] after the plain layers in front of the first interaction (LVA:269-281)
         # transients shared by all layers
         for nm in ("u16", "br16", "dy16", "dh16", "dmixed"):
             sp[nm] = (H16, (M, D))
@@ -438,6 +440,20 @@ class Engine:
                 ws["x0d"] = torch.empty(B * L, D, dtype=F32, device=dev)
             ops.dropout_f32(ws["x0"], ws["x0d"], B * L, D, d_in, xmap=rowmap(L, 0, 0))
             src, src_map = ws["x0d"], rowmap(L, L, 0)
+        a0 = cfg.first_interaction_layer
+        if a0 > 0:
+            # interaction_indexes[0][0] != 0 (LVA:269-281): the layers below the first interaction run on [cls; embedded slide] as plain
+            # backbone layers.  Nothing trainable sits in front of them, so they run forward-only (no tape entries); with Dropout /
+            # DropPath on, every task pass draws its own masks there too.
+            hin0 = ws["hin0"]
+            ops.copy_rows(self._cls_source().view(1, D), hin0, B, D, smap=rowmap(1, 0, 0), dmap=rowmap(1, N, 0))
+            ops.copy_rows(src, hin0, B * L, D, smap=src_map, dmap=patch_map)
+            grad_was, tape.grad_enabled = tape.grad_enabled, False
+            pend = None
+            for l in range(a0):
+                pend = self._layer(l, ws[f"hin{l + 1}"] if l < a0 - 1 else ws["hpre"], pend, defer=(l < a0 - 1))
+            tape.grad_enabled = grad_was
+            src, src_map = ws["hpre"], patch_map
         for i, (la, lb) in enumerate(cfg.interaction_indexes):
             # Everything recorded from here on belongs to interaction block i (and the blocks above): when the backward
             # reaches this marker, the gradients of interactions.{i}.* / prompt_selfattention.{i}.* (and of the head, for the
@@ -448,7 +464,9 @@ class Engine:
                 c = self._prompt_self_attention(c, pe, f"prompt_selfattention.{i}.")
             hin = ws[f"hin{la}"]
             # cls row of every pass: cls_token (+ pos_embed[0] = 0) for block 0, else carried from the previous block
-            if i == 0:
+            if i == 0 and a0 > 0:
+                ops.copy_rows(ws["hpre"], hin, B, D, smap=rowmap(1, N, 0), dmap=rowmap(1, N, 0))
+            elif i == 0:
                 ops.copy_rows(self._cls_source().view(1, D), hin, B, D, smap=rowmap(1, 0, 0), dmap=rowmap(1, N, 0))
             else:
                 ops.copy_rows(ws[f"hout{i - 1}"], hin, B, D, smap=rowmap(1, N, 0), dmap=rowmap(1, N, 0))
@@ -493,13 +511,24 @@ class Engine:
         ctx, tape, D = self._ctx, self.tape, self.cfg.embed_dim
         B, N, ws = ctx["B"], ctx["N"], ctx["ws"]
         cls = Var(tape.new(B, D))
-        ops.copy_rows(hout, cls.data, B, D, smap=rowmap(1, N, 0))
+        if self.cfg.global_pool:             # img_outcome = x.mean(dim=1) over the PATCH rows (LVA:309-310; x excludes cls there)
+            L = N - 1
+            w = torch.full((L,), 1.0 / L, dtype=F32, device=self.device)
+            ops.sgemm(w, (0, 1), hout.view(-1)[D:], (1, D), cls.data, (D, 1), 1, D, L, batch=B, b_bs=N * D, c_bs=D)
+        else:
+            ops.copy_rows(hout, cls.data, B, D, smap=rowmap(1, N, 0))
 
         def bwd():
             dh = ws["dh"]
-            dh.zero_()                       # start of the patch-side backward: only the cls rows carry gradient
+            dh.zero_()                       # start of the patch-side backward: only the cls rows (or, pooled, every patch row) carry gradient
             ctx["dh16_valid"] = False
-            if cls.grad is not None:
+            if cls.grad is None:
+                return
+            if self.cfg.global_pool:         # d x[b, l, :] = d img[b, :] / L
+                L = N - 1
+                w = torch.full((L,), 1.0 / L, dtype=F32, device=self.device)
+                ops.sgemm(w, (1, 0), cls.grad, (1, 0), dh.view(-1)[D:], (D, 1), L, D, 1, accumulate=True, batch=B, b_bs=D, c_bs=N * D)
+            else:
                 ops.copy_rows(cls.grad, dh, B, D, dmap=rowmap(1, N, 0))
         tape.record(bwd)
         return cls
@@ -634,8 +663,11 @@ class Engine:
         B = onehots.shape[0]
         G64 = gene.data.shape[1]
         c = Var(tape.new(B, T, D))
-        nt, ncl = int(self.cfg.is_multi), int(self.cfg.clinical)
+        nt, ncl, ngc = int(self.cfg.is_multi), int(self.cfg.clinical), int(self.cfg.has_gene_cls)
         task = clin = None
+        gcls = P("gene_cls") if ngc else None      # prompt_agg == "cls": a learned token in front of the gene tokens (LVA:259-261)
+        if ngc:
+            ops.copy_rows(gcls.data.view(1, D), c.data, B, D, smap=rowmap(1, 0, 0), dmap=rowmap(1, T, ncl + nt))
         if ncl:
             if clinical is None:
                 raise ValueError("this model variant needs `clinical` features [1, clinfeat_dim]")
@@ -653,7 +685,7 @@ class Engine:
         assert Pg in (1, B)
         gsrc = gene.data.view(G64 * Pg, D)
         for b in range(B):                   # rows (g, b) of the pathway-major gene tokens -> pass b's gene slots
-            ops.copy_rows(gsrc, c.data[b], G64, D, smap=rowmap(1, Pg, b if Pg > 1 else 0), dmap=rowmap(G64, T, ncl + nt))
+            ops.copy_rows(gsrc, c.data[b], G64, D, smap=rowmap(1, Pg, b if Pg > 1 else 0), dmap=rowmap(G64, T, ncl + nt + ngc))
 
         def bwd():
             if c.grad is None:
@@ -662,8 +694,10 @@ class Engine:
                 ops.copy_rows(c.grad, task.g(), B, D, smap=rowmap(1, T, ncl), accumulate=True)
             gg = gene.g().view(G64 * Pg, D)
             for b in range(B):      # d gene tokens of pass b (summed over the passes when they share one encoder pass)
-                ops.copy_rows(c.grad, gg, G64, D, smap=rowmap(G64, T, b * T + ncl + nt), dmap=rowmap(1, Pg, b if Pg > 1 else 0),
+                ops.copy_rows(c.grad, gg, G64, D, smap=rowmap(G64, T, b * T + ncl + nt + ngc), dmap=rowmap(1, Pg, b if Pg > 1 else 0),
                               accumulate=True)
+                if gcls is not None and gcls.grad is not None:
+                    ops.copy_rows(c.grad, gcls.grad.view(1, D), 1, D, smap=rowmap(1, T, b * T + ncl + nt), accumulate=True)
                 if clin is not None:
                     ops.copy_rows(c.grad, clin.g(), 1, D, smap=rowmap(1, T, b * T), accumulate=True)
         tape.record(bwd)
@@ -897,13 +931,15 @@ class Engine:
     def _head(self, c: Var, hout: torch.Tensor) -> Var:
         cfg, ctx, tape, P = self.cfg, self._ctx, self.tape, self.store.param
         B, N, D, T, ws = ctx["B"], ctx["N"], cfg.embed_dim, self.T, ctx["ws"]
-        nt, ncl = int(cfg.is_multi), int(cfg.clinical)
-        off = ncl + nt                              # token order: [clinical], [task], genes (LVA:572-580)
-        G64 = T - off
+        nt, ncl, ngc = int(cfg.is_multi), int(cfg.clinical), int(cfg.has_gene_cls)
+        off = ncl + nt                              # token order: [clinical], [task], [gene_cls], genes (LVA:259-266,572-580)
+        G64 = T - off - ngc
         cls = self._image_token(hout)
         gene = Var(tape.new(B, D))
-        # mean over the gene tokens: gene[b, d] = sum_t (1/G64) c[b, off + t, d]
-        ops.sgemm(self._mean_w, (0, 1), c.data[:, off:], (1, D), gene.data, (D, 1), 1, D, G64, batch=B, b_bs=T * D, c_bs=D)
+        if ngc:                                     # prompt_agg "cls": the gene_cls slot is the gene outcome (LVA:316-320 / 620-629)
+            ops.copy_rows(c.data, gene.data, B, D, smap=rowmap(1, T, off))
+        else:       # "avg": mean over the gene tokens: gene[b, d] = sum_t (1/G64) c[b, off + t, d]
+            ops.sgemm(self._mean_w, (0, 1), c.data[:, off:], (1, D), gene.data, (D, 1), 1, D, G64, batch=B, b_bs=T * D, c_bs=D)
         task = clin = None
         if nt:
             task = Var(tape.new(B, D))
@@ -914,7 +950,9 @@ class Engine:
 
         def bwd_gather():
             cg = c.g()
-            if gene.grad is not None:   # dc[b, off + t, :] += dgene[b, :] / G64
+            if gene.grad is not None and ngc:
+                ops.copy_rows(gene.grad, cg, B, D, dmap=rowmap(1, T, off), accumulate=True)
+            elif gene.grad is not None:   # dc[b, off + t, :] += dgene[b, :] / G64
                 ops.sgemm(self._mean_w, (1, 0), gene.grad, (1, 0), cg[:, off:], (D, 1), G64, D, 1, accumulate=True, batch=B,
                           b_bs=D, c_bs=T * D)
             if task is not None and task.grad is not None:

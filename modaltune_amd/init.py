@@ -66,7 +66,7 @@ def _family(key: str, kind: str) -> str:
         return kind
     if key == "cls_token":
         return "normal"
-    if key == "gene_pe":
+    if key in ("gene_pe", "gene_cls"):       # nn.init.trunc_normal_(std=0.02) (longvit_adapter.py:149,182)
         return "trunc"
     if key.startswith("interactions.") and ".attn." in key:
         return "xavier" if kind == "w" else "zero"

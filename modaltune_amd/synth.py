@@ -57,6 +57,8 @@ def param_specs(cfg: ModelConfig, group_sizes: Sequence[int]) -> List[Tuple[str,
         s.extend((k, sh, kind, trainable) for k, sh, kind in items)
 
     add([("cls_token", (1, 1, D), "tok")], False)
+    if cfg.has_gene_cls:                     # prompt_agg == "cls" (longvit_adapter.py:146-149)
+        add([("gene_cls", (1, 1, D), "tok")], True)
     add([("gene_pe", (T, D), "tok")], True)
     add([("patch_embed.proj.weight", (D, cfg.in_chans), "w"), ("patch_embed.proj.bias", (D,), "b")], False)
     for l in range(cfg.depth):
@@ -83,7 +85,7 @@ def param_specs(cfg: ModelConfig, group_sizes: Sequence[int]) -> List[Tuple[str,
         if i == nint - 1 and cfg.use_extra_extractor:
             for j in range(2):
                 add(_extractor_keys(p + f"extra_extractors.{j}.", D, E), True)
-    for i in range(1, nint):
+    for i in range(1, nint if cfg.use_prompt_sa else 1):      # (use_prompt_sa False: Identity_mod, no parameters)
         p = f"prompt_selfattention.{i}."
         add([(p + "q_proj.weight", (E, D), "w"), (p + "q_proj.bias", (E,), "b"),
              (p + "output_proj.weight", (D, E), "w"), (p + "output_proj.bias", (D,), "b"),

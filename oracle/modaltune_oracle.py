@@ -301,6 +301,9 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token
     x = x + pos_embed_rows(coords, cfg.embed_dim, cfg.slide_ngrids, x.dtype)             # LVA:235-237
     cls = sd["cls_token"] + 0.0                                                          # + pos_embed[0] == zeros
     c = gene_encoder(genes, sd, depth=cfg.gene.depth)                                    # LVA:257
+    ngc = int(getattr(cfg, "prompt_agg", "avg") == "cls")
+    if ngc:                                                                              # LVA:259-261: learned token in front of the gene tokens
+        c = torch.cat((sd["gene_cls"], c), dim=1)
     if cfg.is_multi:                                                                     # LVA:263-266
         t = _ln(_linear(task_token.unsqueeze(0), sd, "task_weight.0"), sd, "task_weight.1")
         c = torch.cat((t.unsqueeze(0), c), dim=1)
@@ -311,6 +314,12 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token
     pe = sd["gene_pe"]
     if taps is not None:
         taps["x0"] = x.detach().clone(); taps["c0"] = c.detach().clone()
+    a0 = int(cfg.interaction_indexes[0][0])
+    if a0 != 0:                                                                          # LVA:269-281: plain backbone layers first
+        h = torch.cat((cls, x), dim=1)
+        for l in range(a0):
+            h = encoder_layer(h, sd, f"encoder.layers.{l}", seg_lengths, ratios)
+        cls, x = h[:, :1], h[:, 1:]
     for i, (a, b) in enumerate(cfg.interaction_indexes):                                 # LVA:294-307
         if i > 0 and cfg.use_prompt_sa:
             c = prompt_self_attention(c, pe, sd, f"prompt_selfattention.{i}", heads)
@@ -327,12 +336,13 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token
             taps[f"cls{i}"] = cls.detach().clone(); taps[f"c{i}"] = c.detach().clone()
             taps[f"x{i}_head"] = x[:, :8].detach().clone()
     nt = int(cfg.is_multi)
-    clin_out, task_out = c[:, :ncl], c[:, ncl:ncl + nt]                                  # LVA:321-325 / 632-641
-    gene_out = c[:, ncl + nt:].mean(dim=1, keepdim=True)
+    img = x.mean(dim=1).unsqueeze(0) if getattr(cfg, "global_pool", False) else cls      # LVA:309-312 (x: the patch rows, cls excluded)
+    clin_out, task_out = c[:, :ncl], c[:, ncl:ncl + nt]                                  # LVA:315-325 / 620-641
+    gene_out = c[:, ncl + nt:ncl + nt + 1] if ngc else c[:, ncl + nt:].mean(dim=1, keepdim=True)
     if cfg.token_agg == "sum":
-        out = cls + gene_out + (task_out if nt else 0) + (clin_out if ncl else 0)
+        out = img + gene_out + (task_out if nt else 0) + (clin_out if ncl else 0)
     else:
-        parts = [cls] + ([task_out] if nt else []) + [gene_out] + ([clin_out] if ncl else [])
+        parts = [img] + ([task_out] if nt else []) + [gene_out] + ([clin_out] if ncl else [])
         out = torch.cat(parts, dim=-1)
     out = _ln(out, sd, "final_norm")
     return _linear(out.squeeze(1), sd, "final_project")

@@ -253,7 +253,7 @@ GRAD_KEYS_FULL = ["interactions.0.injector.gamma", "interactions.1.injector.gamm
 
 
 def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32), ngrids=128, time_it=False, clinical=False,
-               token_agg=None, multi_task=3, adamw_steps=0, lr=1e-3):
+               token_agg=None, multi_task=3, adamw_steps=0, lr=1e-3, extra=None):
     """multi_task: width of the task one-hot (3: train_modaltune.py; 4: train_modaltune_pancancer.py:537-542, task ids 0..2
     either way; 1: the single-task path, one model call, TM:172-179).  adamw_steps > 0: after the backward, take that many
     torch.optim.AdamW steps exactly as the trainer does (TM:139-149,235-238; no GradScaler on the CPU) and record the
@@ -262,6 +262,8 @@ def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32
     cfg_kw.update(depth=depth, interaction_indexes=inter, slide_ngrids=ngrids, pretrained=False)
     if token_agg:
         cfg_kw["token_agg"] = token_agg
+    if extra:      # config branches outside the two shipped JSONs: prompt_agg "cls", use_prompt_sa False, global_pool True, ...
+        cfg_kw.update(extra)
     cfg = ModelConfig.from_json(cfg_kw, multi_task=multi_task, clinical=clinical)
     sizes = synth.toy_group_sizes(6)
     groups = {i: ["g"] * n for i, n in enumerate(sizes)}
@@ -269,7 +271,7 @@ def model_case(name, L, depth, inter, seed, dtypes=(torch.float64, torch.float32
     inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
     psd = synth.projector_state(seed)
     out = {"L": L, "depth": depth, "inter": np.array(inter), "seed": seed, "ngrids": ngrids, "sizes": np.array(sizes),
-           "clinical": int(clinical), "token_agg": cfg.token_agg, "multi_task": multi_task}
+           "clinical": int(clinical), "token_agg": cfg.token_agg, "multi_task": multi_task, "extra_cfg": json.dumps(extra or {})}
     for dt in dtypes:
         tag = "f64" if dt == torch.float64 else "f32"
         model = Aggregator.create("longnetvit_gene_clinical_adapter" if clinical else "longnetvit_gene_adapter",
@@ -474,6 +476,14 @@ if __name__ == "__main__":
     if "titan" in which:   # TITAN configuration (BASELINE config 4 family) on the stand-in backbone
         titan_case("titan_L300", 300, seed=21)
         titan_case("titan_L170_clin", 170, seed=22, clinical=True, grid=16)
+    if "branches" in which or "branches2" in which:   # reference config branches outside the shipped JSONs (longvit_adapter.py:146,259-261,269-281,309-320)
+        if "branches2" not in which:
+            model_case("L37_d3_cls", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=31, dtypes=(torch.float64,),
+                       extra=dict(prompt_agg="cls", use_prompt_sa=False))
+        model_case("L37_d6_pre_gp", 37, 6, [[2, 2], [3, 4], [5, 5]], seed=32, dtypes=(torch.float64,), token_agg="cat",
+                   extra=dict(global_pool=True))
+        model_case("L37_d3_clin_cls", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=33, dtypes=(torch.float64,), clinical=True, token_agg="cat",
+                   extra=dict(prompt_agg="cls"))
     if "pan" in which:    # pan-cancer trainer shape: one-hot width 4, task ids 0..2 (train_modaltune_pancancer.py:50-134,537-542)
         model_case("L37_d3_pan", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=17, multi_task=4)
         model_case("L129_d3_pan", 129, 3, [[0, 0], [1, 1], [2, 2]], seed=18, multi_task=4, dtypes=(torch.float64,))

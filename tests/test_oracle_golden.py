@@ -1,5 +1,6 @@
 """Pins the CPU oracle (oracle/modaltune_oracle.py) against golden vectors produced by running the
 reference itself (tests/golden/make_golden.py).  CPU only."""
+import json
 import os
 
 import numpy as np
@@ -101,7 +102,8 @@ def _run_model_case(path, dtype):
     cfg = ModelConfig(depth=depth, interaction_indexes=tuple(tuple(int(i) for i in p) for p in g["inter"]),
                       slide_ngrids=ngrids, clinical=bool(int(g["clinical"])) if "clinical" in g.files else False,
                       token_agg=str(g["token_agg"]) if "token_agg" in g.files else "sum",
-                      multi_task=int(g["multi_task"]) if "multi_task" in g.files else 3)
+                      multi_task=int(g["multi_task"]) if "multi_task" in g.files else 3,
+                      **(json.loads(str(g["extra_cfg"])) if "extra_cfg" in g.files else {}))
     cfg.validate()
     sd = _sd(cfg, sizes, seed, dtype)
     inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
@@ -117,7 +119,7 @@ def _run_model_case(path, dtype):
 
 
 @pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L512_d12", "L37_d3_clin", "L37_d3_clin_cat", "L37_d3_cat",
-                                  "L37_d3_pan", "L129_d3_pan", "L37_d3_single"])
+                                  "L37_d3_pan", "L129_d3_pan", "L37_d3_single", "L37_d3_cls", "L37_d6_pre_gp", "L37_d3_clin_cls"])
 def test_full_train_step_f64(golden_dir, name):
     path = os.path.join(golden_dir, f"model_{name}.npz")
     if not os.path.exists(path):
