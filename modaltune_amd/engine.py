@@ -14,6 +14,7 @@ through all frozen layers, weight gradients exist only for adapter / gene / head
 from __future__ import annotations
 
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -184,9 +185,33 @@ class Engine:
         self._fresh_pool: Dict[int, list] = {}      # B -> free workspace stores of the module API's per-call workspaces
         dpr = np.linspace(0.0, float(cfg.drop_path_rate), cfg.depth) if cfg.depth > 1 else np.zeros(1)
         self._layer_path_p = [float(v) for v in dpr]          # ENC:37-41
+        self.leaf_stream = os.environ.get("MT_LEAF_STREAM", "0") == "1"
+        self._side, self._side_refs, self._side_busy = None, [], False
 
     def _bump_generation(self):
         self.generation += 1
+
+    # -- weight-gradient LEAVES of the adapters' big-M linears (mt_gemm_tn_f16: atomics / L2 bound, 0.8 ms per step): nothing reads
+    # their result before the optimiser, so they may run on a second stream beside the MFMA-bound kernels that follow.  Off by
+    # default (MT_LEAF_STREAM=1 / engine.leaf_stream = True): same-box A/B in hipGraph replay 41.73 / 41.99 ms without, 42.21 / 42.30 with
+    #  -- the cross-stream edges of the replayed graph cost more than the overlap returns.
+    def _leaf(self, fn, *keep):
+        if not self.leaf_stream:
+            fn()
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))      # the operands were produced on the main stream
+        with torch.cuda.stream(self._side):
+            fn()
+        self._side_refs.extend(keep)          # the operands stay allocated until the join (the allocator knows nothing of the side stream)
+        self._side_busy = True
+
+    def _leaf_join(self):
+        if self._side_busy:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._side_refs.clear()
+            self._side_busy = False
 
     def set_stochastic(self, on: bool, seed: int = 0):
         """Dropout(cfg.dropout) on the embedded input and after out_proj / fc2, per-layer DropPath on both backbone
@@ -459,7 +484,7 @@ class Engine:
             # reaches this marker, the gradients of interactions.{i}.* / prompt_selfattention.{i}.* (and of the head, for the
             # last block) are final -- the data-parallel reducer starts their all-reduce while the blocks below still run.
             if need_grad and self.grad_ready_hook is not None:
-                tape.record(lambda i=i: self.grad_ready_hook is not None and self.grad_ready_hook(i))
+                tape.record(lambda i=i: self.grad_ready_hook is not None and (self._leaf_join(), self.grad_ready_hook(i)))
             if i > 0 and cfg.use_prompt_sa:
                 c = self._prompt_self_attention(c, pe, f"prompt_selfattention.{i}.")
             hin = ws[f"hin{la}"]
@@ -763,18 +788,20 @@ class Engine:
             # residual path: dh_patch <- (1+gamma) dh_patch (in place; block 0's input x0 needs no gradient)
             ops.inject_resid_bwd(dh, src, proj, t[pref + "gamma"], dh if not first else ws["scratch32"], dproj,
                                  g[pref + "gamma"], Mp, D, dymap=pm, xmap=src_map, dxmap=pm if not first else None)
-            ops.gemm_tn(dproj, o1, g[ap + "output_proj.weight"], Mp, D, E, colsum=g[ap + "output_proj.bias"])
+            self._leaf(lambda: ops.gemm_tn(dproj, o1, g[ap + "output_proj.weight"], Mp, D, E, colsum=g[ap + "output_proj.bias"]), dproj, o1)
             do1 = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.gemm_nt(dproj, w16[ap + "output_proj"].wt, do1, Mp, E, D)
-            ops.gemm_tn(do1, a, g[ap + "multihead_attn.out_proj.weight"], Mp, E, E, colsum=g[ap + "multihead_attn.out_proj.bias"])
+            self._leaf(lambda: ops.gemm_tn(do1, a, g[ap + "multihead_attn.out_proj.weight"], Mp, E, E, colsum=g[ap + "multihead_attn.out_proj.bias"]),
+                       do1, a)
             da = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.gemm_nt(do1, w16[ap + "out_in"].wt, da, Mp, E, E)
             dq2 = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.inject_attn_bwd(q2, a, alse, da, k.data, v.data, dq2, k.g(), v.g(), Mp, L, T)
-            ops.gemm_tn(dq2, q1, g[ap + "multihead_attn.q_proj_weight"], Mp, E, E, colsum=g[ap + "multihead_attn.in_proj_bias"][:E])
+            self._leaf(lambda: ops.gemm_tn(dq2, q1, g[ap + "multihead_attn.q_proj_weight"], Mp, E, E, colsum=g[ap + "multihead_attn.in_proj_bias"][:E]),
+                       dq2, q1)
             dq1 = torch.empty(Mp, E, dtype=H16, device=dev)
             ops.gemm_nt(dq2, w16[ap + "q_in"].wt, dq1, Mp, E, E)
-            ops.gemm_tn(dq1, xhat, g[ap + "q_proj.weight"], Mp, E, D, colsum=g[ap + "q_proj.bias"])
+            self._leaf(lambda: ops.gemm_tn(dq1, xhat, g[ap + "q_proj.weight"], Mp, E, D, colsum=g[ap + "q_proj.bias"]), dq1, xhat)
             dxhat = torch.empty(Mp, D, dtype=H16, device=dev)
             ops.gemm_nt(dq1, w16[ap + "q_proj"].wt, dxhat, Mp, D, E)
             if first:
@@ -901,8 +928,8 @@ class Engine:
                 return
             dkv = torch.empty(Mp, 2 * E, dtype=H16, device=dev)
             ops.extract_attn_bwd(q2.data, kv, out.data, lse, out.grad, q2.g(), dkv, B, T, L)
-            ops.gemm_tn(dkv, xk, g[ap + "multihead_attn.k_proj_weight"], Mp, 2 * E, D,       # k | v weights are adjacent
-                        colsum=g[ap + "multihead_attn.in_proj_bias"][E:])
+            self._leaf(lambda: ops.gemm_tn(dkv, xk, g[ap + "multihead_attn.k_proj_weight"], Mp, 2 * E, D,       # k | v weights are adjacent
+                                           colsum=g[ap + "multihead_attn.in_proj_bias"][E:]), dkv, xk)
             dxk = torch.empty(Mp, D, dtype=H16, device=dev)
             ops.gemm_nt(dkv, w16[ap + "kv"].wt, dxk, Mp, D, 2 * E)
             ops.layernorm_bwd(dxk, hout, t[ap + "norm_kq.weight"], st, ws["dh"], Mp, D, xmap=pm, dxmap=pm, accumulate=True,
@@ -987,3 +1014,4 @@ class Engine:
         tape, logits = call if call is not None else (self.tape, self._logits)
         logits.grad = dlogits.to(self.device, F32).contiguous()
         tape.run_backward()
+        self._leaf_join()                      # (side-stream weight-gradient leaves, if enabled: final before anything reads the flat gradient)
