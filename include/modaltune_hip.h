@@ -224,8 +224,9 @@ int mt_dilated_attn_bwd(const mt_half* qkv, const mt_half* dmixed, const float* 
 /* The attention of the TITAN slide encoder's ViT blocks (titan_adapter.py:253-293 `get_alibi`, :359-361,394
  * `blocks.modules_list[i](x, attn_bias, bg_mask)`; adapter_modules.py:526-558): H heads of 64 over one sequence of N tokens
  * per pass (cls + the slide's foreground cells), softmax(q k^T / 8 + bias) v with bias[h, i, j] = -slope_h * euclidean distance
- * of the tokens' grid cells (0 to and from cls).  The bias is computed inside the kernels from two [N, 8] fp16 side tables
- * (mt_alibi_pos) -- the squared distance comes off one extra MFMA k-step, exactly -- instead of a [H, N, N] table.
+ * of the tokens' grid cells (0 to and from cls).  The distance is head-independent: ONE fp16 [N, N] table per slide
+ * (mt_alibi_dist), stored in the order the kernels' accumulator registers consume it, replaces the reference's [H, N, N] fp32
+ * bias; the kernels read it straight into registers and apply the slope with one fused multiply-add per score.
  * qkv: fp16 TOKEN-MAJOR [B*N, 3*H*64] (q' | k | v) as the qkv GEMM writes it, q' = MT_DENSE_QK_SCALE_LOG2 * q (the caller
  * bakes 64^-1/2 log2(e) into the q rows of the frozen qkv weight / bias).  o: fp16 [B*N, H*64]; lse: fp32 [B*N, H] (natural
  * log, bias included). */
@@ -234,13 +235,16 @@ typedef struct {
   int N;                 /* tokens per pass */
   int B;                 /* task passes batched */
   int H;                 /* heads (head dim 64) */
-  const mt_half* posk;   /* [N, 8] key-side table, or NULL (with posq): no bias */
-  const mt_half* posq;   /* [N, 8] query-side table */
-  const float* nslope;   /* [H]: -slope_h * log2(e) */
+  const mt_half* dist;   /* distance table of mt_alibi_dist (mt_alibi_dist_halves(N) halves), or NULL: no bias */
+  const float* nslope;   /* [H]: -slope_h * log2(e) (with dist) */
 } MtDensePlan;
-/* posk / posq rows of token i (row 0 = cls: zeros) from cells[i - 1] = (row, col) of its grid cell, centred at dims / 2
- * (dims: DEVICE int[2] = {H, W} as mt_titan_grid wrote them); *err |= 2 if a centred coordinate leaves [-1024, 1024]. */
-int mt_alibi_pos(const int* cells, int N, const int* dims, mt_half* posk, mt_half* posq, int* err, mt_stream_t stream);
+/* table[...] = euclidean distance between the grid cells of tokens i and j (token 0 = cls: zero row and column), from
+ * cells[i - 1] = (row, col) of token i's cell, rounded to fp16 (relative 2^-12: a bias error below 2.5e-4 of the bias), in
+ * blocks of 32 x 64 tokens laid out as four 16-byte pieces per lane of a wave (csrc/dense_attn.hip: DistRegs).  Symmetric, so
+ * one table serves the query-in-lane and the key-in-lane kernels.  mt_alibi_dist_halves(N) = its size in fp16 elements
+ * (N^2 rounded up to whole blocks: 34 MB at N = 4097). */
+long mt_alibi_dist_halves(int N);
+int mt_alibi_dist(const int* cells, int N, mt_half* table, mt_stream_t stream);
 int mt_dense_attn_fwd(const mt_half* qkv, const MtDensePlan* plan, mt_half* o, float* lse, mt_stream_t stream);
 /* dqkv fp16 [B*N, 3*H*64] (overwritten; q columns = gradient of the pre-scaled q') from qkv, o, dO (fp16 [B*N, H*64]) and lse.
  * delta: fp32 [B*N, H] workspace (sum_d dO * O, written by the DELTA phase).  The bias carries no gradient.  Every output

@@ -49,7 +49,7 @@ class MtDilatedPlan(C.Structure):
 
 
 class MtDensePlan(C.Structure):
-    _fields_ = [("N", I), ("B", I), ("H", I), ("posk", P), ("posq", P), ("nslope", P)]
+    _fields_ = [("N", I), ("B", I), ("H", I), ("dist", P), ("nslope", P)]
 
 
 class MtLongNetLayerWeights(C.Structure):
@@ -131,7 +131,8 @@ SIGNATURES = {
     "mt_longnet_layer_bwd": [P, P, PL, I, I, I, I, I, DR, DR, DR, P],
     "mt_vit_block_fwd": [P, P, DP, I, I, I, P, P, I, P, P],
     "mt_vit_block_bwd": [P, P, DP, I, I, I, I, I, P],
-    "mt_alibi_pos": [P, I, P, P, P, P, P],
+    "mt_alibi_dist": [P, I, P, P],
+    "mt_alibi_dist_halves": [I],
     "mt_dense_attn_fwd": [P, DP, P, P, P],
     "mt_dense_attn_bwd": [P, P, P, P, DP, P, P, I, P],
     "mt_gelu_f16_fwd": [P, P, L, P],
@@ -146,7 +147,8 @@ SIGNATURES = {
     "mt_scatter_rows_f32": [P, P, P, P, I, I, I, P],
     "mt_row_absmax_f32": [P, P, I, I, P],
 }
-_RESTYPE = {"mt_status_string": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long, "mt_pool_attn_workspace_floats": C.c_long}
+_RESTYPE = {"mt_status_string": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long, "mt_pool_attn_workspace_floats": C.c_long,
+             "mt_alibi_dist_halves": C.c_long}
 
 _lib = None
 

@@ -1,5 +1,5 @@
-// Dense multi-head flash attention with an in-kernel 2-D ALiBi bias: the attention of the TITAN slide encoder's pre-norm ViT
-// blocks (reference call sites: models/aggregators/titan_adapter.py:253-293 `get_alibi`, :359-361,394
+// Dense multi-head flash attention with a 2-D ALiBi bias: the attention of the TITAN slide encoder's pre-norm ViT blocks
+// (reference call sites: models/aggregators/titan_adapter.py:253-293 `get_alibi`, :359-361,394
 // `blocks.modules_list[i](x, attn_bias, bg_mask)`; models/vitadapter/adapter_modules.py:526-558).  H heads of 64, one
 // sequence of N tokens per task pass (cls + the slide's foreground cells), no dilation, no padding keys.
 //
@@ -7,29 +7,30 @@
 // head's row is one aligned 128-byte line, so a 64-key tile is 64 full lines whatever the row stride -- no head-major epilogue,
 // no combine pass; o, dO and dq | dk | dv are token-major too and feed / come from plain GEMMs.
 //
-// ALiBi: bias[h, i, j] = -slope_h * |cell_i - cell_j| (euclidean, in grid cells; 0 to and from cls).  A [H, N, N] table would
-// cost more HBM traffic than K and V together (N = 4097: 805 MB per layer and pass), so the squared distance is produced ON THE
-// MATRIX PIPE from two [N, 8] fp16 side tables (mt_alibi_pos): a_k = [x, y, n0, n1, n2, 1, 64, 4096] and
-// b_q = [-2x, -2y, 1, 64, 4096, n0, n1, n2] with n = x^2 + y^2 = n0 + 64 n1 + 4096 n2, so that a_k . b_q = |p_k - p_q|^2
-// EXACTLY (all operands are integers below 2^11 or powers of two, the fp32 accumulation is exact below 2^24; |x|, |y| <= 1024
-// after centring); cls carries all-zero rows, which zeroes its row and column.  One extra MFMA k-step per 32 keys, then
-// s += nslope_h * sqrt(d2) on the VALU (nslope_h = -slope_h log2 e: the logits live in log2 units).
+// ALiBi: bias[h, i, j] = -slope_h * |cell_i - cell_j| (euclidean, in grid cells; 0 to and from cls).  The reference's
+// [H, N, N] fp32 table would cost more HBM traffic than K and V together (N = 4097: 805 MB per layer and pass).  The distance
+// itself is head-independent, so ONE fp16 [N, N] table per slide (mt_alibi_dist: 34 MB at N = 4097, shared by every head, pass,
+// layer and kernel of the step) is kept in the order the accumulator registers want it: a wave reads the 64 distances each of
+// its lanes needs for a key tile as four coalesced 16-byte loads straight into registers (no LDS), and
+// `s = fma(dist, -slope_h log2 e, -m)` is written INTO the accumulators the Q.K^T chain then starts from -- the bias costs
+// one v_fma_mix_f32 per score and nothing else.  (Rounds 3 / early 4 produced the squared distance on the matrix pipe from two
+// [N, 8] side tables and took v_sqrt_f32 per score: a transcendental costs two plain VALU slots on gfx950 --
+// tools/experiments/valu_rate_probe -- and these kernels are VALU-bound at d = 64.)
 //
 // Kernel structure = the dilated kernels of attn.hip: swapped products with the query (forward, dQ) or the key (dK / dV) in the
 // lane, 64-row LDS-DMA tile images with XOR-swizzled 16-byte chunks (attn_common.h: img_off -- all eight chunks are data here),
 // double-buffered, one barrier per tile; q pre-scaled by 64^-1/2 log2 e inside the frozen qkv weight cache; per-query constants
 // as initial accumulators; deferred exact rescale; P from the accumulators as the next operand.  The row sum is accumulated on
-// the VALU (there is no spare column for a ones trick at d = 64).
+// the VALU in packed pairs (there is no spare column for a ones trick at d = 64).
 #include "attn_common.h"
 
 namespace {
 
 constexpr int DH = 64;
-constexpr int PIMG = 64 * 8;          // halves per positional tile image: 64 rows x 16 B
 
 struct DenseArgs {
   const h16* qkv; long ld;            // [B*N, ld]: q at column 0, k at D, v at 2 D (D = H * 64); ld = 3 D
-  const h16* posk; const h16* posq;   // [N, 8] each (mt_alibi_pos), or nullptr: no bias
+  const h16* dist;                    // blocked distance table (mt_alibi_dist), or nullptr: no bias
   const float* nslope;                // [H]: -slope_h * log2(e)
   int N, B, H, D, qtiles;
 };
@@ -66,11 +67,6 @@ MT_DEVINL void dma_tile64(h16* img, __amdgpu_buffer_rsrc_t rs, const DmaLane64& 
   for (int i = 0; i < 2; ++i)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + d.lds_halves[i]), 16, d.voff[i], 0, 0, 0);
 }
-// positional tile image: 64 rows x 16 B = one 1-KiB piece, issued by the first wave
-MT_DEVINL void dma_pos(h16* img, const h16* tab, int t, int N, int lane) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(tab, (long)t * 1024, (long)N * 16),
-                                           (__attribute__((address_space(3))) void*)img, 16, (uint32_t)(lane * 16), 0, 0, 0);
-}
 MT_DEVINL f32x16 splat16(float v) {
   f32x16 r;
 #pragma unroll
@@ -79,12 +75,45 @@ MT_DEVINL f32x16 splat16(float v) {
 }
 MT_DEVINL float sum_halves(float x) { return x + __shfl_xor(x, 32, 64); }
 
+// Distance table: block (A, t) = the distances between the 32 lane-side tokens 32 A .. 32 A + 31 and the 64 tile-side tokens of
+// tile t, stored as the four 16-byte pieces each lane of a wave consumes: piece j = 2 sub + half holds accumulator registers
+// 8 half .. 8 half + 7 of sub-block sub, i.e. the tile-side tokens sub * 32 + (i & 3) + 8 (i >> 2) + 4 hh of lane (l31, hh).
+// The matrix is symmetric, so the same table serves the kernels with the query in the lane (forward, dQ) and the one with the
+// key in the lane (dK / dV).
+constexpr int DBLK = 2048;            // halves per (A, t) block
+struct DistRegs { h16x8 p[4]; };
+MT_DEVINL void dist_load(DistRegs& r, const h16* stripe, int t) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r.p[j] = ldg8(stripe + (long)t * DBLK + j * 512);
+}
+// nslope * (fp16 half of h2) + c in ONE instruction (hipcc turns the C expression into two conversions and half a v_pk_fma_f32)
+MT_DEVINL float fma_mix_lo(uint32_t h2, float nslope, float c) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(nslope), "v"(c));
+  return r;
+}
+MT_DEVINL float fma_mix_hi(uint32_t h2, float nslope, float c) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(nslope), "v"(c));
+  return r;
+}
+MT_DEVINL float dist_bias(const DistRegs& r, int sub, int i, float nslope, float c) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 w = __builtin_bit_cast(u32x4, r.p[2 * sub + (i >> 3)]);
+  return (i & 1) ? fma_mix_hi(w[(i & 7) >> 1], nslope, c) : fma_mix_lo(w[(i & 7) >> 1], nslope, c);
+}
+// accumulator initialiser of sub-block sub: nslope * dist + c
+MT_DEVINL f32x16 dist_init(const DistRegs& r, int sub, float nslope, float c) {
+  f32x16 s;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = dist_bias(r, sub, i, nslope, c);
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <bool BIAS>
-// (launch bound: 3 waves per SIMD -- 158 VGPRs instead of 172, no spill: -4 % same-box, tools/dense_microbench.py)
 __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16* __restrict__ o, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // K0 | K1 | V0 | V1
-  __shared__ __attribute__((aligned(16))) h16 pos_s[2 * PIMG + 8];       // key a_k tiles (two buffers) + a zero chunk
   h16* const Ks = smem;
   h16* const Vs = smem + 2 * IMG_HALVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,8 +122,6 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
   if (!w.live) return;
   const int N = a.N;
   const long ld = a.ld;
-  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (tid == 0) *reinterpret_cast<h16x8*>(&pos_s[2 * PIMG]) = zero8;
 
   const int iq = w.qt * 128 + wave * 32 + l31;
   const bool qvalid = iq < N;
@@ -102,14 +129,11 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
   h16x8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = sel8(qvalid, ldg8(a.qkv + qrow * ld + w.h * DH + ks * 16 + hh * 8));
-  h16x8 pqf = zero8;
-  float nslope = 0.f;
-  if (BIAS) {
-    pqf = sel8(qvalid && hh == 0, ldg8(a.posq + (long)min(iq, N - 1) * 8));
-    nslope = a.nslope[w.h];
-  }
+  const float nslope = BIAS ? a.nslope[w.h] : 0.f;
 
   const int ntile = (N + 63) >> 6;
+  const h16* const dstripe = BIAS ? a.dist + (long)(w.qt * 4 + wave) * ntile * DBLK + lane * 8 : nullptr;
+  DistRegs dr;
   const int row_bytes = (int)ld * 2;
   const long valid_bytes = (long)(N - 1) * row_bytes + DH * 2;
   const long tile_bytes = 64L * row_bytes;
@@ -119,7 +143,6 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
   auto dma = [&](int t) {
     dma_tile64(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), dl);
     dma_tile64(Vs + (t & 1) * IMG_HALVES, tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl);
-    if (BIAS && tid < 64) dma_pos(pos_s + (t & 1) * PIMG, a.posk, t, N, lane);
   };
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   int krd[4];
@@ -129,42 +152,40 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
   const int va0 = img_off(4 * hh + tq, vc) + vo, va1 = img_off(4 * hh + tq, vc + 4) + vo;
   const int vb0 = img_off(4 * hh + tq + 8, vc) + vo, vb1 = img_off(4 * hh + tq + 8, vc + 4) + vo;
 
-  // logits of one 64-key tile in log2 units, relative to the reference: s[sub][reg] = q'.k + nslope * dist - m2
-  auto scores = [&](int t, f32x16 (&s)[2], const f32x16& init) {
+  // logits of one 64-key tile in log2 units relative to the running reference: s[sub][reg] = q'.k + nslope * dist - m2; the
+  // chains start from `init` (BIAS: the bias - m2 written by dist_init; otherwise the splat of -m2)
+  auto qk = [&](int t, f32x16 (&s)[2], const f32x16& init0, const f32x16& init1) {
     const h16* Kb = Ks + (t & 1) * IMG_HALVES;
+    h16x8 kf[2][4];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const h16x8 kf = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + krd[ks]]);
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? init : s[sub], 0, 0, 0);
-      }
+      for (int ks = 0; ks < 4; ++ks) kf[sub][ks] = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + krd[ks]]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][ks], qf[ks], ks == 0 ? init0 : s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][ks], qf[ks], ks == 0 ? init1 : s[1], 0, 0, 0);
     }
-    if (BIAS) {
-      const h16* Pb = pos_s + (t & 1) * PIMG;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        // a_k fragment of key row (sub * 32 + l31): the hh = 0 lanes carry k = 0..7, the hh = 1 lanes (k = 8..15) the zero chunk
-        const h16x8 pk = *reinterpret_cast<const h16x8*>(hh ? &pos_s[2 * PIMG] : &Pb[(sub * 32 + l31) * 8]);
-        const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pk, pqf, splat16(0.f), 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[sub][i] = fmaf(__builtin_amdgcn_sqrtf(d2[i]), nslope, s[sub][i]);
-      }
-    }
+    // all eight fragment reads in flight before the first product (hipcc otherwise serialises read -> wait -> MFMA through one
+    // fragment register: eight exposed LDS latencies per tile)
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
   };
 
   f32x16 o0 = splat16(0.f), o1 = splat16(0.f);
-  float lsum = 0.f;
+  f32x2 lsum2 = {0.f, 0.f};
   dma(0);
+  if (BIAS) dist_load(dr, dstripe, 0);
   dma_wait_all();
   __syncthreads();
-  // running reference m2 (log2 units), carried as the accumulator initialiser minit = splat(-m2); starts at the row maximum of
-  // tile 0 (bias included: the ALiBi term can push a whole tile far below its raw scores)
+  // running reference m2 (log2 units); starts at the row maximum of tile 0 (bias included: the ALiBi term can push a whole tile
+  // far below its raw scores)
   float m2;
-  f32x16 minit;
+  f32x16 minit = splat16(0.f);      // (!BIAS: the splat of -m2, the C operand of both chains)
   {
     f32x16 s0[2];
-    scores(0, s0, splat16(0.f));
+    if (BIAS) qk(0, s0, dist_init(dr, 0, nslope, 0.f), dist_init(dr, 1, nslope, 0.f));
+    else qk(0, s0, minit, minit);
     float mx = NEG_BIG;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
         mx = fmaxf(mx, kidx < N ? s0[sub][i] : NEG_BIG);
       }
     m2 = max_halves(mx);
-    minit = splat16(-m2);
+    if (!BIAS) minit = splat16(-m2);
   }
 
   auto tile = [&](int t, auto tail_tag) {
@@ -183,7 +204,13 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
     const h16* Vb = Vs + (t & 1) * IMG_HALVES;
     if (t + 1 < ntile) dma(t + 1);
     f32x16 s_cur[2];
-    scores(t, s_cur, minit);
+    if (BIAS) {
+      const f32x16 i0 = dist_init(dr, 0, nslope, -m2), i1 = dist_init(dr, 1, nslope, -m2);
+      if (t + 1 < ntile) dist_load(dr, dstripe, t + 1);      // (same registers: the two lines above were their last use)
+      qk(t, s_cur, i0, i1);
+    } else {
+      qk(t, s_cur, minit, minit);
+    }
     float mx = NEG_BIG;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -201,9 +228,9 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
       const float alpha = __builtin_amdgcn_exp2f(-up);
 #pragma unroll
       for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; s_cur[0][i] -= up; s_cur[1][i] -= up; }
-      lsum *= alpha;
+      lsum2 *= alpha;
       m2 += up;
-      minit = splat16(-m2);
+      if (!BIAS) minit = splat16(-m2);
     }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -214,7 +241,7 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
         for (int e = 0; e < 8; e += 2) {
           const f32x2 p = pk_exp2((f32x2){s_cur[sub][8 * s2 + e], s_cur[sub][8 * s2 + e + 1]});
           pf[e] = (h16)p[0]; pf[e + 1] = (h16)p[1];
-          lsum += p[0] + p[1];
+          lsum2 += p;
         }
         const h16* vblk = Vb + (sub * 32 + s2 * 16) * IMG_ROW;
         const h16x8 v0 = cat8(lds_tr4(vblk + va0), lds_tr4(vblk + vb0));
@@ -230,7 +257,7 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
   for (int t = 0; t < nplain; ++t) tile(t, std::false_type{});
   if (tail_last) tile(ntile - 1, std::true_type{});
 
-  const float l = sum_halves(lsum);
+  const float l = sum_halves(lsum2[0] + lsum2[1]);
   if (qvalid) {
     const float inv = 1.0f / l;
     h16* orow = o + qrow * a.D + w.h * DH;
@@ -248,10 +275,9 @@ __global__ __launch_bounds__(256, 3) void dense_attn_fwd_kernel(DenseArgs a, h16
 // ------------------------------------------------------------------------------------------------ backward: dQ (query = lane)
 //   P'^T = exp2(S'^T + bias - L2[q] + log2 ln2) ; dP^T = V . dO^T - delta[q] ; dS^T = P'^T dP^T ; dQ'^T += K^T . dS^T
 template <bool BIAS>
-__global__ __launch_bounds__(256) void dense_attn_bwd_q_kernel(DenseArgs a, const h16* __restrict__ d_o, const float* __restrict__ lse,
+__global__ __launch_bounds__(256, 3) void dense_attn_bwd_q_kernel(DenseArgs a, const h16* __restrict__ d_o, const float* __restrict__ lse,
                                                                const float* __restrict__ delta, h16* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // K0 | K1 | V0 | V1
-  __shared__ __attribute__((aligned(16))) h16 pos_s[2 * PIMG + 8];
   h16* const Ks = smem;
   h16* const Vs = smem + 2 * IMG_HALVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -260,8 +286,6 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_q_kernel(DenseArgs a, cons
   if (!w.live) return;
   const int N = a.N;
   const long ld = a.ld;
-  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (tid == 0) *reinterpret_cast<h16x8*>(&pos_s[2 * PIMG]) = zero8;
 
   const int iq = w.qt * 128 + wave * 32 + l31;
   const bool qvalid = iq < N;
@@ -272,17 +296,15 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_q_kernel(DenseArgs a, cons
     qf[ks] = sel8(qvalid, ldg8(a.qkv + qrow * ld + w.h * DH + ks * 16 + hh * 8));
     dof[ks] = sel8(qvalid, ldg8(d_o + qrow * a.D + w.h * DH + ks * 16 + hh * 8));
   }
-  h16x8 pqf = zero8;
-  float nslope = 0.f;
-  if (BIAS) {
-    pqf = sel8(qvalid && hh == 0, ldg8(a.posq + (long)min(iq, N - 1) * 8));
-    nslope = a.nslope[w.h];
-  }
+  const float nslope = BIAS ? a.nslope[w.h] : 0.f;
   const float L2raw = lse[qrow * a.H + w.h], dlraw = delta[qrow * a.H + w.h];
-  const f32x16 nl2i = splat16(qvalid ? fmaf(-L2raw, LOG2E, LOG2_LN2) : -1.0e30f);      // invalid queries: P' = 0
+  const float nl2 = qvalid ? fmaf(-L2raw, LOG2E, LOG2_LN2) : -1.0e30f;      // invalid queries: P' = 0
+  const f32x16 nl2i = splat16(nl2);
   const f32x16 ndli = splat16(qvalid ? -dlraw : 0.f);
 
   const int ntile = (N + 63) >> 6;
+  const h16* const dstripe = BIAS ? a.dist + (long)(w.qt * 4 + wave) * ntile * DBLK + lane * 8 : nullptr;
+  DistRegs dr;
   const int row_bytes = (int)ld * 2;
   const long valid_bytes = (long)(N - 1) * row_bytes + DH * 2;
   const long tile_bytes = 64L * row_bytes;
@@ -292,7 +314,6 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_q_kernel(DenseArgs a, cons
   auto dma = [&](int t) {
     dma_tile64(Ks + (t & 1) * IMG_HALVES, tile_rsrc(kseq, t * tile_bytes, valid_bytes), dl);
     dma_tile64(Vs + (t & 1) * IMG_HALVES, tile_rsrc(vseq, t * tile_bytes, valid_bytes), dl);
-    if (BIAS && tid < 64) dma_pos(pos_s + (t & 1) * PIMG, a.posk, t, N, lane);
   };
   const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   int rrd[4];
@@ -304,6 +325,7 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_q_kernel(DenseArgs a, cons
 
   f32x16 dq0 = splat16(0.f), dq1 = splat16(0.f);
   dma(0);
+  if (BIAS) dist_load(dr, dstripe, 0);
   dma_wait_all();
   __syncthreads();
   auto tile = [&](int t, auto tail_tag) {
@@ -311,23 +333,20 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_q_kernel(DenseArgs a, cons
     const int kb = t * 64;
     const h16* Kb = Ks + (t & 1) * IMG_HALVES;
     const h16* Vb = Vs + (t & 1) * IMG_HALVES;
-    const h16* Pb = pos_s + (t & 1) * PIMG;
     if (t + 1 < ntile) dma(t + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
+      if (BIAS) {
+        s = dist_init(dr, sub, nslope, nl2);
+        if (sub == 1 && t + 1 < ntile) dist_load(dr, dstripe, t + 1);      // (same registers: last use just above)
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const h16x8 kf = *reinterpret_cast<const h16x8*>(&Kb[sub * 32 * IMG_ROW + rrd[ks]]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? nl2i : s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 && !BIAS ? nl2i : s, 0, 0, 0);
         const h16x8 vf = *reinterpret_cast<const h16x8*>(&Vb[sub * 32 * IMG_ROW + rrd[ks]]);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], ks == 0 ? ndli : dp, 0, 0, 0);
-      }
-      if (BIAS) {
-        const h16x8 pk = *reinterpret_cast<const h16x8*>(hh ? &pos_s[2 * PIMG] : &Pb[(sub * 32 + l31) * 8]);
-        const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pk, pqf, splat16(0.f), 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = fmaf(__builtin_amdgcn_sqrtf(d2[i]), nslope, s[i]);
       }
       h16x8 dsf[2];
 #pragma unroll
@@ -377,7 +396,6 @@ template <bool BIAS>
 __global__ __launch_bounds__(256) void dense_attn_bwd_kv_kernel(DenseArgs a, const h16* __restrict__ d_o, const float* __restrict__ lse,
                                                                 const float* __restrict__ delta, h16* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) h16 smem[4 * IMG_HALVES];      // Q0 | Q1 | D0 | D1
-  __shared__ __attribute__((aligned(16))) h16 pos_s[2 * PIMG + 8];       // query b_q tiles + zero chunk
   __shared__ __attribute__((aligned(16))) float L2s[2][64];
   __shared__ __attribute__((aligned(16))) float Dls[2][64];
   h16* const Qx = smem;
@@ -388,8 +406,6 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kv_kernel(DenseArgs a, con
   if (!w.live) return;
   const int N = a.N;
   const long ld = a.ld;
-  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (tid == 0) *reinterpret_cast<h16x8*>(&pos_s[2 * PIMG]) = zero8;
 
   const int ik = w.qt * 128 + wave * 32 + l31;
   const bool kvalid = ik < N;
@@ -400,14 +416,11 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kv_kernel(DenseArgs a, con
     kf[ks] = sel8(kvalid, ldg8(a.qkv + krow * ld + a.D + w.h * DH + ks * 16 + hh * 8));
     vf[ks] = sel8(kvalid, ldg8(a.qkv + krow * ld + 2 * a.D + w.h * DH + ks * 16 + hh * 8));
   }
-  h16x8 pkf = zero8;
-  float nslope = 0.f;
-  if (BIAS) {
-    pkf = sel8(kvalid && hh == 0, ldg8(a.posk + (long)min(ik, N - 1) * 8));
-    nslope = a.nslope[w.h];
-  }
+  const float nslope = BIAS ? a.nslope[w.h] : 0.f;
 
   const int ntile = (N + 63) >> 6;
+  const h16* const dstripe = BIAS ? a.dist + (long)(w.qt * 4 + wave) * ntile * DBLK + lane * 8 : nullptr;
+  DistRegs dr;
   const int qrow_bytes = (int)ld * 2, drow_bytes = a.D * 2;
   const long qvalid_bytes = (long)(N - 1) * qrow_bytes + DH * 2, dvalid_bytes = (long)(N - 1) * drow_bytes + DH * 2;
   const h16* const qseq = a.qkv + (long)w.b * N * ld + w.h * DH;
@@ -420,7 +433,6 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kv_kernel(DenseArgs a, con
     dma_tile64(Qx + (t & 1) * IMG_HALVES, tile_rsrc(qseq, t * 64L * qrow_bytes, qvalid_bytes), dlq);
     dma_tile64(Dx + (t & 1) * IMG_HALVES, tile_rsrc(dseq, t * 64L * drow_bytes, dvalid_bytes), dld);
     if (tid < 64) {
-      if (BIAS) dma_pos(pos_s + (t & 1) * PIMG, a.posq, t, N, lane);
       // RAW loads only; the arithmetic waits in publish() at the end of the tile (a use here parks wave 0 on s_waitcnt vmcnt(0),
       // the DMA just issued included: attn.hip, dK/dV kernel)
       const long off = (long)min(t * 64 + lane, N - 1) * a.H;
@@ -446,13 +458,13 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kv_kernel(DenseArgs a, con
   const int tr_b0 = img_off(4 * hh + tq + 8, trc) + tro, tr_b1 = img_off(4 * hh + tq + 8, trc + 4) + tro;
 
   issue(0);
+  if (BIAS) dist_load(dr, dstripe, 0);
   publish(0);
   dma_wait_all();
   __syncthreads();
   for (int t = 0; t < ntile; ++t) {
     const h16* Qb = Qx + (t & 1) * IMG_HALVES;
     const h16* Db = Dx + (t & 1) * IMG_HALVES;
-    const h16* Pb = pos_s + (t & 1) * PIMG;
     const float* L2b = L2s[t & 1];
     const float* Dlb = Dls[t & 1];
     if (t + 1 < ntile) issue(t + 1);
@@ -464,20 +476,19 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kv_kernel(DenseArgs a, con
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(&L2b[sub * 32 + 8 * g4 + 4 * hh]);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(&Dlb[sub * 32 + 8 * g4 + 4 * hh]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = x0[e]; dp[4 * g4 + e] = x1[e]; }
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g4 + e;
+          s[i] = BIAS ? dist_bias(dr, sub, i, nslope, x0[e]) : x0[e];
+          dp[i] = x1[e];
+        }
       }
+      if (BIAS && sub == 1 && t + 1 < ntile) dist_load(dr, dstripe, t + 1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const h16x8 qa = *reinterpret_cast<const h16x8*>(&Qb[sub * 32 * IMG_ROW + rrd[ks]]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s, 0, 0, 0);
         const h16x8 da = *reinterpret_cast<const h16x8*>(&Db[sub * 32 * IMG_ROW + rrd[ks]]);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp, 0, 0, 0);
-      }
-      if (BIAS) {      // rows = queries: A = b_q of the tile's query rows, B = a_k of this lane's key
-        const h16x8 pq = *reinterpret_cast<const h16x8*>(hh ? &pos_s[2 * PIMG] : &Pb[(sub * 32 + l31) * 8]);
-        const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pq, pkf, splat16(0.f), 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = fmaf(__builtin_amdgcn_sqrtf(d2[i]), nslope, s[i]);
       }
       h16x8 pf[2], dsf[2];
 #pragma unroll
@@ -537,38 +548,36 @@ __global__ __launch_bounds__(256) void dense_attn_delta_kernel(const h16* __rest
   }
 }
 
-// ALiBi side tables from the grid cells of the tokens (token 0 = cls: all-zero rows); see the file header.
-__global__ void alibi_pos_kernel(const int* __restrict__ cells, int N, const int* __restrict__ dims, h16* __restrict__ posk,
-                                 h16* __restrict__ posq, int* __restrict__ err) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int cx = dims[0] >> 1, cy = dims[1] >> 1;
-  h16x8 ak = {0, 0, 0, 0, 0, 0, 0, 0}, bq = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (i > 0) {
-    int x = cells[2 * (i - 1)] - cx, y = cells[2 * (i - 1) + 1] - cy;
-    if (x < -1024 || x > 1024 || y < -1024 || y > 1024) {
-      if (err) atomicOr(err, 2);
-      x = min(max(x, -1024), 1024); y = min(max(y, -1024), 1024);
+// Blocked distance table (see DistRegs): grid (tile t, block A), thread = (piece j, lane).
+__global__ __launch_bounds__(256) void alibi_dist_kernel(const int* __restrict__ cells, int N, int ntile, h16* __restrict__ tab) {
+  const int t = blockIdx.x, A = blockIdx.y, j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, hh = lane >> 5, sub = j >> 1, half = j & 1;
+  const int ia = A * 32 + l31;
+  const bool aok = ia >= 1 && ia < N;
+  const float xa = aok ? (float)cells[2 * (ia - 1)] : 0.f, ya = aok ? (float)cells[2 * (ia - 1) + 1] : 0.f;
+  h16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = 8 * half + e, ib = t * 64 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+    float d = 0.f;
+    if (aok && ib >= 1 && ib < N) {
+      const float dx = xa - (float)cells[2 * (ib - 1)], dy = ya - (float)cells[2 * (ib - 1) + 1];
+      d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
     }
-    const int n = x * x + y * y, n0 = n & 63, n1 = (n >> 6) & 63, n2 = n >> 12;
-    ak = (h16x8){(h16)(float)x, (h16)(float)y, (h16)(float)n0, (h16)(float)n1, (h16)(float)n2, (h16)1.f, (h16)64.f, (h16)4096.f};
-    bq = (h16x8){(h16)(float)(-2 * x), (h16)(float)(-2 * y), (h16)1.f, (h16)64.f, (h16)4096.f, (h16)(float)n0, (h16)(float)n1,
-                 (h16)(float)n2};
+    v[e] = (h16)d;
   }
-  *reinterpret_cast<h16x8*>(posk + (long)i * 8) = ak;
-  *reinterpret_cast<h16x8*>(posq + (long)i * 8) = bq;
+  *reinterpret_cast<h16x8*>(tab + ((long)A * ntile + t) * DBLK + j * 512 + lane * 8) = v;
 }
 
 bool dense_plan_ok(const MtDensePlan* p) {
   if (!p || p->N < 1 || p->B < 1 || p->H < 1 || p->H > 64) return false;
-  if ((p->posk == nullptr) != (p->posq == nullptr)) return false;
-  if (p->posk && !p->nslope) return false;
+  if (p->dist && !p->nslope) return false;
   return true;
 }
 DenseArgs dense_args(const mt_half* qkv, const MtDensePlan* p) {
   DenseArgs a;
   a.qkv = (const h16*)qkv; a.N = p->N; a.B = p->B; a.H = p->H; a.D = p->H * DH; a.ld = 3L * a.D;
-  a.posk = (const h16*)p->posk; a.posq = (const h16*)p->posq; a.nslope = p->nslope;
+  a.nslope = p->nslope; a.dist = (const h16*)p->dist;
   a.qtiles = cdiv(p->N, 128);
   return a;
 }
@@ -576,10 +585,12 @@ int dense_grid(const DenseArgs& a) { return cdiv(a.B * a.H, 8) * 8 * a.qtiles; }
 
 }  // namespace
 
-extern "C" int mt_alibi_pos(const int* cells, int N, const int* dims, mt_half* posk, mt_half* posq, int* err, mt_stream_t stream) {
-  if (!posk || !posq || !dims || N < 1 || (N > 1 && !cells)) return MT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(alibi_pos_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, cells, N, dims, (h16*)posk,
-                     (h16*)posq, err);
+extern "C" long mt_alibi_dist_halves(int N) { return N < 1 ? 0 : 4L * cdiv(N, 128) * cdiv(N, 64) * DBLK; }
+extern "C" int mt_alibi_dist(const int* cells, int N, mt_half* table, mt_stream_t stream) {
+  if (!table || N < 1 || (N > 1 && !cells)) return MT_ERR_BAD_ARG;
+  const int ntile = cdiv(N, 64), nA = 4 * cdiv(N, 128);
+  if (nA > 65535) return MT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(alibi_dist_kernel, dim3(ntile, nA), dim3(256), 0, (hipStream_t)stream, cells, N, ntile, (h16*)table);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
@@ -587,7 +598,7 @@ extern "C" int mt_alibi_pos(const int* cells, int N, const int* dims, mt_half* p
 extern "C" int mt_dense_attn_fwd(const mt_half* qkv, const MtDensePlan* plan, mt_half* o, float* lse, mt_stream_t stream) {
   if (!qkv || !o || !lse || !dense_plan_ok(plan)) return MT_ERR_BAD_ARG;
   const DenseArgs a = dense_args(qkv, plan);
-  if (a.posk)
+  if (a.dist)
     hipLaunchKernelGGL(dense_attn_fwd_kernel<true>, dim3(dense_grid(a)), dim3(256), 0, (hipStream_t)stream, a, (h16*)o, lse);
   else
     hipLaunchKernelGGL(dense_attn_fwd_kernel<false>, dim3(dense_grid(a)), dim3(256), 0, (hipStream_t)stream, a, (h16*)o, lse);
@@ -606,11 +617,11 @@ extern "C" int mt_dense_attn_bwd(const mt_half* qkv, const mt_half* o, const mt_
                        (const h16*)d_o, delta, M, a.H);
   const dim3 grid(dense_grid(a));
   if (phases & MT_DENSE_BWD_KV) {
-    if (a.posk) hipLaunchKernelGGL(dense_attn_bwd_kv_kernel<true>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
+    if (a.dist) hipLaunchKernelGGL(dense_attn_bwd_kv_kernel<true>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
     else hipLaunchKernelGGL(dense_attn_bwd_kv_kernel<false>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
   }
   if (phases & MT_DENSE_BWD_Q) {
-    if (a.posk) hipLaunchKernelGGL(dense_attn_bwd_q_kernel<true>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
+    if (a.dist) hipLaunchKernelGGL(dense_attn_bwd_q_kernel<true>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
     else hipLaunchKernelGGL(dense_attn_bwd_q_kernel<false>, grid, dim3(256), 0, s, a, (const h16*)d_o, lse, delta, (h16*)dqkv);
   }
   MT_CHECK_LAUNCH();

@@ -209,18 +209,24 @@ DENSE_QK_SCALE_LOG2 = 0.125 * 1.4426950408889634
 DENSE_BWD_DELTA, DENSE_BWD_KV, DENSE_BWD_Q, DENSE_BWD_ALL = 1, 2, 4, 7
 
 
-def make_dense_plan(N: int, B: int, H: int, posk=None, posq=None, nslope=None) -> MtDensePlan:
-    """posk / posq: fp16 [N, 8] side tables of mt_alibi_pos (both or neither); nslope: fp32 [H] = -slope_h * log2(e).
+def make_dense_plan(N: int, B: int, H: int, dist=None, nslope=None) -> MtDensePlan:
+    """dist: the fp16 distance table of alibi_dist (or None: no bias); nslope: fp32 [H] = -slope_h * log2(e).
     The tensors must outlive every launch made with the plan."""
     p = MtDensePlan()
     p.N, p.B, p.H = N, B, H
-    p.posk, p.posq = (posk.data_ptr() if posk is not None else None), (posq.data_ptr() if posq is not None else None)
+    p.dist = dist.data_ptr() if dist is not None else None
     p.nslope = nslope.data_ptr() if nslope is not None else None
     return p
 
 
-def alibi_pos(cells, N, dims, posk, posq, err=None):
-    check(_lib.load().mt_alibi_pos(_p(cells), N, _p(dims), _p(posk), _p(posq), _p(err), _s()), "alibi_pos")
+def alibi_dist_halves(N: int) -> int:
+    return int(_lib.load().mt_alibi_dist_halves(N))
+
+
+def alibi_dist(cells, N, table):
+    """cells: int32 [N - 1, 2] (row, col) on the device; table: fp16, alibi_dist_halves(N) elements."""
+    assert table.numel() >= alibi_dist_halves(N) and table.dtype == torch.float16
+    check(_lib.load().mt_alibi_dist(_p(cells), N, _p(table), _s()), "alibi_dist")
 
 
 def dense_attn_fwd(qkv, plan, o, lse):

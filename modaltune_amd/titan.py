@@ -592,12 +592,13 @@ class NativeBackbone:
                 dcur = tmp
 
     def make_plan(self, cells: torch.Tensor, dims: torch.Tensor, N: int, B: int, err: Optional[torch.Tensor] = None):
-        """Dense-attention plan of one slide: the ALiBi side tables from the token cells.  Returns (plan, tensors to keep alive)."""
+        """Dense-attention plan of one slide: the fp16 distance table of the token cells (one per slide: every head, pass, block
+        and kernel of the step reads the same one).  Returns (plan, tensors to keep alive)."""
         if not self.alibi:
             return ops.make_dense_plan(N, B, self.H), ()
-        posk, posq = torch.empty(N, 8, dtype=H16, device=self.dev), torch.empty(N, 8, dtype=H16, device=self.dev)
-        ops.alibi_pos(cells.contiguous(), N, dims, posk, posq, err)
-        return ops.make_dense_plan(N, B, self.H, posk, posq, self.nslope), (posk, posq)
+        dist = torch.empty(ops.alibi_dist_halves(N), dtype=H16, device=self.dev)
+        ops.alibi_dist(cells.contiguous(), N, dist)
+        return ops.make_dense_plan(N, B, self.H, dist, self.nslope), (dist,)
 
     # -- construction-time check of every native piece against the module's torch code
     def _probe_inputs(self, seed: int = 7):
@@ -722,7 +723,7 @@ class TitanEngine(Engine):
     def check_inputs(self):
         if int(self._titan_err) != 0:
             self._titan_err.zero_()
-            raise ValueError("TITAN slide: non-finite / out-of-range coordinates, or a grid wider than 2049 cells (ALiBi tables)")
+            raise ValueError("TITAN slide: non-finite or out-of-range coordinates")
         super().check_inputs()
 
     def stage_slide(self, x, coords, patch_size_lv0: int = 1024) -> int:

@@ -144,15 +144,15 @@ _op("dilated_attention_bwd(Tensor dy, Tensor qkv_hm, Tensor o_br, Tensor lse_br,
     "int[] ratio, Tensor ln_w) -> Tensor")((_dilated_attention_bwd, lambda dy, *a: dy.new_empty((dy.shape[0], 2304))))
 
 
-# ---- dense attention with in-kernel 2-D ALiBi (TITAN blocks)
+# ---- dense attention with the 2-D ALiBi bias (TITAN blocks)
 def _dense_alibi_plan(qkv: Tensor, cells: Optional[Tensor], dims: Optional[Tensor], slopes: Optional[Tensor], N: int, B: int, H: int):
     dev = qkv.device
     if cells is None:
         return ops.make_dense_plan(N, B, H), ()
-    posk, posq = torch.empty(N, 8, dtype=H16, device=dev), torch.empty(N, 8, dtype=H16, device=dev)
-    ops.alibi_pos(cells.to(torch.int32).contiguous(), N, dims.to(torch.int32).contiguous(), posk, posq, None)
+    dist = torch.empty(ops.alibi_dist_halves(N), dtype=H16, device=dev)
+    ops.alibi_dist(cells.to(torch.int32).contiguous(), N, dist)
     nslope = (-slopes.to(F32) * 1.4426950408889634).contiguous()
-    return ops.make_dense_plan(N, B, H, posk, posq, nslope), (posk, posq, nslope)
+    return ops.make_dense_plan(N, B, H, dist, nslope), (dist, nslope)
 
 
 def _dense_attention_fwd(qkv: Tensor, N: int, B: int, H: int, cells: Optional[Tensor], dims: Optional[Tensor], slopes: Optional[Tensor]):

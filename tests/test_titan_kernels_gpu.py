@@ -52,15 +52,12 @@ def test_dense_alibi_attention_fwd_bwd_vs_oracle(N, B, span, bias):
     cells = _cells(Lv, span, N) if Lv > 0 else torch.zeros(0, 2, dtype=torch.int32)
     slopes = _slopes(H)
     dev = "cuda"
-    posk = posq = nslope = None
+    dist = nslope = None
     if bias:
-        posk, posq = torch.empty(N, 8, dtype=H16, device=dev), torch.empty(N, 8, dtype=H16, device=dev)
-        err = torch.zeros(1, dtype=I32, device=dev)
-        dims = torch.tensor([span, span], dtype=I32, device=dev)
-        ops.alibi_pos(cells.cuda() if Lv > 0 else None, N, dims, posk, posq, err)
-        assert int(err) == 0
+        dist = torch.full((ops.alibi_dist_halves(N),), float("nan"), dtype=H16, device=dev)
+        ops.alibi_dist(cells.cuda() if Lv > 0 else None, N, dist)
         nslope = (-slopes * math.log2(math.e)).float().cuda()
-    plan = ops.make_dense_plan(N, B, H, posk, posq, nslope)
+    plan = ops.make_dense_plan(N, B, H, dist, nslope)
     o = torch.empty(M, D, dtype=H16, device=dev)
     lse = torch.empty(M, H, dtype=F32, device=dev)
     ops.dense_attn_fwd(qkv, plan, o, lse)
@@ -87,24 +84,42 @@ def test_dense_alibi_attention_fwd_bwd_vs_oracle(N, B, span, bias):
     assert relf(dg[:, :, 2], vo.grad) < 2e-2
 
 
-def test_alibi_squared_distance_is_exact_and_range_checked():
-    """a_k . b_q of the side tables is |p_k - p_q|^2 exactly (integers through fp16 operands), also at the edge of the range."""
+def test_alibi_distance_table_layout_and_values():
+    """mt_alibi_dist: every (lane-side token a, tile-side token b) pair sits where the kernels' accumulator register i of
+    sub-block sub in lane (l31, hh) looks for it, holds the fp16-rounded euclidean cell distance, and is zero to / from cls and
+    past the end; also far outside the old +-1024 window of the side-table scheme."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from modaltune_amd import ops
-    cells = torch.tensor([[0, 0], [2048, 2048], [0, 2048], [1024, 1024], [1, 2047], [777, 1333]], dtype=I32)
-    N = cells.shape[0] + 1
-    posk, posq = torch.empty(N, 8, dtype=H16, device="cuda"), torch.empty(N, 8, dtype=H16, device="cuda")
-    err = torch.zeros(1, dtype=I32, device="cuda")
-    ops.alibi_pos(cells.cuda(), N, torch.tensor([2049, 2049], dtype=I32, device="cuda"), posk, posq, err)
-    assert int(err) == 0
-    d2 = posk.double().cpu() @ posq.double().cpu().T
-    p = cells.double()
-    want = torch.zeros(N, N, dtype=torch.float64)
-    want[1:, 1:] = ((p[:, None] - p[None]) ** 2).sum(-1)
-    assert torch.equal(d2, want)                                # cls row / column: zeros
-    ops.alibi_pos(cells.cuda(), N, torch.tensor([2051, 2049], dtype=I32, device="cuda"), posk, posq, err)
-    assert int(err) == 2                                        # centred row 0 - 1025 leaves [-1024, 1024]
+    g = torch.Generator().manual_seed(5)
+    for N, span in ((7, 2049), (130, 300), (333, 30000)):
+        cells = torch.randint(0, span, (N - 1, 2), generator=g, dtype=I32)
+        tab = torch.full((ops.alibi_dist_halves(N),), float("nan"), dtype=H16, device="cuda")
+        ops.alibi_dist(cells.cuda(), N, tab)
+        nA, nt = 4 * ((N + 127) // 128), (N + 63) // 64
+        assert tab.numel() == nA * nt * 2048
+        t5 = tab.cpu().view(nA, nt, 4, 64, 8)                     # [A, t, piece j, lane, e]
+        p = torch.zeros(N, 2, dtype=torch.float64)
+        p[1:] = cells.double()
+        want = (p[:, None] - p[None]).pow(2).sum(-1).sqrt()
+        want[0, :] = 0.0
+        want[:, 0] = 0.0
+        full = torch.zeros(nA * 32, nt * 64, dtype=torch.float64)
+        full[:N, :N] = want
+        j, lane, e = torch.meshgrid(torch.arange(4), torch.arange(64), torch.arange(8), indexing="ij")
+        sub, half, l31, hh = j >> 1, j & 1, lane & 31, lane >> 5
+        i = 8 * half + e
+        b_in = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh          # tile-side token of (piece, lane, element)
+        for A in range(nA):
+            for t in range(nt):
+                got = t5[A, t].double()
+                exact = full[(A * 32 + l31), (t * 64 + b_in)]
+                exp = exact.half().double()
+                if span <= 2049:                                   # dx^2 + dy^2 < 2^24: the fp32 arithmetic is exact up to the root
+                    assert torch.equal(got, exp), (N, A, t)
+                else:                                              # (fp32 sum rounded before the root: a tie may fall the other way)
+                    assert float(((got - exact).abs() - exact * 2.0 ** -11).max()) <= 0.0, (N, A, t)
+                assert torch.equal(got == 0, exact == 0)
 
 
 def test_gelu_f16_fwd_bwd():
@@ -207,11 +222,11 @@ def test_dense_attention_full_size_properties():
     side = 80
     flat = torch.randperm(side * side, device="cuda", generator=g)[:N - 1].sort().values
     cells = torch.stack([flat // side, flat % side], 1).int()
-    posk, posq = torch.empty(N, 8, dtype=H16, device="cuda"), torch.empty(N, 8, dtype=H16, device="cuda")
-    ops.alibi_pos(cells, N, torch.tensor([side, side], dtype=I32, device="cuda"), posk, posq, None)
+    dtab = torch.empty(ops.alibi_dist_halves(N), dtype=H16, device="cuda")      # (the plan points into it: keep it alive)
+    ops.alibi_dist(cells, N, dtab)
     slopes = _slopes(H).cuda()
     nslope = (-slopes * math.log2(math.e)).float()
-    plan = ops.make_dense_plan(N, B, H, posk, posq, nslope)
+    plan = ops.make_dense_plan(N, B, H, dtab, nslope)
     o, lse = torch.empty(M, D, dtype=H16, device="cuda"), torch.empty(M, H, dtype=F32, device="cuda")
     ops.dense_attn_fwd(qkv, plan, o, lse)
     dist = torch.cdist(cells.float(), cells.float())

@@ -10,10 +10,10 @@ qkv = (torch.randn(M, 3 * D, device="cuda", generator=g) * 0.5).half()
 d_o = (torch.randn(M, D, device="cuda", generator=g) * 0.1).half()
 side = int(math.sqrt(N)) + 1
 cells = torch.stack([torch.arange(N - 1) // side, torch.arange(N - 1) % side], 1).int().cuda()
-posk, posq = torch.empty(N, 8, dtype=torch.float16, device="cuda"), torch.empty(N, 8, dtype=torch.float16, device="cuda")
-ops.alibi_pos(cells, N, torch.tensor([side, side], dtype=torch.int32, device="cuda"), posk, posq, None)
 nslope = torch.tensor([-(2.0 ** (-8.0 * (i + 1) / H)) * math.log2(math.e) for i in range(H)], device="cuda")
-plan = ops.make_dense_plan(N, B, H, posk, posq, nslope)
+dist = torch.empty(ops.alibi_dist_halves(N), dtype=torch.float16, device="cuda")
+ops.alibi_dist(cells, N, dist)
+plan = ops.make_dense_plan(N, B, H, dist if os.environ.get("MT_DENSE_BIAS", "1") != "0" else None, nslope)
 o = torch.empty(M, D, dtype=torch.float16, device="cuda"); lse = torch.empty(M, H, device="cuda")
 delta = torch.empty(M, H, device="cuda"); dqkv = torch.empty_like(qkv)
 
