@@ -36,13 +36,17 @@ struct DenseArgs {
 };
 
 struct DItem { int b, h, qt; bool live; };
-// Workgroup -> (pass, head, 128-row tile): blocks b and b + 8 share an XCD, so XCD x walks the (pass, head) groups x, x + 8, ...
-// with the tiles of a group back to back: every tile of a group re-reads the same K / V rows from ONE L2.
+// Workgroup -> (pass, head, 128-row tile): blocks b and b + 8 share an XCD, so XCD x owns the (pass, head) groups x, x + 8, ... and
+// walks them with their tiles interleaved (tile 0 of each of its groups, then tile 1 of each, ...): every tile of a group
+// re-reads the same K / V rows from ONE L2 (4-5 groups x 1 MB at N = 4097 stay resident), and the workgroups of one tile index
+// that run side by side share that tile's stripe of the distance table (same-box: -1..-3 % on all three kernels against
+// group after group; two groups at a time: +10 %, tools/experiments/README.md).
 MT_DEVINL DItem ddecode(const DenseArgs& a, int bid) {
   const int x = bid & 7, j = bid >> 3;
+  const int ng = (a.B * a.H + 7) >> 3;      // groups per XCD
   DItem w;
-  w.qt = __builtin_amdgcn_readfirstlane(j % a.qtiles);
-  const int gid = __builtin_amdgcn_readfirstlane((j / a.qtiles) * 8 + x);
+  w.qt = __builtin_amdgcn_readfirstlane(j / ng);
+  const int gid = __builtin_amdgcn_readfirstlane((j % ng) * 8 + x);
   w.live = gid < a.B * a.H;
   w.h = __builtin_amdgcn_readfirstlane(gid % a.H);
   w.b = __builtin_amdgcn_readfirstlane(gid / a.H);
