@@ -378,7 +378,7 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
         "metric": "slides/sec (train step), TITAN backbone configuration, ~4k foreground cells", "value": value, "unit": "slides/s",
         "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 4: TITAN-geometry ViT (768-d, 6 blocks, 12 heads x 64, MLP 3072, 2-D ALiBi in-kernel, attentional pooling; "
+        "config": {"workload": f"BASELINE config 4: TITAN-geometry ViT (768-d, 6 blocks, 12 heads x 64, MLP 3072, 2-D ALiBi from one fp16 distance table per slide, attentional pooling; "
                                f"random init, stand-in for the absent MahmoodLab/TITAN snapshot: backbone parity UNPINNED) + Modal Adapter, "
                                f"{T - 1} gene tokens + 1 task token, 3 task passes batched, fp16 operands / fp32 accumulate, "
                                + ("train mode (DropPath 0.2 on the Extractor FFN, gene-encoder dropouts), " if not args.no_dropout else "dropout off, ") +

@@ -204,7 +204,7 @@ def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
         TIMER.setdefault(name, []).append((e0, e1))
 
 
-# ---- dense attention with in-kernel 2-D ALiBi + the other TITAN-side launchers (include/modaltune_hip.h)
+# ---- dense attention with the 2-D ALiBi bias (one fp16 distance table per slide) + the other TITAN-side launchers (include/modaltune_hip.h)
 DENSE_QK_SCALE_LOG2 = 0.125 * 1.4426950408889634
 DENSE_BWD_DELTA, DENSE_BWD_KV, DENSE_BWD_Q, DENSE_BWD_ALL = 1, 2, 4, 7
 

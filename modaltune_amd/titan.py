@@ -8,7 +8,7 @@ Native (HIP kernels, same tape and flat parameter buffers as the Prov-GigaPath p
     the fusion head on the pooled image token (TA:399-437);
   * the frozen slide encoder itself, when the supplied `VisionTransformer` has the standard pre-norm ViT structure
     (`NativeBackbone`): patch-embedding MLP + cls + `norm_pre`, blocks = LayerNorm -> qkv -> dense attention with the 2-D ALiBi
-    bias computed in-kernel from the cells (csrc/dense_attn.hip) -> proj (+ layer scale) -> LayerNorm -> fc1 -> GELU -> fc2, with
+    bias from one fp16 cell-distance table per slide (csrc/dense_attn.hip) -> proj (+ layer scale) -> LayerNorm -> fc1 -> GELU -> fc2, with
     activation-gradient (dX-only) backward through all of it, and the attentional pooling.
 
 The TITAN snapshot's source and weights (HF MahmoodLab/TITAN @ b2fb4f47, utils/constants.py:22-23) are NOT in the reference
