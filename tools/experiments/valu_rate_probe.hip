@@ -21,6 +21,11 @@ __device__ __forceinline__ unsigned long long now() {
 #define FMAMIX(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(y[(i) & 15]) : "v"(u[(i) & 15]), "v"(c))
 #define MAX3(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(y[(i) & 15]) : "v"(y[((i) + 1) & 15]), "v"(y[((i) + 2) & 15]))
 #define MOV(i) asm volatile("v_mov_b32 %0, %1" : "=v"(u[(i) & 15]) : "v"(y[(i) & 15]))
+#define CVTRTZ(i) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[(i) & 15]) : "v"(y[(i) & 15]), "v"(y[((i) + 1) & 15]))
+#define PKMUL(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[(i) & 7]) : "v"(pc))
+#define PKADD(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[(i) & 7]) : "v"(pc))
+#define MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(y[(i) & 15]) : "v"(c))
+#define PERM(i) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(u[(i) & 15]) : "v"(u[((i) + 3) & 15]), "v"(u[((i) + 7) & 15]), "v"(u[((i) + 11) & 15]))
 #define MFMA(i) acc[(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[(i) & 3], 0, 0, 0)
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(256 * WAVES) void probe(unsigned long long* out, float* sink, int iters) {
@@ -47,6 +52,11 @@ __global__ __launch_bounds__(256 * WAVES) void probe(unsigned long long* out, fl
       if (MODE == 6) FMAMIX(i);
       if (MODE == 10) MAX3(i);
       if (MODE == 11) MOV(i);
+      if (MODE == 13) CVTRTZ(i);
+      if (MODE == 14) PKMUL(i);
+      if (MODE == 15) PKADD(i);
+      if (MODE == 16) MUL(i);
+      if (MODE == 17) PERM(i);
       if ((MODE == 7 || MODE == 8 || MODE == 9) && (i & 3) == 0) MFMA(i >> 2);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256 * WAVES) void probe(unsigned long long* out, fl
 template <int WAVES>
 static void launch(int mode, unsigned long long* o, float* k, int iters, int grid) {
 #define CASE(m) if (mode == m) hipLaunchKernelGGL((probe<m, WAVES>), dim3(grid), dim3(256 * WAVES), 0, 0, o, k, iters)
-  CASE(0); CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7); CASE(8); CASE(9); CASE(10); CASE(11); CASE(12);
+  CASE(0); CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7); CASE(8); CASE(9); CASE(10); CASE(11); CASE(12); CASE(13); CASE(14); CASE(15); CASE(16); CASE(17);
 }
 extern "C" int run_probe(void* out, void* sink, int iters, int grid, int mode, int waves) {
   if (waves == 1) launch<1>(mode, (unsigned long long*)out, (float*)sink, iters, grid);
