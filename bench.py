@@ -59,6 +59,9 @@ def parse_args():
                     help="trainstep: the fused TrainStep (3 task passes batched, device-side loss / GradScaler / AdamW, hipGraph replay); "
                          "module: the reference trainer's own loop on the drop-in nn.Module (train_modaltune.py:172-177,225-238): "
                          "3x model(...) -> torch KL loss -> GradScaler.scale(loss).backward() -> torch.optim.AdamW.step()")
+    ap.add_argument("--optim", default="fused", choices=["fused", "torch"],
+                    help="--api module: modaltune_amd.optim.AdamW (the second import of INTEGRATION.md section 1: torch.optim.AdamW's surface, one "
+                         "fused launch on the model's flat buffers) or torch.optim.AdamW itself, as the reference trainer builds it")
     ap.add_argument("--config", default="gigapath", choices=["gigapath", "titan"],
                     help="gigapath: BASELINE config 2 (the headline metric); titan: BASELINE config 4 (TITAN backbone configuration, "
                          "--patches foreground cells, --ragged: mixed bag lengths) -- a separate JSON line, never the headline")
@@ -401,7 +404,7 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
     return out
 
 
-def run_module(args, steps=None, warmup=None):
+def run_module(args, steps=None, warmup=None, optim=None):
     """The boundary north_star names, driven exactly as the reference trainer drives it (train_modaltune.py:123-149,172-177,
     195-240): Aggregator.create -> per step the frozen torch projector, three model(...) calls (one per task id), torch's
     KL-divergence loss under autocast, GradScaler.scale(loss).backward(), GradScaler.step(torch.optim.AdamW), update, zero_grad."""
@@ -421,12 +424,20 @@ def run_module(args, steps=None, warmup=None):
     sizes = json.load(open(os.path.join(ROOT, "tests", "golden", "pathway_sizes_331.json"))) if args.pathways == "real" else \
         synth.toy_group_sizes(int(args.pathways))
     groups = {i: ["g%d_%d" % (i, j) for j in range(n)] for i, n in enumerate(sizes)}
-    kw = {} if not args.no_dropout else dict(dropout=0.0, drop_path_rate=0.0)
+    from modaltune_amd.config import GIGAPATH_JSON
+    kw = dict(GIGAPATH_JSON, pretrained=False)                     # TM:123-126: **json_config (no weight file exists offline)
+    if args.no_dropout:
+        kw.update(dropout=0.0, drop_path_rate=0.0)
     # TM:123-126 -- the model is used AS CONSTRUCTED (reference init families; pretrained False: no weight file exists offline)
-    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3, pretrained=False, init_seed=0, **kw).to(dev)
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3, init_seed=0, **kw).to(dev)
     cfg = model.cfg
     params = [{"params": list(filter(lambda p: p.requires_grad, model.parameters())), "lr": 1e-4 / 20}]             # TM:139-149
-    opt = torch.optim.AdamW(params, weight_decay=0.01, betas=(0.9, 0.999))
+    optim = optim or args.optim
+    if optim == "fused":
+        from modaltune_amd.optim import AdamW
+    else:
+        AdamW = torch.optim.AdamW
+    opt = AdamW(params, weight_decay=0.01, betas=(0.9, 0.999))
     scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=2.0 ** 15)                                        # TM:107
     psd = {k: torch.from_numpy(v).to(dev) for k, v in synth.projector_state(0).items()}
 
@@ -466,6 +477,7 @@ def run_module(args, steps=None, warmup=None):
     t0 = time.perf_counter()
     for i in range(nwarm, nwarm + steps):
         step(i)
+    host_dt = time.perf_counter() - t0          # when the host had ENQUEUED the last step (no sync inside the loop: below dt when the GPU is the bound)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     T = cfg.num_tokens
@@ -475,11 +487,13 @@ def run_module(args, steps=None, warmup=None):
            "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f16", "data": "synthetic",
            "config": {"workload": f"Prov-GigaPath ModalAdapter train step through the drop-in nn.Module exactly as train_modaltune.py drives it "
-                                  f"(3 model calls, torch KL loss, GradScaler, torch.optim.AdamW), {L} patches x 1536-d, {len(sizes)} pathways -> {T - 1} gene "
+                                  f"(3 model calls, torch KL loss, GradScaler, {'modaltune_amd.optim.AdamW' if optim == 'fused' else 'torch.optim.AdamW'}), {L} patches x 1536-d, {len(sizes)} pathways -> {T - 1} gene "
                                   f"tokens + 1 task token, 1 slide per step, eager, " + ("dropout off" if args.no_dropout else "train mode (Dropout / DropPath on)"),
                       "api": "module", "patches": L, "tokens": T, "parallelism": "dp1"},
            "loss": float(last["loss"]), "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / 1e12 / PEAK_F16_MFMA_TFLOPS,
-           "launch": "eager (torch autograd + torch.optim)"}
+           "launch": "eager (torch autograd + torch.optim)", "optimizer": "modaltune_amd.optim.AdamW" if optim == "fused" else "torch.optim.AdamW",
+           "optimizer_steps_fused": getattr(opt, "last_step_fused", None), "host_enqueue_ms_per_step": 1e3 * host_dt / steps,
+           "task_tokens_read_back": model._nosync_rows is None}
     return out
 
 
@@ -498,7 +512,7 @@ def _leg(fn):
 def _brief(rec):
     """Sub-record form of a leg's full JSON line."""
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "loss", "step_tflops", "step_mfma_frac", "roofline",
-            "roofline_kernels", "launch", "kernel_ms_per_step", "graph_replays")
+            "roofline_kernels", "launch", "kernel_ms_per_step", "graph_replays", "optimizer", "optimizer_steps_fused", "torch_adamw", "host_enqueue_ms_per_step", "task_tokens_read_back")
     return {k: rec[k] for k in keep if k in rec}
 
 
@@ -617,11 +631,29 @@ def main():
         torch.cuda.synchronize()
         run(nwarm)
     eng.check_inputs()
+    comm = None
+    if world > 1:
+        # the collective path is real before anything is timed: an all-reduce of ones must come back as the world size
+        probe = torch.ones(1, device=dev) if args.backend == "nccl" else torch.ones(1)
+        torch.distributed.all_reduce(probe)
+        comm = {"ranks_seen_by_all_reduce": int(round(float(probe))), "backend": torch.distributed.get_backend(),
+                "bucket_bytes": [4 * sum(n for _, n in bk) for bk in ts.reducer.buckets],
+                "last_bucket_sharded": bool(ts.reducer.sharded)}
+        if comm["ranks_seen_by_all_reduce"] != world:
+            raise RuntimeError(f"all_reduce of ones returned {float(probe)} on a world of {world}")
+        ts.comm_events = []
     barrier()
     t0 = time.perf_counter()
     run(args.steps, first=nwarm)
     barrier()
     dt = time.perf_counter() - t0
+    dt_own = dt
+    if comm is not None:
+        ev, ts.comm_events = ts.comm_events, None
+        for kind, key in (("grad", "comm_exposed_ms"), ("param", "param_gather_exposed_ms")):
+            ms = [a.elapsed_time(b) for k, a, b in ev if k == kind]
+            comm[key] = sum(ms) / max(1, args.steps)      # per step: GPU time on the compute stream between the two marks
+            comm[key.replace("_ms", "_events")] = len(ms)
     loss = float(ts.loss)
     replays, eager_steps = ts.graph_replays, ts.eager_steps
     # per-kernel durations: HIP events on the launch stream around every launch of an eager, instrumented pass of the
@@ -632,9 +664,16 @@ def main():
     barrier()
     timer, ops.TIMER = ops.TIMER, None
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        host = args.backend != "nccl"
+        tt = torch.tensor([dt, comm["comm_exposed_ms"], comm["param_gather_exposed_ms"]], device="cpu" if host else dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt)
+        dt, comm["comm_exposed_ms"], comm["param_gather_exposed_ms"] = (float(v) for v in tt)
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, round(1e3 * dt_own / args.steps, 3))
+        comm["per_rank_ms_per_step"] = per_rank
+        comm["how"] = ("comm_exposed_ms: HIP events on the compute stream from the end of the backward to the point the optimiser may start "
+                       "(bucket all-reduces launched from inside the backward + the last bucket's reduce-scatter + the 4-byte found_inf MAX), "
+                       "per step, MAX over ranks; param_gather_exposed_ms: the next step's wait for the sharded parameter all-gather, same rule")
     skipped = nwarm + args.steps + prof_steps - int(ts.step_dev)
 
     if rank == 0:
@@ -694,7 +733,7 @@ def main():
             "roofline_worst": worst,
             "roofline_kernels": table,
             "launch": "eager" if (args.eager or args.ragged) else "hipGraph replay",
-            "graph_replays": replays, "eager_steps": eager_steps,
+            "graph_replays": replays, "eager_steps": eager_steps, "comm": comm,
             "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]},
         }
         default_line = world == 1 and not (args.ragged or args.eager)
@@ -703,7 +742,13 @@ def main():
             out["pcie_inclusive"] = _leg(lambda: leg_pcie(ts, eng, sizes, L, value))
             del ts, eng, slides
             torch.cuda.empty_cache()
-            out["module_api"] = _leg(lambda: _brief(run_module(args, steps=8, warmup=4)))
+            def module_leg():
+                rec = run_module(args, steps=8, warmup=4, optim="fused")
+                torch.cuda.empty_cache()
+                ref = run_module(args, steps=6, warmup=4, optim="torch")      # the trainer's loop with NOTHING but the model import replaced
+                rec["torch_adamw"] = {"ms_per_step": ref["ms_per_step"], "value": ref["value"], "optimizer": ref["optimizer"]}
+                return _brief(rec)
+            out["module_api"] = _leg(module_leg)
             torch.cuda.empty_cache()
             out["titan"] = _leg(lambda: _brief(run_titan(args, steps=16, warmup=8, patches=4096, ragged=True, cpu_baseline=False)))
         if world == 1 and not args.no_cpu_baseline:

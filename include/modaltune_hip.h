@@ -403,8 +403,9 @@ int mt_distill_loss(const float* logits, const float* target, int R, int O, floa
 /* Fused multi-tensor AdamW over one flat fp32 parameter/gradient buffer (torch.optim.AdamW, TM:145-149) with
  * GradScaler.step semantics (TM:235-237): grads are divided by *scale; if any is non-finite the update is
  * skipped and *found_inf is set.  step_count is 1-based. */
-int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step_count, const int* step_dev /* device count of completed
+int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay /* doubles: torch forms 1 - beta, lr * weight_decay and the bias corrections in
+                  double before they meet the fp32 tensors (1 - 0.999f is 4.7e-5 off 0.001) */, int step_count, const int* step_dev /* device count of completed
                   steps (overrides step_count - 1) or NULL */, float grad_mult /* e.g. 1/world_size */,
                   const float* scale, int* found_inf, const float* lr_dev /* device scalar: the schedule's current
                   learning rate (overrides lr; a captured graph replays with whatever it holds -- the reference steps

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MODALTUNE_HIP_LIB", os.path.join(_HERE, "_C", "libmodaltune_hip.so"))   # override: diagnostic builds
 
-P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+P, I, L, F, D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
 
 class MtRowMap(C.Structure):
@@ -120,7 +120,7 @@ SIGNATURES = {
     "mt_inject_resid_bwd": [P, L, RM, P, L, RM, P, P, P, L, RM, I, P, P, I, I, P],
     "mt_l2norm_rows": [P, P, I, I, P],
     "mt_distill_loss": [P, P, I, I, F, P, P, P, P],
-    "mt_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, P, F, P, P, P, P],
+    "mt_adamw_step": [P, P, P, P, L, D, D, D, D, D, I, P, F, P, P, P, P],
     "mt_scaler_update": [P, P, P, P, F, F, I, P],
     "mt_check_finite": [P, L, P, P],
     "mt_absmax_scale": [P, L, F, P, P],

@@ -142,7 +142,7 @@ class LongNetGeneAdapter(Aggregator):
                  weights_location: str = None, init_seed: int = None, **kwargs):
         super().__init__()
         gene_group_defination = gene_group_defination or {}
-        cfg = ModelConfig.from_json(kwargs, multi_task=multi_task, clinical=self.CLINICAL)
+        cfg = ModelConfig.from_longnet_ctor(kwargs, multi_task=multi_task, clinical=self.CLINICAL)
         self.cfg = cfg
         self.is_multi = multi_task > 1                       # longvit_adapter.py:88 (read at TM:174)
         sizes = [len(v) for v in gene_group_defination.values()]
@@ -166,7 +166,13 @@ class LongNetGeneAdapter(Aggregator):
         self._group = self._token = None
         self._spec = self._hist = self._spec_rows = None      # speculative batching of the per-task calls (_forward_one_task)
         self.speculate = True                                 # (False: every call runs on its own; the calls of a step still share one hand-over)
+        self._init_nosync()
         self.train(True)
+
+    def _init_nosync(self):
+        self.nosync_after = 2              # slides served in full by the same prediction before task tokens stop being read back (0: never)
+        self._nosync_rows = self._ns_eye = self._ns_stream = self._ns_seen = None
+        self._ns_pending, self._ns_pins, self._ns_slide, self._streak = [], [], 0, 0
 
     def _open_group(self, x, coords):
         """The chain token for this call (None = first call of a new group) -- see _StepGroup.  A group is the consecutive
@@ -204,11 +210,32 @@ class LongNetGeneAdapter(Aggregator):
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        self.engine.load_state_dict(state_dict, strict=strict)
+        """nn.Module.load_state_dict's contract: strict raises on any missing / unexpected key, a non-strict load copies what
+        matches and RETURNS the two lists (train_modaltune.py:546-547 prints them)."""
+        have = self.engine.store.tensors
+        missing = [k for k in have if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in have]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for {}: missing keys {}, unexpected keys {}".format(
+                type(self).__name__, missing, unexpected))
+        self.engine.load_state_dict(state_dict, strict=False)
         self._versions = None
-        return torch.nn.modules.module._IncompatibleKeys([], [])
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
-    def _apply(self, fn, recurse=True):     # .to()/.cuda()/.float(): tensors already live on the GPU in their final dtypes
+    def _apply(self, fn, recurse=True):
+        """.to() / .cuda() / .float() (train_modaltune.py:126 `.to(device)`): the tensors already live on the engine's device in their
+        final dtypes (fp32 masters, derived fp16 caches), so a request for exactly that is a no-op -- anything else is REFUSED rather
+        than silently ignored (the engine's buffers, caches and captured graphs cannot move)."""
+        probe = fn(torch.empty(0, dtype=F32, device=self.engine.device))
+        want, have = torch.device(probe.device), self.engine.device
+
+        def index(d):
+            return d.index if d.index is not None else (torch.cuda.current_device() if d.type == "cuda" and torch.cuda.is_available() else 0)
+        if want.type != have.type or (want.type == "cuda" and index(want) != index(have)):
+            raise RuntimeError(f"this model lives on {have} (the `device=` argument of its constructor); it cannot be moved to {want}: "
+                               "construct it on the target device instead")
+        if probe.dtype != F32:
+            raise RuntimeError(f"the parameters are fp32 masters (fp16 operand caches are derived from them); conversion to {probe.dtype} is not supported")
         return self
 
     def _sync_weight_caches(self):
@@ -251,19 +278,30 @@ class LongNetGeneAdapter(Aggregator):
         r0, r1, ... it answers the next slide's first call (task r0) with ONE batched engine pass over all of them and hands the
         later calls their rows of that result: one B = len(rows) forward, and -- the rows being slices of one autograd output --
         one backward, exactly what the fused TrainStep runs.  A call that does not fit the prediction (other task id, repeated
-        id, different tensors / weights / mode) simply runs on its own and the observed pattern is learnt afresh.  Reading the
-        one-hot costs one small host read-back per call."""
+        id, different tensors / weights / mode) simply runs on its own and the observed pattern is learnt afresh.
+
+        LEARNING a pattern reads each one-hot back (one small host sync per call).  Once the same pattern has served
+        `nosync_after` slides in a row the module stops reading: every slide's first call runs the batched pass over the learnt
+        rows and each call takes its row by a DEVICE-side index (`_serve_nosync`) -- a host sync in front of every call would
+        otherwise drain the queue three times per step and leave the GPU waiting for the host at the start of the forward and
+        of the backward (round 5: 2 ms per step at L = 10 000).  The one-hots are still copied back, asynchronously, and checked
+        when they have arrived (`_drain_decodes`): a task id outside the learnt rows raises there (one or two calls late, never
+        silently); a pattern that merely shrank or changed order sends the module back to learning."""
         genes = self._gene_list(genes)
         if not self.speculate:
             return self.forward_tasks(x, coords, genes, onehot, clinical=clinical)
         self._sync_weight_caches()
         need = torch.is_grad_enabled() and self.training_grad
+        key = self._call_key(x, coords, genes, clinical, need)
+        self._drain_decodes()
+        if self._nosync_rows is not None and onehot.is_cuda:
+            return self._serve_nosync(x, coords, genes, onehot, clinical, key)
         vals = onehot.detach().reshape(-1).tolist()
         row = vals.index(1.0) if (vals.count(1.0) == 1 and vals.count(0.0) == len(vals) - 1) else None
         if row is None:                       # not a one-hot: no prediction possible
             self._spec = self._hist = self._spec_rows = None
+            self._streak = 0
             return self.forward_tasks(x, coords, genes, onehot, clinical=clinical)
-        key = self._call_key(x, coords, genes, clinical, need)
         sp = self._spec
         if sp is not None and sp["key"] == key and row in sp["rows"] and row not in sp["used"]:
             sp["used"].add(row)
@@ -276,7 +314,15 @@ class LongNetGeneAdapter(Aggregator):
         else:                                 # a new slide (or a break of the pattern): what the last one showed is the prediction
             if hist is not None:
                 r = hist["rows"]
-                self._spec_rows = list(r) if (len(r) >= 2 and len(set(r)) == len(r)) else None
+                new_rows = list(r) if (len(r) >= 2 and len(set(r)) == len(r)) else None
+                # a prediction that was served in full counts towards the switch to the read-back-free mode
+                full = sp is not None and new_rows is not None and new_rows == self._spec_rows and sp["used"] == set(new_rows)
+                self._streak = self._streak + 1 if full else 0
+                self._spec_rows = new_rows
+                if self.nosync_after and self._streak >= self.nosync_after and onehot.is_cuda:
+                    self._nosync_rows, self._streak = list(new_rows), 0
+                    self._spec = self._hist = None
+                    return self._serve_nosync(x, coords, genes, onehot, clinical, key)
             # (`hold`: the keyed objects stay alive as long as the key is compared against, so neither the caching allocator nor
             # CPython can hand their addresses / ids to another slide's tensors)
             hold = (x, coords, genes, clinical)
@@ -289,6 +335,68 @@ class LongNetGeneAdapter(Aggregator):
                 self._spec = {"key": key, "rows": rows, "used": {row}, "logits": logits, "hold": hold}
                 return logits[0:1]
         return self.forward_tasks(x, coords, genes, onehot, clinical=clinical)
+
+    def _serve_nosync(self, x, coords, genes, onehot, clinical, key):
+        """One call in the read-back-free mode: the slide's batched pass over the learnt rows (first call of the slide), then this
+        call's row of it picked by an index computed on the device from the one-hot.  Exact (an index_select, no arithmetic on the
+        logits) and differentiable; the one-hot goes to the host asynchronously for the deferred check."""
+        rows = self._nosync_rows
+        dev = self.engine.device
+        sp = self._spec
+        if sp is None or sp["key"] != key or sp.get("rows") is not rows:
+            if self._ns_eye is None or self._ns_eye[0] is not rows:
+                self._ns_eye = (rows, torch.eye(self.cfg.multi_task, dtype=F32, device=dev)[rows].contiguous(),
+                                torch.tensor(rows, dtype=torch.long, device=dev))
+            logits = self.forward_tasks(x, coords, genes, self._ns_eye[1], clinical=clinical)
+            self._ns_slide += 1
+            sp = self._spec = {"key": key, "rows": rows, "logits": logits, "hold": (x, coords, genes, clinical), "slide": self._ns_slide}
+        oh = onehot.detach().reshape(-1)
+        # --- deferred check: one-hot -> pinned host memory on a side stream (behind everything queued so far, never waited for here)
+        if self._ns_stream is None:
+            self._ns_stream = torch.cuda.Stream(device=dev)
+        pin = self._ns_pins.pop() if self._ns_pins else torch.empty(self.cfg.multi_task, dtype=F32).pin_memory()
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._ns_stream):
+            self._ns_stream.wait_event(ready)
+            pin.copy_(oh.to(F32), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        self._ns_pending.append((done, pin, oh, rows, sp["slide"]))
+        idx = (oh[self._ns_eye[2]] == 1).to(torch.int64).argmax().reshape(1)       # position of this call's task id among `rows`
+        return sp["logits"].index_select(0, idx)
+
+    def _drain_decodes(self, block: bool = False):
+        """Consume the one-hots whose asynchronous read-back has completed (never blocks unless asked to): validate the calls they
+        belonged to and follow the pattern of task ids per slide."""
+        pend = self._ns_pending
+        while pend and (block or pend[0][0].query()):
+            done, pin, _, rows, slide = pend.pop(0)
+            if block:
+                done.synchronize()
+            vals = pin.tolist()
+            self._ns_pins.append(pin)
+            row = vals.index(1.0) if (vals.count(1.0) == 1 and vals.count(0.0) == len(vals) - 1) else None
+            if row is None or row not in rows:
+                self._nosync_rows = self._spec = self._hist = self._spec_rows = None
+                self._ns_seen, self._streak = None, 0
+                pend.clear()
+                raise RuntimeError(
+                    f"task token {vals} (passed to model(...) a few calls ago) is not a one-hot of one of the task ids {rows} this slide's "
+                    "batched pass was speculated on: the logits that call returned were NOT this task's.  The module had stopped reading "
+                    "task tokens back after the same ids had been served for several slides in a row; it is learning the pattern afresh "
+                    "now.  Set model.nosync_after = 0 (read every task token back) or model.speculate = False (one engine pass per call) "
+                    "for a loop whose task ids change between slides.")
+            seen = self._ns_seen
+            if seen is None or seen[0] != slide:
+                if seen is not None and sorted(seen[1]) != sorted(rows):
+                    # the previous slide was served with fewer / other ids than the batched pass computed: correct, but wasteful
+                    self._nosync_rows = self._spec = self._hist = self._spec_rows = None
+                    self._ns_seen, self._streak = None, 0
+                    return
+                self._ns_seen = (slide, [row])
+            else:
+                seen[1].append(row)
 
     def forward_tasks(self, x, coords, genes, task_onehots, clinical=None):
         """All task passes of one slide in one batched engine call: logits [B, output_dim]."""

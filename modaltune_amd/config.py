@@ -21,6 +21,19 @@ DILATED_RATIOS = (1, 2, 4, 8, 16)
 LN_EPS = 1e-5  # torchscale EncoderConfig.layernorm_eps (architecture/config.py:43); nn.LayerNorm default too
 
 
+# model_configs/modaltune_gigapath_config.json:1-30 -- the configuration the reference trainer passes to the constructor
+GIGAPATH_JSON = {"in_chans": 1536, "embed_dim": 768, "depth": 12, "slide_ngrids": 1000, "tile_size": 256, "max_wsi_size": 262144,
+                 "global_pool": False, "dropout": 0.25, "drop_path_rate": 0.1, "mlp_ratio": 4, "num_heads": 12, "output_dim": 256,
+                 "init_values": 0.0, "geneclass_name": "gene_mixer_group", "interaction_indexes": [[0, 3], [4, 7], [8, 11]],
+                 "with_cffn": True, "cffn_ratio": 0.25, "add_prompt_feature": True, "use_extra_extractor": True, "freeze_vit": True,
+                 "with_cp": False, "use_prompt_sa": True, "prompt_dropout": 0.0, "prompt_agg": "avg", "token_agg": "sum",
+                 "pretrained": True, "clinfeat_dim": 5}
+# What the reference CONSTRUCTOR assumes for a key the caller leaves out, where that differs from the shipped JSON
+# (LongNetGeneAdapter.__init__, longvit_adapter.py:35-53; LongNetViT.__init__, slide_encoder.py:87-97): a bare
+# `Aggregator.create("longnetvit_gene_adapter", ...)` must build the architecture (and state_dict key set) the reference builds.
+LONGNET_CTOR_DEFAULTS = {"use_prompt_sa": False, "prompt_agg": "cls", "token_agg": "cat", "embed_dim": 256, "interaction_indexes": None}
+
+
 @dataclasses.dataclass
 class GeneConfig:
     """model_configs/other_configs.py:12-21 ("gene_mixer_group")."""
@@ -117,6 +130,18 @@ class ModelConfig:
             last = b
         if last != self.depth - 1:
             raise ValueError("interaction_indexes must cover the layers up to depth - 1")
+
+    @staticmethod
+    def from_longnet_ctor(kwargs, **overrides) -> "ModelConfig":
+        """The configuration `LongNetGeneAdapter(**kwargs)` builds in the reference: omitted keys take the reference CONSTRUCTOR's
+        defaults (prompt_agg "cls", token_agg "cat", no prompt self-attention, embed_dim 256 -- which `validate` then refuses), not
+        the shipped JSON's.  `interaction_indexes` has no usable default there either (None: longvit_adapter.py:40,100-129 iterate it)."""
+        d = dict(LONGNET_CTOR_DEFAULTS)
+        d.update(kwargs)
+        if d["interaction_indexes"] is None:
+            raise TypeError("interaction_indexes is required (the reference constructor's default None cannot be iterated, "
+                            "longvit_adapter.py:40,100-129); model_configs/modaltune_gigapath_config.json passes [[0, 3], [4, 7], [8, 11]]")
+        return ModelConfig.from_json(d, **overrides)
 
     @staticmethod
     def from_json(path_or_dict, **overrides) -> "ModelConfig":

@@ -409,9 +409,11 @@ int mt_gemm_ps_launch(const void* A, long lda, const void* W, int M, int N, int 
   if (K > 2304) return MT_ERR_UNSUPPORTED;
   int grid = min(ncu, ntiles);
   grid = max(8, grid / 8 * 8);
-  if ((long)M * K * 2 >= (1L << 32) || (long)M * N * 2 >= (1L << 32) || (long)N * K * 2 >= (1L << 32)) return MT_ERR_UNSUPPORTED;   // 32-bit byte offsets
+  // 32-bit byte offsets: the A descriptor's extent and the per-lane A offsets are formed from lda (a strided A -- lda > K, e.g. a column
+  // slice of a wider buffer -- must not wrap them either)
+  if (lda < K || (long)M * lda * 2 >= (1L << 32) || (long)M * N * 2 >= (1L << 32) || (long)N * K * 2 >= (1L << 32)) return MT_ERR_UNSUPPORTED;
   if (epilogue == MT_EPI_QKV_HM) {
-    if (!bias) return MT_ERR_UNSUPPORTED;
+    if (!bias || N % 48 != 0) return MT_ERR_UNSUPPORTED;      // (head-major layout: N = 3 x heads x 48; the caller's fallback reports BAD_ARG)
     hipLaunchKernelGGL((gemm_nt_ps_kernel<MT_EPI_QKV_HM, true>), dim3(grid), dim3(256), 0, s, g);
   } else if (bias) {
     hipLaunchKernelGGL((gemm_nt_ps_kernel<MT_EPI_BIAS, true>), dim3(grid), dim3(256), 0, s, g);

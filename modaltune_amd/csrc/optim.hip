@@ -58,11 +58,11 @@ __global__ __launch_bounds__(256) void distill_loss_kernel(const float* __restri
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float grad_mult,
-                             const float* __restrict__ scale, const int* __restrict__ found_inf, const int* __restrict__ step_dev,
-                             const float* __restrict__ lr_dev) {
+                             float lr, float b1, float b2, float omb1, float omb2, float eps, float wd, float decay, float bc1, float bc2s,
+                             float grad_mult, const float* __restrict__ scale, const int* __restrict__ found_inf,
+                             const int* __restrict__ step_dev, const float* __restrict__ lr_dev) {
   if (found_inf && *found_inf) return;       // GradScaler.step: skip the whole update when a grad is inf/nan
-  if (lr_dev) lr = *lr_dev;                  // the schedule's current learning rate lives on the device (graph replays read it)
+  if (lr_dev) { lr = *lr_dev; decay = 1.0f - lr * wd; }   // the schedule's current learning rate lives on the device (graph replays read it)
   if (step_dev) {                            // optimiser step count lives on the device (skipped steps do not count)
     const float st = (float)(*step_dev + 1);
     bc1 = 1.0f - powf(b1, st);
@@ -71,9 +71,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   const float inv_scale = grad_mult * (scale ? 1.0f / *scale : 1.0f);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * inv_scale;
-    float pi = p[i] * (1.0f - lr * wd);
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    float pi = p[i] * decay;
+    const float mi = b1 * m[i] + omb1 * gi;                 // (omb = 1 - beta formed in double on the host, as torch does)
+    const float vi = b2 * v[i] + omb2 * gi * gi;
     pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
@@ -228,16 +228,17 @@ extern "C" int mt_distill_loss(const float* logits, const float* target, int R, 
   return MT_OK;
 }
 
-extern "C" int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int step_count, const int* step_dev, float grad_mult,
+extern "C" int mt_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, int step_count, const int* step_dev, float grad_mult,
                              const float* scale, int* found_inf, const float* lr_dev, mt_stream_t stream) {
   if (!p || !g || !m || !v || n <= 0 || (step_count < 1 && !step_dev)) return MT_ERR_BAD_ARG;
   if (step_count < 1) step_count = 1;
-  const float bc1 = 1.0f - powf(beta1, (float)step_count);
-  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step_count));
+  const float bc1 = (float)(1.0 - pow(beta1, (double)step_count));
+  const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step_count));
   const int grid = (int)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2s, grad_mult, scale, (const int*)found_inf, step_dev, lr_dev);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)beta1, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(1.0 - lr * weight_decay), bc1, bc2s,
+                     grad_mult, scale, (const int*)found_inf, step_dev, lr_dev);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

@@ -143,6 +143,7 @@ class Engine:
         self.group_sizes = list(group_sizes)
         self.store = ParamStore(cfg, group_sizes, self.device)
         self.tape = Tape(self.device)
+        self._fresh_arenas = {"need": 0, "pool": []}      # gradient arenas of the per-call tapes (module API), see Tape.__init__
         self.tape.on_realloc = self._bump_generation
         self._main_tape = self.tape
         self.seg_lengths = segment_lengths(cfg.max_wsi_size, cfg.tile_size)
@@ -423,7 +424,7 @@ class Engine:
         ws = self._workspace(B, L, fresh=fresh)
         # fresh: this call owns its tape (several forwards alive at once); the engine's long-lived tape -- whose gradient
         # arena captured graphs point into -- is put back before returning
-        self.tape = Tape(self.device) if fresh else self._main_tape
+        self.tape = Tape(self.device, shared=self._fresh_arenas) if fresh else self._main_tape
         tape = self.tape
         if fresh:
             tape.lease = ws["_lease"]             # the backward closures read views of the leased store

@@ -60,10 +60,19 @@ class Param:
 
 
 class Tape:
-    def __init__(self, device):
+    def __init__(self, device, shared: Optional[dict] = None):
+        """shared (Engine: the per-call tapes of the module API): {"need": elements the last such tape asked for, "pool": [free
+        arenas]} -- a short-lived tape takes its zero-initialised gradient arena from there (sized by its predecessors' demand)
+        and hands it back when it dies, so the ~110 gradient buffers of a call cost ONE fill instead of one each."""
         self.device = device
+        self.shared = shared
         self.back: List[Callable[[], None]] = []
-        self._ones = torch.ones(4096, device=device)
+        if shared is not None:
+            if "ones" not in shared:
+                shared["ones"] = torch.ones(4096, device=device)
+            self._ones = shared["ones"]
+        else:
+            self._ones = torch.ones(4096, device=device)
         self.grad_enabled = True
         self.lease = None         # (Engine: keeps a recycled per-call workspace alive as long as this tape's closures may read it)
         # Zero-initialised gradient storage: one flat buffer cleared with ONE fill per step instead of a fill launch per
@@ -79,6 +88,12 @@ class Tape:
         _ACTIVE = self
         self.back.clear()
         need = self._arena_used + self._arena_miss
+        if self.shared is not None and self._arena is None and self.grad_enabled:
+            need = max(need, int(self.shared.get("need", 0)))
+            pool = self.shared["pool"]
+            fit = [i for i, a in enumerate(pool) if a.numel() >= need]
+            if need > 0 and fit:
+                self._arena = pool.pop(min(fit, key=lambda i: pool[i].numel()))
         if need > 0 and (self._arena is None or need > self._arena.numel()):
             self._arena = torch.empty(need + need // 4 + 1024, device=self.device, dtype=torch.float32)
             if self.on_realloc is not None:
@@ -86,6 +101,16 @@ class Tape:
         self._arena_used = self._arena_miss = 0
         if self._arena is not None and self.grad_enabled:      # forward-only passes allocate no gradients
             self._arena.zero_()
+
+    def __del__(self):
+        sh = getattr(self, "shared", None)
+        try:
+            if sh is not None:
+                sh["need"] = max(int(0.9 * sh.get("need", 0)), self._arena_used + self._arena_miss)
+                if self._arena is not None and len(sh["pool"]) < 6:
+                    sh["pool"].append(self._arena)
+        except Exception:       # interpreter shutdown
+            pass
 
     def zeros_like(self, t: torch.Tensor) -> torch.Tensor:
         n = t.numel()

@@ -95,7 +95,7 @@ class GridStage:
     def ensure(self, L: int, C: int) -> bool:
         if L <= self.cap and C == self.C:
             return False
-        cap = max(L, self.cap + self.cap // 4)
+        cap = self.cap if L <= self.cap else -(-max(L, self.cap + self.cap // 4) // 256) * 256     # (a new feature width alone keeps the capacity)
         dev = self.dev
         self.f = torch.empty(cap, C, dtype=F32, device=dev)
         self.c = torch.empty(cap, 2, dtype=F32, device=dev)
@@ -273,6 +273,7 @@ class NativeBackbone:
     """The frozen TITAN-style ViT on the HIP kernels (module docstring).  Construct with the user's `VisionTransformer`; raises
     `Unsupported` (with the reason) when a structural or numerical check fails."""
     kind = "native"
+    alibi_table_budget_bytes = 16 << 30      # refuse (clearly) a slide whose fp16 distance table would exceed this (N ~ 92 k tokens)
     PROBE_TOL = 2e-2          # fp16-operand kernels vs the module's fp32 torch code, relative max error on the probe slide
 
     def __init__(self, vit: nn.Module, device, self_check: bool = True):
@@ -289,10 +290,13 @@ class NativeBackbone:
         self.depth = len(blocks)
         # The native blocks are deterministic; the reference keeps the frozen backbone's stochastic layers alive in train mode
         # (SURVEY fact 3).  A module that HAS such layers with p > 0 is not what the kernels implement.
+        # Such a module still runs natively in eval mode, where those layers are identities (embedding extraction, TM:252-327);
+        # putting the MODEL in train mode is what is refused (TITANGeneAdapter.train), not its construction.
+        self.stochastic_layers = []
         for nm, m in vit.named_modules():
             p = getattr(m, "p", None) if isinstance(m, (nn.Dropout, nn.AlphaDropout)) else getattr(m, "drop_prob", None)
             if isinstance(p, (int, float)) and p > 0:
-                raise Unsupported(f"{nm}: {type(m).__name__}(p = {p}) inside the backbone (the native blocks have no stochastic layers)")
+                self.stochastic_layers.append(f"{nm}: {type(m).__name__}(p = {p})")
         D = None
         self.blocks: List[dict] = []
         for l, blk in enumerate(blocks):
@@ -596,6 +600,12 @@ class NativeBackbone:
         and kernel of the step reads the same one).  Returns (plan, tensors to keep alive)."""
         if not self.alibi:
             return ops.make_dense_plan(N, B, self.H), ()
+        need = 2 * ops.alibi_dist_halves(N)          # the table is O(N^2): 34 MB at N = 4097, 0.8 GB at 20 k, 4.3 GB at 46 k tokens
+        free = torch.cuda.mem_get_info(self.dev)[0] if self.dev.type == "cuda" else need
+        if need > self.alibi_table_budget_bytes or need > free:
+            raise ValueError(f"TITAN slide with {N - 1} foreground cells: the ALiBi distance table needs {need / 2**30:.2f} GiB of fp16 "
+                             f"(2 N^2 bytes; budget `backbone.alibi_table_budget_bytes` = {self.alibi_table_budget_bytes / 2**30:.1f} GiB, "
+                             f"free device memory {free / 2**30:.1f} GiB): subsample the slide or raise the budget")
         dist = torch.empty(ops.alibi_dist_halves(N), dtype=H16, device=self.dev)
         ops.alibi_dist(cells.contiguous(), N, dist)
         return ops.make_dense_plan(N, B, self.H, dist, self.nslope), (dist,)
@@ -736,7 +746,7 @@ class TitanEngine(Engine):
         x = x.reshape(-1, x.shape[-1])
         if self._grid_stage.ensure(x.shape[0], x.shape[1]):
             self.generation += 1            # captured graphs read the old buffers
-        return self._grid_stage.run(x.to(self.device), coords, patch_size_lv0, self._titan_err)
+        return self._grid_stage.run(x, coords, patch_size_lv0, self._titan_err)      # (ONE copy: host / device, any float dtype -> the static fp32 buffer)
 
     def forward_slide(self, x, coords, genes, task_onehots, patch_size_lv0: int = 1024, need_grad: bool = True, fresh: bool = False,
                       clinical=None, share: Optional[dict] = None, staged: bool = False) -> torch.Tensor:
@@ -933,12 +943,24 @@ class TITANGeneAdapter(LongNetGeneAdapter):
         self._group = self._token = None
         self._spec = self._hist = self._spec_rows = None
         self.speculate = True
+        self._init_nosync()
         self._call_psz = 1024
-        self.train(True)
+        try:
+            self.train(True)
+        except RuntimeError as e:      # a backbone with live Dropout / DropPath on the native path: usable for inference only
+            warnings.warn(f"{e} -- the model is left in eval() mode")
+            self.train(False)
 
     def train(self, mode: bool = True):
         """The reference adapter IS the backbone module (TA:42), so model.train() / .eval() reach its blocks; here the module is
         held outside nn.Module's registry, so the mode is forwarded by hand (it matters to the TorchBackbone path)."""
+        eng_bb = getattr(getattr(self, "engine", None), "backbone", None)
+        live = getattr(eng_bb, "stochastic_layers", None)
+        if mode and live:
+            raise RuntimeError("model.train(): the slide encoder has live stochastic layers (" + "; ".join(live[:3]) + (" ..." if len(live) > 3 else "")
+                               + ") which the reference keeps active in train mode and the native HIP blocks do not implement; the model runs "
+                               "natively in eval() -- for training pass backbone_impl=\"torch\" (the module's own blocks between the HIP "
+                               "kernels, slower) or set those probabilities to 0")
         super().train(mode)
         bb = getattr(self, "_backbone_module", None)
         if bb is not None:
@@ -976,21 +998,29 @@ class TITANGeneAdapter(LongNetGeneAdapter):
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Adapter-side keys go to the engine, the rest to the attached slide-encoder module; returns the missing / unexpected keys
+        of both halves (strict: raises on any, like nn.Module)."""
         bb = self._backbone_module
         own = {k: v for k, v in state_dict.items() if k in self._params}
         rest = {k: v for k, v in state_dict.items() if k not in self._params}
         missing = [k for k in self._params if k not in own]
-        if strict and missing:
-            raise KeyError(f"state_dict mismatch: missing {missing[:5]}")
+        unexpected = []
+        if bb is not None:
+            have = bb.state_dict()
+            missing = [k for k in have if k not in rest] + missing
+            unexpected = [k for k in rest if k not in have]
+        else:
+            unexpected = list(rest)
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for {}: missing keys {}, unexpected keys {}{}".format(
+                type(self).__name__, missing, unexpected, "" if bb is not None else " (no backbone attached)"))
         full = {k: (own[k] if k in own else self.engine.store.tensors[k]) for k in self.engine.store.tensors}
         self.engine.load_state_dict(full, strict=False)
         if bb is not None and rest:
-            bb.load_state_dict(rest, strict=strict)
+            bb.load_state_dict({k: v for k, v in rest.items() if k not in unexpected}, strict=False)
             self._rebuild_backbone()
-        elif strict and rest:
-            raise KeyError(f"unexpected keys (no backbone attached): {list(rest)[:5]}")
         self._versions = None
-        return torch.nn.modules.module._IncompatibleKeys([], [])
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def forward(self, x, coords, genes, task_token=None, patch_size_lv0=1024, clinical=None, **kwargs):
         self._call_psz = int(patch_size_lv0)

@@ -81,6 +81,10 @@ class TrainStep:
         self.graph_replays = 0
         self.eager_steps = 0
         self.patch_size_lv0 = 1024          # TITAN configuration only (titan_adapter.py:335)
+        # bench.py --gpus N: set to a list to collect, per step, HIP events around the two places a collective can be EXPOSED on the
+        # compute stream -- ("grad", e0, e1): last backward kernel -> the optimiser may start (bucket all-reduces / the last bucket's
+        # reduce-scatter not hidden under the backward); ("param", e0, e1): the next step's wait for the sharded parameter all-gather
+        self.comm_events: Optional[list] = None
 
     # ------------------------------------------------------------------ learning-rate schedule hook
     @property
@@ -135,7 +139,7 @@ class TrainStep:
 
     def _fwd_bwd(self, x, coords, genes, text, clinical, staged_geometry=None, reduce: bool = True):
         eng = self.engine
-        self.reducer.wait_params()        # the all-gather of the last step's sharded parameter update (no-op otherwise)
+        self._wait_params()               # the all-gather of the last step's sharded parameter update (no-op otherwise)
         eng.grad_ready_hook = self._on_grad_ready if (reduce and self._world() > 1) else None
         if eng.stochastic:
             ops.rng_advance(eng.rng)          # a fresh set of dropout / DropPath masks per step
@@ -188,14 +192,31 @@ class TrainStep:
         ops.scaler_update(self.scale, self.tracker, self.found_inf, self.step_dev, 2.0, 0.5, self.growth_interval)
         eng.refresh_trainable_caches()
 
+    def _mark(self):
+        if self.comm_events is None or self._cap is not None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _wait_params(self):
+        e0 = self._mark() if self.reducer._param_pending else None
+        self.reducer.wait_params()
+        if e0 is not None:
+            self.comm_events.append(("param", e0, self._mark()))
+
     def optimizer_step(self):
         """Launch whatever buckets the backward has not started, wait for the collectives, AdamW + weight-cache refresh; with
         a sharded last bucket (world > 1) the updated shards are then all-gathered asynchronously (waited for at the top of the
         next step)."""
+        e0 = self._mark()
         self.reducer.start_rest()
         world = self.reducer.wait()
         if self.reducer.sharded:
             self._check_finite()
+        if e0 is not None:
+            self.comm_events.append(("grad", e0, self._mark()))
+        if self.reducer.sharded:
             self._adam_and_refresh(world, check=False)
             self.reducer.start_param_gather()
         else:
@@ -239,7 +260,7 @@ class TrainStep:
         else:
             Lv = L
             eng.stage_inputs(x, coords, B=B)      # (may grow the workspace: bumps eng.generation)
-        self.reducer.wait_params()                # last step's sharded parameter all-gather ran under the staging above
+        self._wait_params()                       # last step's sharded parameter all-gather ran under the staging above
         self._sgenes.copy_(gflat, non_blocking=True)
         self._stext.copy_(text, non_blocking=True)
         if self._sclin is not None:
@@ -283,10 +304,13 @@ class TrainStep:
         self.last_logits = ent.logits
         self.graph_replays += 1
         if world > 1:
+            e0 = self._mark()
             self.reducer.start_rest()
             self.reducer.wait()
             if self.reducer.sharded:
                 self._check_finite()
+            if e0 is not None:
+                self.comm_events.append(("grad", e0, self._mark()))
             self._opt_graph.replay()
             self.reducer.start_param_gather()
         return self.loss

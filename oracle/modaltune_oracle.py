@@ -23,12 +23,39 @@ import torch.nn.functional as F
 
 LN_EPS = 1e-5
 
+# Diagnostic switch (tests/test_grad_rounding_cpu.py only; parity is defined with it OFF): emulate the storage precision of the
+# reference's GPU run -- `torch.cuda.amp.autocast` (train_modaltune.py:216) rounds the operands and the result of every nn.Linear /
+# attention product over the patch rows to fp16 -- in an otherwise fp64 computation.  Rounding is straight-through (the backward
+# sees the identity), so the gradients are the exact gradients of the network evaluated at the ROUNDED forward activations: what
+# remains is the forward rounding's effect on the gradients, with no fp16 gradient stream at all (F16_GRAD_SCALE adds that stream).
+F16_PATCH_OPERANDS = False
+F16_GRAD_SCALE = 0.0          # > 0: the gradients flowing back through those products are rounded to fp16 too, at this loss scale
+
+
+class _Round16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.float16).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        if F16_GRAD_SCALE > 0.0:
+            return (g * F16_GRAD_SCALE).to(torch.float16).to(g.dtype) / F16_GRAD_SCALE
+        return g
+
+
+def _r16(t):
+    return _Round16.apply(t) if F16_PATCH_OPERANDS else t
+
 
 def _ln(x, sd, prefix, eps=LN_EPS):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
 
 
-def _linear(x, sd, prefix):
+def _linear(x, sd, prefix, patch_rows=False):
+    """nn.Linear; patch_rows: x holds the slide's patch rows (the products the GPU runs with fp16 operands, see F16_PATCH_OPERANDS)."""
+    if patch_rows and F16_PATCH_OPERANDS:
+        return _r16(F.linear(_r16(x), _r16(sd[prefix + ".weight"]), sd[prefix + ".bias"]))
     return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
 
 
@@ -37,12 +64,16 @@ def _linear(x, sd, prefix):
 # (models/vitadapter/adapter_modules.py:42-49,157-164): separate q/k/v projection weights, a packed
 # in_proj_bias, per-head softmax(q k^T / sqrt(E/heads)) v, concat, out_proj.
 # ------------------------------------------------------------------------------------------------
-def mha(q_in, k_in, v_in, sd, prefix, heads):
+def mha(q_in, k_in, v_in, sd, prefix, heads, patch_q=False, patch_kv=False):
     E = sd[prefix + ".q_proj_weight"].shape[0]
     b = sd[prefix + ".in_proj_bias"]
-    q = F.linear(q_in, sd[prefix + ".q_proj_weight"], b[:E])
-    k = F.linear(k_in, sd[prefix + ".k_proj_weight"], b[E:2 * E])
-    v = F.linear(v_in, sd[prefix + ".v_proj_weight"], b[2 * E:])
+    rq = _r16 if patch_q else (lambda t: t)
+    rk = _r16 if patch_kv else (lambda t: t)
+    q = rq(F.linear(rq(q_in), rq(sd[prefix + ".q_proj_weight"]), b[:E]))
+    k = rk(F.linear(rk(k_in), rk(sd[prefix + ".k_proj_weight"]), b[E:2 * E]))
+    v = rk(F.linear(rk(v_in), rk(sd[prefix + ".v_proj_weight"]), b[2 * E:]))
+    if patch_q or patch_kv:          # (both sides of the cross attention sit in fp16 images next to the patch rows)
+        q, k, v = _r16(q), _r16(k), _r16(v)
     B, Lq, _ = q.shape
     Lk = k.shape[1]
     hd = E // heads
@@ -52,29 +83,34 @@ def mha(q_in, k_in, v_in, sd, prefix, heads):
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     a = torch.softmax(s, dim=-1) @ v
     a = a.transpose(1, 2).reshape(B, Lq, E)
+    if patch_q:
+        return _r16(F.linear(_r16(a), _r16(sd[prefix + ".out_proj.weight"]), sd[prefix + ".out_proj.bias"]))
     return F.linear(a, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
 
 
-def cross_attention_pre(tgt, memory, sd, prefix, heads, pos=None, query_pos=None):
-    """CrossAttentionLayer.forward_pre (adapter_modules.py:210-234), normalize_before=True, with_cffn=True."""
+def cross_attention_pre(tgt, memory, sd, prefix, heads, pos=None, query_pos=None, patch_q=False, patch_kv=False):
+    """CrossAttentionLayer.forward_pre (adapter_modules.py:210-234), normalize_before=True, with_cffn=True.
+    patch_q / patch_kv: which side holds the slide's patch rows (diagnostic fp16 emulation only, see F16_PATCH_OPERANDS)."""
     t2 = _ln(tgt, sd, prefix + ".norm")
     mem = _ln(memory, sd, prefix + ".norm_kq")
-    q = _linear(t2 if query_pos is None else t2 + query_pos, sd, prefix + ".q_proj")
+    q = _linear(t2 if query_pos is None else t2 + query_pos, sd, prefix + ".q_proj", patch_rows=patch_q)
     kv = mem if pos is None else mem + pos
-    a = mha(q, kv, kv, sd, prefix + ".multihead_attn", heads)
+    a = mha(q, kv, kv, sd, prefix + ".multihead_attn", heads, patch_q=patch_q, patch_kv=patch_kv)
+    if patch_q and F16_PATCH_OPERANDS:       # (the Injector's output_proj epilogue writes the fp32 residual stream directly)
+        return tgt + F.linear(_r16(a), _r16(sd[prefix + ".output_proj.weight"]), sd[prefix + ".output_proj.bias"])
     return tgt + _linear(a, sd, prefix + ".output_proj")
 
 
 def injector(x, c, pe, sd, prefix, heads):
     """Injector.forward (adapter_modules.py:359-369): attn(query=x, feat=c, pos=pe, query_pos=None);
     y = x + gamma * attn where attn already contains the inner residual."""
-    attn = cross_attention_pre(x, c, sd, prefix + ".attn", heads, pos=pe, query_pos=None)
+    attn = cross_attention_pre(x, c, sd, prefix + ".attn", heads, pos=pe, query_pos=None, patch_q=True)
     return x + sd[prefix + ".gamma"] * attn
 
 
 def extractor(c, x, pe, sd, prefix, heads):
     """Extractor.forward (adapter_modules.py:321-335) + FFNLayer.forward_pre (284-287); SURVEY A.2."""
-    attn = cross_attention_pre(c, x, sd, prefix + ".attn", heads, pos=None, query_pos=pe)
+    attn = cross_attention_pre(c, x, sd, prefix + ".attn", heads, pos=None, query_pos=pe, patch_kv=True)
     c1 = c + attn
     t = _ln(c1, sd, prefix + ".ffn.norm")
     t = _linear(F.relu(_linear(t, sd, prefix + ".ffn.linear1")), sd, prefix + ".ffn.linear2")
@@ -230,17 +266,17 @@ def encoder_layer(x, sd, prefix, seg_lengths, ratios, heads=16, attn_impl="auto"
     pre-LN (subln), alpha = 1, dropout/droppath off.  SURVEY A.4."""
     B, N, D = x.shape
     h = _ln(x, sd, prefix + ".self_attn_layer_norm")
-    q = _linear(h, sd, prefix + ".self_attn.q_proj").view(B, N, heads, D // heads)
-    k = _linear(h, sd, prefix + ".self_attn.k_proj").view(B, N, heads, D // heads)
-    v = _linear(h, sd, prefix + ".self_attn.v_proj").view(B, N, heads, D // heads)
-    a = dilated_attention_core(q, k, v, seg_lengths, ratios, impl=attn_impl)
+    q = _linear(h, sd, prefix + ".self_attn.q_proj", patch_rows=True).view(B, N, heads, D // heads)
+    k = _linear(h, sd, prefix + ".self_attn.k_proj", patch_rows=True).view(B, N, heads, D // heads)
+    v = _linear(h, sd, prefix + ".self_attn.v_proj", patch_rows=True).view(B, N, heads, D // heads)
+    a = _r16(dilated_attention_core(q, k, v, seg_lengths, ratios, impl=attn_impl))
     a = _ln(a, sd, prefix + ".self_attn.inner_attn_ln")
-    x = x + _linear(a, sd, prefix + ".self_attn.out_proj")
+    x = x + _linear(a, sd, prefix + ".self_attn.out_proj", patch_rows=True)
     h = _ln(x, sd, prefix + ".final_layer_norm")
-    h = _linear(h, sd, prefix + ".ffn.fc1")
-    h = F.gelu(h.float()).type_as(h)          # GELU is forced to fp32 (feedforward_network.py:136)
+    h = _linear(h, sd, prefix + ".ffn.fc1", patch_rows=True)
+    h = F.gelu(h.float()).type_as(h) if not F16_PATCH_OPERANDS else F.gelu(h)     # GELU is forced to fp32 (feedforward_network.py:136)
     h = _ln(h, sd, prefix + ".ffn.ffn_layernorm")
-    return x + _linear(h, sd, prefix + ".ffn.fc2")
+    return x + _linear(h, sd, prefix + ".ffn.fc2", patch_rows=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -297,7 +333,7 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg, x, coords, genes, task_token
     """x [1,L,in], coords [1,L,2], genes list of [1,n_i], task_token [num_tasks] -> [1, output_dim]."""
     heads = cfg.num_heads
     ratios = (1, 2, 4, 8, 16)
-    x = F.linear(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"])          # LVA:232
+    x = F.linear(_r16(x), _r16(sd["patch_embed.proj.weight"]), sd["patch_embed.proj.bias"])          # LVA:232
     x = x + pos_embed_rows(coords, cfg.embed_dim, cfg.slide_ngrids, x.dtype)             # LVA:235-237
     cls = sd["cls_token"] + 0.0                                                          # + pos_embed[0] == zeros
     c = gene_encoder(genes, sd, depth=cfg.gene.depth)                                    # LVA:257

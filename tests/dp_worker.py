@@ -122,8 +122,10 @@ def ddp_module(rank, world, out):
     from oracle import modaltune_oracle as O
     sizes = synth.toy_group_sizes()
     groups = {i: ["g"] * n for i, n in enumerate(sizes)}
-    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, depth=3, slide_ngrids=NGRIDS,
-                              interaction_indexes=[[0, 0], [1, 1], [2, 2]], dropout=0.0, drop_path_rate=0.0, multi_task=3)
+    from modaltune_amd.config import GIGAPATH_JSON
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3,
+                              **dict(GIGAPATH_JSON, depth=3, slide_ngrids=NGRIDS, interaction_indexes=[[0, 0], [1, 1], [2, 2]], dropout=0.0,
+                                     drop_path_rate=0.0))
     cfg = model.cfg
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, sizes, SEED).items()}, strict=True)
     x, coords, genes, text = _slide(rank, sizes)

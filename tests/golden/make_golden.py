@@ -464,6 +464,22 @@ def init_case():
     print("wrote init_stats.json:", {k: len(v.get("stats", v)) for k, v in out.items()})
 
 
+def ctor_case():
+    """The architecture the REFERENCE's constructors build when the caller passes only what has no usable default there
+    (longvit_adapter.py:35-53: use_prompt_sa False, prompt_agg "cls", token_agg "cat"): state_dict key -> shape, trainable keys."""
+    out = {}
+    sizes = synth.toy_group_sizes(6)
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    minimal = dict(embed_dim=768, depth=3, slide_ngrids=128, interaction_indexes=[[0, 0], [1, 1], [2, 2]], pretrained=False)
+    for name in ("longnetvit_gene_adapter", "longnetvit_gene_clinical_adapter"):
+        torch.manual_seed(0)
+        model = Aggregator.create(name, gene_group_defination=groups, **minimal, multi_task=3)
+        out[name] = {"kwargs": minimal, "shapes": {k: list(v.shape) for k, v in model.state_dict().items()},
+                     "trainable": [k for k, p in model.named_parameters() if p.requires_grad]}
+    json.dump(out, open(os.path.join(HERE, "ctor_defaults.json"), "w"))
+    print("wrote ctor_defaults.json:", {k: len(v["shapes"]) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["adapter", "layer", "gene", "m37", "m1500", "m512", "clin"]
@@ -473,6 +489,8 @@ if __name__ == "__main__":
         model_case("L37_d3_cat", 37, 3, [[0, 0], [1, 1], [2, 2]], seed=16, token_agg="cat")
     if "init" in which:    # constructor-time state of the reference (init families, pretrained loading)
         init_case()
+    if "ctor" in which:    # the reference constructor's own defaults for omitted keys
+        ctor_case()
     if "titan" in which:   # TITAN configuration (BASELINE config 4 family) on the stand-in backbone
         titan_case("titan_L300", 300, seed=21)
         titan_case("titan_L170_clin", 170, seed=22, clinical=True, grid=16)

@@ -43,7 +43,7 @@ lib = _lib.load()
 for name, sig in _lib.SIGNATURES.items():
     if name in ("mt_version", "mt_status_string", "mt_pool_attn_workspace_floats", "mt_alibi_dist_halves"):      # (plain value functions)
         continue
-    args = [0 if t in (_lib.I, _lib.L) else 0.0 if t is _lib.F else None for t in sig]
+    args = [0 if t in (_lib.I, _lib.L) else 0.0 if t in (_lib.F, _lib.D) else None for t in sig]
     print(name, getattr(lib, name)(*args), flush=True)
 '''
 

@@ -196,3 +196,11 @@ def _check_bench(backend):
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
     assert out["launch"] == "hipGraph replay" and out["graph_replays"] >= 3
     assert out["value"] > 0 and out["skipped_steps"] == 0
+    # the N > 1 line explains itself -- the collective really ran over `world` ranks, the bucket sizes, and how
+    # much of the gradient / parameter exchange was EXPOSED on the compute stream (HIP events, max over ranks)
+    c = out["comm"]
+    assert c["ranks_seen_by_all_reduce"] == 2 and c["backend"] == backend and c["last_bucket_sharded"] is True
+    assert len(c["bucket_bytes"]) == 4 and all(b > 0 for b in c["bucket_bytes"]) and sum(c["bucket_bytes"]) > 30e6
+    assert c["comm_exposed_events"] == 3 and c["comm_exposed_ms"] >= 0.0
+    assert c["param_gather_exposed_ms"] >= 0.0 and len(c["per_rank_ms_per_step"]) == 2
+    assert max(c["per_rank_ms_per_step"]) <= out["ms_per_step"] * 1.001

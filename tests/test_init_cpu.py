@@ -2,6 +2,7 @@
 slide_encoder.py:292-322): init families pinned to statistics of the REFERENCE's freshly constructed model
 (tests/golden/init_stats.json, written by `make_golden.py init`), `pretrained` honoured like the reference does.
 Construction and state_dict need no GPU (no kernel runs before the first forward)."""
+import contextlib
 import json
 import math
 import os
@@ -103,6 +104,49 @@ def test_pretrained_loads_slide_encoder_pth_like_the_reference(ref_stats, tmp_pa
     with pytest.raises(ValueError, match="cls_token"):
         Aggregator.create("longnetvit_gene_adapter", gene_group_defination=GROUPS, **dict(SHIPPED_JSON, slide_ngrids=128), multi_task=3,
                           device="cpu", weights_location=str(other))
+
+
+@pytest.mark.parametrize("name", ["longnetvit_gene_adapter", "longnetvit_gene_clinical_adapter"])
+def test_omitted_constructor_keys_take_the_reference_constructor_defaults(golden_dir, name):
+    """`Aggregator.create(...)` with keys left out must build what the REFERENCE's constructor builds for them
+    (longvit_adapter.py:35-53: prompt_agg "cls", token_agg "cat", no prompt self-attention), not the shipped JSON's architecture:
+    same state_dict keys, shapes and trainable set as `make_golden.py ctor` recorded from the reference."""
+    ref = json.load(open(os.path.join(golden_dir, "ctor_defaults.json")))[name]
+    with pytest.warns(UserWarning) if ref["kwargs"].get("pretrained") else contextlib.nullcontext():
+        model = Aggregator.create(name, gene_group_defination=GROUPS, multi_task=3, device="cpu", **ref["kwargs"])
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(ref["shapes"].keys())
+    assert {k: list(v.shape) for k, v in sd.items()} == ref["shapes"]
+    assert [k for k, p in model.named_parameters() if p.requires_grad] == ref["trainable"]
+    assert "gene_cls" in sd and not any(k.startswith("prompt_selfattention.") for k in sd) and sd["final_norm.weight"].numel() > 768
+    # nothing usable to fall back on for these two (reference: interaction_indexes=None is iterated; embed_dim 256 is another backbone)
+    with pytest.raises(TypeError, match="interaction_indexes"):
+        Aggregator.create(name, gene_group_defination=GROUPS, multi_task=3, device="cpu", embed_dim=768)
+    with pytest.raises(ValueError, match="768"):
+        Aggregator.create(name, gene_group_defination=GROUPS, multi_task=3, device="cpu", interaction_indexes=[[0, 3], [4, 7], [8, 11]])
+
+
+def test_load_state_dict_reports_missing_and_unexpected_keys_and_to_refuses_another_device():
+    """train_modaltune.py:546-547 prints what a non-strict load returns; `.to(device)` (train_modaltune.py:126) is accepted for the
+    engine's own device and refused (not ignored) for another one."""
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=GROUPS, multi_task=3, device="cpu",
+                              **dict(SHIPPED_JSON, slide_ngrids=128, depth=3, interaction_indexes=[[0, 0], [1, 1], [2, 2]], pretrained=False))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    full = model.load_state_dict(sd, strict=True)
+    assert list(full.missing_keys) == [] and list(full.unexpected_keys) == []
+    del sd["final_project.bias"], sd["encoder.layers.1.ffn.fc1.weight"]
+    sd["projector.weight"] = torch.zeros(2)
+    sd["gene_pe"] = sd["gene_pe"] + 1.0
+    res = model.load_state_dict(sd, strict=False)
+    assert sorted(res.missing_keys) == ["encoder.layers.1.ffn.fc1.weight", "final_project.bias"] and list(res.unexpected_keys) == ["projector.weight"]
+    assert torch.equal(model.state_dict()["gene_pe"], sd["gene_pe"])
+    with pytest.raises((RuntimeError, KeyError), match="final_project.bias"):
+        model.load_state_dict(sd, strict=True)
+    assert model.to("cpu") is model and model.to(torch.device("cpu")) is model and model.float() is model
+    with pytest.raises(RuntimeError, match="lives on"):
+        model.to("meta")
+    with pytest.raises(RuntimeError, match="fp32"):
+        model.half()
 
 
 def test_titan_constructor_takes_the_reference_route_to_the_backbone(tmp_path, monkeypatch, golden_dir):

@@ -118,6 +118,38 @@ def test_titan_gridding_and_ragged_bags(golden_dir, impl):
                 outs[L] = o.clone()
 
 
+def test_backbone_with_live_dropout_runs_natively_in_eval_and_refuses_train():
+    """a slide encoder that carries Dropout / DropPath with p > 0 is usable for inference on the native blocks (those
+    layers are identities in eval mode); what is refused -- with the `backbone_impl="torch"` hint -- is putting the model in train
+    mode, where the reference keeps them active and the HIP blocks have no such layers.  Construction warns and
+    leaves the model in eval()."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    import modaltune_amd.titan  # noqa: F401
+    sizes = synth.toy_group_sizes()
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    vit = titan_standin.VisionTransformer()
+    titan_standin.init_standin(vit, 9)
+    vit.blocks.modules_list[2].extra_drop = torch.nn.Dropout(0.1)        # (registered, p > 0: a stochastic layer inside the backbone)
+    with pytest.warns(UserWarning, match="left in eval"):
+        model = Aggregator.create("titan_gene_adapter", gene_group_defination=groups, **TITAN_JSON, multi_task=3, backbone=vit)
+    assert model.backbone_impl == "native" and not model.training
+    inp = synth.synth_inputs_titan(150, sizes, 2)
+    with torch.no_grad():
+        out = model(x=torch.from_numpy(inp["x"]).cuda(), coords=torch.from_numpy(inp["coords"]).cuda(),
+                    genes=[torch.from_numpy(a).cuda() for a in inp["genes"]], task_token=torch.eye(3)[1].cuda())
+    assert out.shape == (1, 256) and bool(torch.isfinite(out).all())
+    with pytest.raises(RuntimeError, match='backbone_impl="torch"'):
+        model.train()
+    assert model.eval() is model
+    vit2 = titan_standin.VisionTransformer()
+    titan_standin.init_standin(vit2, 9)
+    vit2.blocks.modules_list[2].extra_drop = torch.nn.Dropout(0.1)
+    m2 = Aggregator.create("titan_gene_adapter", gene_group_defination=groups, **TITAN_JSON, multi_task=3, backbone=vit2, backbone_impl="torch")
+    assert m2.backbone_impl == "torch" and m2.training
+
+
 def test_titan_without_backbone_fails_loudly():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

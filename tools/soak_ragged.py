@@ -3,7 +3,7 @@ and the drop-in nn.Module driven like the reference loop; watches device memory 
 import os, sys, time, random, resource, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from modaltune_amd import synth
-from modaltune_amd.config import ModelConfig
+from modaltune_amd.config import GIGAPATH_JSON, ModelConfig
 from modaltune_amd.engine import Engine
 from modaltune_amd.trainer import TrainStep
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -42,7 +42,7 @@ else:
     import json
     from bench import ROOT  # noqa: F401
     groups = {i: [f"g{i}_{j}" for j in range(n)] for i, n in enumerate(sizes)}
-    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3).to(dev)
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3, **GIGAPATH_JSON).to(dev)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, sizes, seed=0).items()}, strict=True)
     model.train()
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
