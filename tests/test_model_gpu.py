@@ -839,7 +839,8 @@ def test_fused_adamw_is_torch_adamw_on_the_models_flat_buffers():
     for a, b in zip(other, r2.param_groups[0]["params"]):
         a.grad = torch.ones_like(a); b.grad = torch.ones_like(b)
     o2.step(); r2.step()
-    assert o2.last_step_fused is False and all(torch.equal(a, b) for a, b in zip(other, r2.param_groups[0]["params"]))
+    assert o2.last_step_fused is False          # (torch's own single-tensor step on this object's state; the twin runs torch's foreach flavour)
+    assert all(torch.allclose(a, b, rtol=1e-6, atol=1e-7) for a, b in zip(other, r2.param_groups[0]["params"]))
 
 
 def test_lr_schedule_reaches_captured_graphs_and_eager_steps(golden_dir):
