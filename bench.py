@@ -663,6 +663,39 @@ def main():
     run(prof_steps, graphed=False, first=nwarm + args.steps)
     barrier()
     timer, ops.TIMER = ops.TIMER, None
+    skipped = nwarm + args.steps + prof_steps - int(ts.step_dev)
+    # the token side on its own: every token-side launch of ONE step recorded in order, captured as a hipGraph on the same buffers and
+    # replayed -- what the ~220 small dependent launches cost INSIDE the replayed step (HIP events around each launch of the eager pass
+    # above add the event overhead to every one of them: that table's `token_side` row is an upper bound)
+    token_graph = None
+    if world == 1 and not args.ragged:
+        try:
+            ops.RECORD, ops.RECORD_KEEP[:] = [], []
+            run(1, graphed=False, first=nwarm + args.steps + prof_steps)
+            rec, ops.RECORD = ops.RECORD, None
+            torch.cuda.synchronize()
+            gs = torch.cuda.Stream()
+            with torch.cuda.stream(gs):
+                tg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(tg, stream=gs):
+                    for fn, a, k in rec:
+                        fn(*a, **k)
+                tg.replay(); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(gs)
+                for _ in range(10):
+                    tg.replay()
+                e1.record(gs); torch.cuda.synchronize()
+            token_graph = {"launches": len(rec), "ms": e0.elapsed_time(e1) / 10,
+                           "how": "all token-side launches of one step (LayerNorms and fp32 products of <= 1024 rows, adds, copies, DropPath rows, "
+                                  "T x T attention, pathway networks, loss head) re-issued in order inside one hipGraph on the step's own buffers, "
+                                  "10 replays"}
+            del tg, rec
+        except Exception as e:       # a measurement aid must never cost the headline line
+            token_graph = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            ops.RECORD = None
+            ops.RECORD_KEEP[:] = []
     if world > 1:
         host = args.backend != "nccl"
         tt = torch.tensor([dt, comm["comm_exposed_ms"], comm["param_gather_exposed_ms"]], device="cpu" if host else dev, dtype=torch.float64)
@@ -674,7 +707,6 @@ def main():
         comm["how"] = ("comm_exposed_ms: HIP events on the compute stream from the end of the backward to the point the optimiser may start "
                        "(bucket all-reduces launched from inside the backward + the last bucket's reduce-scatter + the 4-byte found_inf MAX), "
                        "per step, MAX over ranks; param_gather_exposed_ms: the next step's wait for the sharded parameter all-gather, same rule")
-    skipped = nwarm + args.steps + prof_steps - int(ts.step_dev)
 
     if rank == 0:
         T = cfg.num_tokens
@@ -733,7 +765,7 @@ def main():
             "roofline_worst": worst,
             "roofline_kernels": table,
             "launch": "eager" if (args.eager or args.ragged) else "hipGraph replay",
-            "graph_replays": replays, "eager_steps": eager_steps, "comm": comm,
+            "graph_replays": replays, "eager_steps": eager_steps, "comm": comm, "token_side_in_graph": token_graph,
             "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]},
         }
         default_line = world == 1 and not (args.ragged or args.eager)

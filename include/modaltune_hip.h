@@ -119,8 +119,12 @@ int mt_sgemm_small(const float* A, long as0, long as1, long a_bs, const float* B
  *   backward  A'(m,k) = drop_a(A(m,k)) * act'(a_aux(m,k)) is formed as the dy operand is loaded (a_aux = the saved
  *             pre_out, a_drop = the forward's c_drop): dX = A' W and dW = A'^T x (+ rowsum = db) of one nn.Linear share a launch.
  * pre_out / resid are addressed like C, a_aux like A.  The masks are element dropout of a DENSE tensor: the mask index
- * is the element offset from C / from A (path_p must be 0).  Products of one launch must not write what another reads or
- * writes.  mt_sgemm_small is the one-product, no-fusion form of this entry. */
+ * is the element offset from C / from A.  DropPath of the branch (path_p > 0: one Bernoulli per task pass of rows_per_pass
+ * rows, AM:319,327) rides on the same specs: in c_drop the pass is (row m of C) / rows_per_pass; in a_drop it is
+ * (element offset in A / a_ld) / rows_per_pass with a_ld = the row length of the dense dy tensor (required then).
+ * resid_scale: the residual enters as resid_scale * resid (0 is read as 1; `query + (tgt + f(.))` with tgt == query is
+ * 2 * query + f(.), AM:231,324).  Products of one launch must not write what another reads or writes.  mt_sgemm_small is the
+ * one-product, no-fusion form of this entry. */
 #define MT_SGEMM_MAX 3
 typedef struct {
   const float* A; long as0, as1, a_bs;
@@ -134,6 +138,7 @@ typedef struct {
   MtDropout c_drop;
   const float* a_aux; int a_act;
   MtDropout a_drop;
+  float resid_scale; int a_ld;
 } MtSgemm;
 int mt_sgemm_multi(const MtSgemm* probs, int n, mt_stream_t stream);
 

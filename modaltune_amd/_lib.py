@@ -37,7 +37,7 @@ class MtSgemm(C.Structure):
                 ("bias", P), ("bias_on_m", I), ("C", P), ("cs0", L), ("cs1", L), ("c_bs", L),
                 ("M", I), ("N", I), ("K", I), ("batch", I), ("act", I), ("accumulate", I),
                 ("rowsum", P), ("pre_out", P), ("resid", P), ("c_drop", MtDropout),
-                ("a_aux", P), ("a_act", I), ("a_drop", MtDropout)]
+                ("a_aux", P), ("a_act", I), ("a_drop", MtDropout), ("resid_scale", F), ("a_ld", I)]
 
 
 MT_MAX_BRANCHES = 8

@@ -697,6 +697,8 @@ struct SgemmArgs {
   DropArgs cdrop;     // element dropout of the activation output; mask index = element offset in C (a dense tensor)
   const float* a_aux; int a_act;    // A'(m,k) = drop(A(m,k)) * act'(a_aux(m,k)), a_aux addressed like A
   DropArgs adrop;     // mask index = element offset in A (the dense dy tensor whose forward drew the same mask)
+  float resid_scale;  // C = resid_scale * resid + ...
+  int a_ld;           // row length of the dense tensor behind A (DropPath of a_drop: pass = (offset / a_ld) / rows_per_pass)
   int ak, bk;         // operand rows k-contiguous and 16-byte aligned
   int nx, ny, nblk;   // 16 x 16 tiles along n / m; workgroups of this product (nx * ny * batch)
 };
@@ -731,11 +733,18 @@ MT_DEVINL f32x4 sg_load4(const float* p, long k, long s1) {
 // A' = drop(A) * act'(aux) on 4 consecutive k; off0 = element offset of (row, k) from the tensor base
 template <bool KC>
 MT_DEVINL f32x4 sg_xform4(const SgemmArgs& g, f32x4 a, f32x4 aux, long off0) {
-  if (g.adrop.rng) {
+  if (g.adrop.rng && g.adrop.p > 0.f) {
     if (KC) a *= sg_drop4(g.adrop, off0);
     else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] *= sg_drop1(g.adrop, off0 + e * g.as1);
+    }
+  }
+  if (g.adrop.rng && g.adrop.path_p > 0.f) {      // DropPath of the branch: a factor per task pass of the dense dy tensor's rows
+    if (KC) a *= drop_path_factor(g.adrop, (int)(off0 / g.a_ld) / g.adrop.rows_per_pass);      // (4 consecutive k: one row)
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= drop_path_factor(g.adrop, (int)((off0 + e * g.as1) / g.a_ld) / g.adrop.rows_per_pass);
     }
   }
   if (g.a_aux) {
@@ -811,7 +820,8 @@ MT_DEVINL void sgemm_tile(const SgemmArgs& g, int bx, int by, int bz, float (*pa
       const int kc = ok ? k : kb;
       float av = ap[(long)kc * g.as1];
       const float bv = bp[(long)kc * g.bs1];
-      if (g.adrop.rng) av *= sg_drop1(g.adrop, arow + (long)kc * g.as1);
+      if (g.adrop.rng && g.adrop.p > 0.f) av *= sg_drop1(g.adrop, arow + (long)kc * g.as1);
+      if (g.adrop.rng && g.adrop.path_p > 0.f) av *= drop_path_factor(g.adrop, (int)((arow + (long)kc * g.as1) / g.a_ld) / g.adrop.rows_per_pass);
       if (xp) av *= act_grad(xp[(long)kc * g.as1], g.a_act);
       a[e] = ok ? av : 0.f; b[e] = ok ? bv : 0.f;
     }
@@ -838,8 +848,9 @@ MT_DEVINL void sgemm_tile(const SgemmArgs& g, int bx, int by, int bz, float (*pa
     const long off = (long)bz * g.c_bs + m * g.cs0 + n * g.cs1;
     if (g.pre_out) g.pre_out[off] = v;
     v = apply_act(v, g.act);
-    if (g.cdrop.rng) v *= sg_drop1(g.cdrop, off);
-    if (g.resid) v += g.resid[off];
+    if (g.cdrop.rng && g.cdrop.p > 0.f) v *= sg_drop1(g.cdrop, off);
+    if (g.cdrop.rng && g.cdrop.path_p > 0.f) v *= drop_path_factor(g.cdrop, m / g.cdrop.rows_per_pass);
+    if (g.resid) v += g.resid_scale * g.resid[off];
     float* c = &g.C[off];
     *c = g.accumulate ? *c + v : v;
   }
@@ -951,10 +962,13 @@ static int sgemm_fill(const MtSgemm& q, SgemmArgs& g) {
   g.M = q.M; g.N = q.N; g.K = q.K; g.act = q.act; g.accumulate = q.accumulate;
   g.rowsum = q.rowsum; g.pre_out = q.pre_out; g.resid = q.resid;
   g.cdrop = make_drop(&q.c_drop); g.a_aux = q.a_aux; g.a_act = q.a_act; g.adrop = make_drop(&q.a_drop);
-  // the fused masks are element dropout only (DropPath is a row factor: mt_droppath_rows_f32)
-  if (g.cdrop.path_p > 0.f || g.adrop.path_p > 0.f) return MT_ERR_UNSUPPORTED;
-  if (!(g.cdrop.p > 0.f)) g.cdrop.rng = nullptr;
-  if (!(g.adrop.p > 0.f)) g.adrop.rng = nullptr;
+  g.resid_scale = q.resid_scale != 0.f ? q.resid_scale : 1.f;
+  g.a_ld = q.a_ld;
+  // DropPath of a_drop needs the row length of the dense tensor behind A; of c_drop a dense one-batch C (row m = its row)
+  if (g.adrop.rng && g.adrop.path_p > 0.f && q.a_ld < 1) return MT_ERR_BAD_ARG;
+  if (g.cdrop.rng && g.cdrop.path_p > 0.f && q.batch != 1) return MT_ERR_UNSUPPORTED;
+  if (!(g.cdrop.p > 0.f || g.cdrop.path_p > 0.f)) g.cdrop.rng = nullptr;
+  if (!(g.adrop.p > 0.f || g.adrop.path_p > 0.f)) g.adrop.rng = nullptr;
   // 16-byte loads along k need k-contiguous, 16-byte aligned rows (of the auxiliary operand too)
   g.ak = q.as1 == 1 && (q.as0 % 4) == 0 && (q.a_bs % 4) == 0 && ((uintptr_t)q.A & 15) == 0 && ((uintptr_t)q.a_aux & 15) == 0;
   g.bk = q.bs1 == 1 && (q.bs0 % 4) == 0 && (q.b_bs % 4) == 0 && ((uintptr_t)q.B & 15) == 0;

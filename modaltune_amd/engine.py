@@ -937,23 +937,16 @@ class Engine:
                               dw=g[ap + "norm_kq.weight"], db=g[ap + "norm_kq.bias"])
         tape.record(bwd_core)
         o = tape.linear(out, P(ap + "multihead_attn.out_proj.weight"), P(ap + "multihead_attn.out_proj.bias"))
-        attn_out = tape.linear(o, P(ap + "output_proj.weight"), P(ap + "output_proj.bias"), resid=c)   # tgt + output_proj(.)
-        c1 = tape.add(c, attn_out)                      # query + (tgt + output_proj(.)) (AM:231,324)
+        # c1 = query + (tgt + output_proj(.)) with tgt == query (AM:231,324): 2 c + output_proj(.) on the product's epilogue
+        c1 = tape.linear(o, P(ap + "output_proj.weight"), P(ap + "output_proj.bias"), resid=c, resid_scale=2.0)
         fp = pref + "ffn."
         tn = tape.layernorm(c1, P(fp + "norm.weight"), P(fp + "norm.bias"))
-        f = tape.linear(tape.linear(tn, P(fp + "linear1.weight"), P(fp + "linear1.bias"), act=ops.ACT_RELU),
-                        P(fp + "linear2.weight"), P(fp + "linear2.bias"))
-        # query + drop_path(ffn(query)) (AM:319,327): one Bernoulli per task pass
+        f1 = tape.linear(tn, P(fp + "linear1.weight"), P(fp + "linear1.bias"), act=ops.ACT_RELU)
+        # query + drop_path(ffn(query)) (AM:319,327; one Bernoulli per task pass): DropPath and the add ride on linear2's epilogue,
+        # the backward regenerates the factor as the dX / dW products load dy
         self._ext_calls = getattr(self, "_ext_calls", 0) + 1
         d_path = self._drop(0, 0.0, 200 + self._ext_calls, float(cfg.drop_path_rate), T)
-        if d_path is not None:
-            ops.droppath_rows(f.data, B * T, D, d_path)          # in place (linear backward does not read its own output)
-
-            def bwd_path():
-                if f.grad is not None:
-                    ops.droppath_rows(f.grad, B * T, D, d_path)
-            tape.record(bwd_path)
-        return tape.add(c1, f)
+        return tape.linear(f1, P(fp + "linear2.weight"), P(fp + "linear2.bias"), drop=d_path, resid=c1)
 
     # ------------------------------------------------------------------ fusion head (LVA:309-347)
     def _head(self, c: Var, hout: torch.Tensor) -> Var:

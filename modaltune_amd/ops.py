@@ -106,7 +106,7 @@ def colsum(A, out, M, N, *, lda=None, amap=None):
 
 def sgemm_problem(A, a_str, B, b_str, Cm, c_str, M, N, K, *, bias=None, bias_on_m=False, act=ACT_NONE, accumulate=False,
                   batch=1, a_bs=0, b_bs=0, c_bs=0, rowsum=None, pre_out=None, resid=None, c_drop=None, a_aux=None,
-                  a_act=ACT_NONE, a_drop=None) -> MtSgemm:
+                  a_act=ACT_NONE, a_drop=None, resid_scale=1.0, a_ld=0) -> MtSgemm:
     """One product of an mt_sgemm_multi launch (include/modaltune_hip.h: MtSgemm).  The tensors must outlive the launch."""
     q = MtSgemm()
     q.A, q.as0, q.as1, q.a_bs = _p(A), a_str[0], a_str[1], a_bs
@@ -120,6 +120,7 @@ def sgemm_problem(A, a_str, B, b_str, Cm, c_str, M, N, K, *, bias=None, bias_on_
     q.a_aux, q.a_act = _p(a_aux), a_act
     if a_drop is not None:
         q.a_drop = a_drop
+    q.resid_scale, q.a_ld = float(resid_scale), int(a_ld)
     return q
 
 
@@ -485,14 +486,20 @@ def check_finite(g, n, found_inf):
 # TIMER maps "<op>[shape]" -> list of (start_event, end_event); None = disabled (zero overhead path).
 # ------------------------------------------------------------------------------------------------
 TIMER = None
+RECORD = None          # bench.py: list that receives (fn, args, kwargs) of every token-side launch of a step (replayed in isolation as a graph)
+RECORD_KEEP = []       # tensors the recorded launches point to (Tape.new appends while RECORD is set)
 
 
 def _timed(name_fn):
     def deco(fn):
         def wrapper(*a, **k):
-            if TIMER is None:
+            if TIMER is None and RECORD is None:
                 return fn(*a, **k)
             key = name_fn(*a, **k)
+            if RECORD is not None and key == "token_side":
+                RECORD.append((fn, a, k))
+            if TIMER is None:
+                return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*a, **k)
@@ -525,6 +532,22 @@ colsum = _timed(lambda *a, **k: "colsum")(colsum)
 _DETAIL = bool(os.environ.get("MT_TIMER_DETAIL"))
 sgemm_multi = _timed(lambda problems: ("sgemm[" + "+".join(f"{q.M}x{q.N}x{q.K}b{q.batch}" for q in problems) + "]" if _DETAIL else "token_side"))(sgemm_multi)
 adamw_step = _timed(lambda *a, **k: "adamw")(adamw_step)
+# the rest of the token side (T <= ~200 rows: adds, copies, DropPath rows, T x T attention, pathway networks, loss head) -- until round 5
+# these launches were outside the table (it listed 184 of the ~220 token-side launches of a step)
+_small = lambda n: "token_side" if n <= (1 << 20) else "elementwise"
+axpy = _timed(lambda a, b, alpha, y, n=None: _small(n if n is not None else b.numel()))(axpy)
+axpy_bcast = _timed(lambda a, b, alpha, y, period, n=None: _small(n if n is not None else a.numel()))(axpy_bcast)
+copy_rows = _timed(lambda src, dst, M, D, **k: "token_side" if M <= 1024 else "copy_rows")(copy_rows)
+droppath_rows = _timed(lambda x, M, D, drop: "token_side" if M <= 1024 else "droppath_rows")(droppath_rows)
+dropout_f32 = _timed(lambda x, y, M, D, drop, **k: "token_side" if M <= 1024 else "dropout_f32")(dropout_f32)
+token_mha_fwd = _timed(lambda *a, **k: "token_side")(token_mha_fwd)
+token_mha_bwd = _timed(lambda *a, **k: "token_side")(token_mha_bwd)
+act_fwd = _timed(lambda x, y, act, n=None: _small(n if n is not None else x.numel()))(act_fwd)
+act_bwd = _timed(lambda x, dy, dx, act, n=None: _small(n if n is not None else x.numel()))(act_bwd)
+gene_snn_fwd = _timed(lambda *a, **k: "token_side")(gene_snn_fwd)
+gene_snn_bwd = _timed(lambda *a, **k: "token_side")(gene_snn_bwd)
+l2norm_row = _timed(lambda *a, **k: "token_side")(l2norm_row)
+distill_loss = _timed(lambda *a, **k: "token_side")(distill_loss)
 
 
 def timer_summary(timer):

@@ -132,22 +132,35 @@ class Tape:
         self.back.clear()
 
     def new(self, *shape) -> torch.Tensor:
-        return torch.empty(*shape, device=self.device, dtype=torch.float32)
+        t = torch.empty(*shape, device=self.device, dtype=torch.float32)
+        if ops.RECORD is not None:      # (bench.py replays the recorded token-side launches later: their buffers must stay)
+            ops.RECORD_KEEP.append(t)
+        return t
 
     # ------------------------------------------------------------------ ops
-    def _take_residual_grad(self, resid: Optional[Var], y: Var):
-        """d resid += dy of y = resid + f(.): dy is dead after the closure that calls this, so the first contribution
-        simply becomes resid's gradient (the launches that read dy are already queued ahead of any later writer)."""
-        if resid is not None and resid.needs_grad:
+    def _take_residual_grad(self, resid: Optional[Var], y: Var, scale: float = 1.0):
+        """d resid += scale * dy of y = scale * resid + f(.): dy is dead after the closure that calls this, so with scale 1 the
+        first contribution simply becomes resid's gradient (the launches that read dy are already queued ahead of any later
+        writer); any other scale costs one launch either way."""
+        if resid is None or not resid.needs_grad:
+            return
+        if scale == 1.0:
             resid.acc(y.grad)
+        elif resid.grad is None:
+            resid.grad = self.new(*y.grad.shape)
+            ops.axpy(y.grad, y.grad, scale - 1.0, resid.grad)
+        else:
+            ops.axpy(resid.grad, y.grad, scale, resid.grad)
 
-    def linear(self, x: Var, W: Param, b: Optional[Param], act: int = ops.ACT_NONE, drop=None, resid: Optional[Var] = None) -> Var:
-        """y = [resid +] Dropout(act(x @ W^T + b)) over the last dim: nn.Linear with the activation, the nn.Dropout that
-        follows it and the residual add on the GEMM's epilogue (one launch); the backward applies the mask and act' to dy
-        as the dX and dW products load it, and both products share a launch (mt_sgemm_multi)."""
-        return self.linear_group([(x, W, b)], act=act, drop=drop, resid=resid)[0]
+    def linear(self, x: Var, W: Param, b: Optional[Param], act: int = ops.ACT_NONE, drop=None, resid: Optional[Var] = None,
+               resid_scale: float = 1.0) -> Var:
+        """y = [resid_scale * resid +] Dropout(act(x @ W^T + b)) over the last dim: nn.Linear with the activation, the nn.Dropout
+        (and / or the DropPath of the branch: `drop` may carry path_p) that follows it and the residual add on the GEMM's epilogue
+        (one launch); the backward applies the mask and act' to dy as the dX and dW products load it, and both products share a
+        launch (mt_sgemm_multi)."""
+        return self.linear_group([(x, W, b)], act=act, drop=drop, resid=resid, resid_scale=resid_scale)[0]
 
-    def linear_group(self, items, act: int = ops.ACT_NONE, drop=None, resid: Optional[Var] = None) -> List[Var]:
+    def linear_group(self, items, act: int = ops.ACT_NONE, drop=None, resid: Optional[Var] = None, resid_scale: float = 1.0) -> List[Var]:
         """Independent nn.Linear modules [(x, W, b), ...] (sibling projections: q | k | v of one normed input) whose forward
         products share launches; each keeps its own backward closure."""
         probs, outs = [], []
@@ -156,20 +169,21 @@ class Tape:
             y = Var(self.new(*x.data.shape[:-1], N))
             pre = self.new(*y.data.shape) if act != ops.ACT_NONE else None
             probs.append(ops.sgemm_problem(x.data, (K, 1), W.data, (K, 1), y.data, (N, 1), R, N, K, bias=None if b is None else b.data,
-                                           act=act, pre_out=pre, c_drop=drop, resid=None if resid is None else resid.data))
-            self.record(self._linear_bwd(x, W, b, y, pre, act, drop, resid))
+                                           act=act, pre_out=pre, c_drop=drop, resid=None if resid is None else resid.data,
+                                           resid_scale=resid_scale))
+            self.record(self._linear_bwd(x, W, b, y, pre, act, drop, resid, resid_scale))
             outs.append(y)
         ops.sgemm_multi(probs)
         return outs
 
-    def _linear_bwd(self, x: Var, W: Param, b: Optional[Param], y: Var, pre, act: int, drop, resid: Optional[Var]):
+    def _linear_bwd(self, x: Var, W: Param, b: Optional[Param], y: Var, pre, act: int, drop, resid: Optional[Var], resid_scale: float = 1.0):
         K, N, R = x.cols, W.data.shape[0], x.rows
 
         def bwd():
             if y.grad is None:
                 return
             dy = y.grad
-            fuse = dict(a_aux=pre, a_act=act, a_drop=drop)       # dpre = mask(dy) * act'(pre), formed at the operand load
+            fuse = dict(a_aux=pre, a_act=act, a_drop=drop, a_ld=N)       # dpre = mask(dy) * act'(pre), formed at the operand load
             probs = []
             if x.needs_grad:   # dx += dpre @ W
                 probs.append(ops.sgemm_problem(dy, (N, 1), W.data, (1, K), x.g(), (K, 1), R, K, N, accumulate=True, **fuse))
@@ -182,7 +196,7 @@ class Tape:
                 probs.append(ops.sgemm_problem(dy, (1, N), self._ones, (0, 1), b.grad, (1, 1), N, 1, R, accumulate=True, **fuse))
             if probs:
                 ops.sgemm_multi(probs)
-            self._take_residual_grad(resid, y)
+            self._take_residual_grad(resid, y, resid_scale)
         return bwd
 
     def dropout(self, x: Var, spec) -> Var:

@@ -19,6 +19,15 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
 
 
+# Gradient tolerances: 1 % on every norm, except the gene-encoder tensors whose gradients are sums over the gene tokens that cancel
+# almost completely (norm ~1e-4 of the largest): the forward's fp16 operand rounding ALONE -- exact gradients of the network
+# evaluated at fp16-rounded activations, no HIP kernel involved -- moves exactly these by 0.8-2.6 % in the fp64 oracle
+# (tests/test_grad_rounding_cpu.py), and the HIP gradients lie 4 x closer to that emulation than to the fp64 golden
+# (test_gradient_exceptions_follow_the_forward_fp16_rounding below).
+GRAD_TOL_NAMED = {"gene_encoder.mlp_mixer.0.0.fn.0.bias": 2.5e-2, "gene_encoder.mlp_mixer.1.0.fn.0.bias": 2.5e-2,
+                  "gene_encoder.mlp_mixer.2.0.fn.0.bias": 2.5e-2, "gene_encoder.pathway_compression.weight": 3.5e-2}
+
+
 def _build(path):
     from modaltune_amd.engine import Engine
     from modaltune_amd.trainer import TrainStep
@@ -75,8 +84,7 @@ def test_train_step_matches_reference_golden(golden_dir, name):
     # fixtures, with two exceptions inside the gene encoder).  The exceptions do NOT come from the fp16 gradient stream: their
     # error is the same to three digits at loss scales 2^10 ... 2^24 -- it is the forward's fp16 operand rounding (activations
     # off by ~3e-4, as under the reference's own autocast) seen through gradient sums that cancel almost completely.
-    loose = {"gene_encoder.mlp_mixer.2.0.fn.0.bias": 2.5e-2,
-             "gene_encoder.mlp_mixer.1.0.fn.0.bias": 2.5e-2}      # (same family: 1.7 % in the global-pool fixture, a norm of 1.1e-4)
+    loose = GRAD_TOL_NAMED
     bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > loose.get(n, 1e-2) * r + 1e-6 * ref.max()]
     assert not bad, bad[:10]
     for k in g.files:
@@ -118,8 +126,13 @@ def test_gradient_exceptions_follow_the_forward_fp16_rounding(golden_dir):
     rows.sort(key=lambda r: -r[1])
     for r in rows[:8]:
         print("%-58s hip-exact %.3e  hip-emulated %.3e  emulated-exact %.3e" % r)
-    worst = {r[0]: r for r in rows[:3]}
-    assert any(k.startswith("gene_encoder.") for k in worst)
+    # every tensor whose HIP gradient is more than 0.5 % (relative L2) off the fp64 golden is a gene-encoder tensor, and its HIP
+    # gradient agrees with the fp16-operand emulation at least twice as well as with the golden: the deviation IS the forward rounding
+    off = [r for r in rows if r[1] > 8e-3]
+    assert off and all(r[0] in GRAD_TOL_NAMED for r in off), off[:5]
+    assert all(r[2] < 0.5 * r[1] for r in off), off[:5]
+    gene = [r for r in rows if r[0].startswith("gene_encoder.") and r[1] > 4e-3]
+    assert gene and all(r[2] < 0.6 * r[1] for r in gene), gene[:8]
 
 
 @pytest.mark.parametrize("L", [1, 2, 7, 63, 129])
@@ -162,7 +175,7 @@ def test_tiny_bags_against_the_oracle(L):
         o, rn = float(grads[n].double().norm()), float(r.norm())
         # (L = 1: softmax over a single patch is exactly 1, so the extractor's query-side gradients are exactly zero in
         # fp64 and rounding noise, ~1e-5 of the largest gradient, here: hence the absolute term)
-        if abs(o - rn) > 2e-2 * rn + 1e-4 * ref_max:
+        if abs(o - rn) > GRAD_TOL_NAMED.get(n, 1e-2) * rn + 1e-4 * ref_max:
             bad.append((n, o, rn))
     assert not bad, (ref_max, bad[:10])
 
@@ -230,7 +243,7 @@ def test_nn_module_dropin_api_matches_reference_golden(golden_dir):
     params = dict(model.named_parameters())
     ours = np.array([float(params[n].grad.double().norm()) for n in names])
     ref = g["f64_grad_norms"]
-    bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > 2e-2 * r + 1e-6 * ref.max()]
+    bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > GRAD_TOL_NAMED.get(n, 1e-2) * r + 1e-6 * ref.max()]
     assert not bad, bad[:10]
     # a torch optimiser over model.parameters() works on the flat-buffer views, and the next forward sees the update
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
