@@ -8,6 +8,7 @@ The probes themselves (sklearn LogisticRegression / lifelines Cox, TM:329-458) a
 """
 from __future__ import annotations
 
+from collections import OrderedDict
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -29,55 +30,97 @@ def multitask_forward(model, task_ids: Optional[Sequence[int]] = None, num_tasks
 
 
 class EmbeddingExtractor:
-    """Forward-only pass over slides with static buffers + hipGraph replay per bag geometry."""
+    """Forward-only pass over slides with static buffers + hipGraph replay per bag geometry: an LRU of captured geometries, a
+    geometry is captured once it has come back `capture_after` times (real data has a new bag length almost every slide: those run
+    the eager schedule).  TITAN configuration: the gridding and its one host read-back (the token count) run eagerly into static
+    buffers, the capture starts at the token gather and is keyed on (patches, TOKENS) -- as TrainStep.step_graphed does."""
 
-    def __init__(self, engine: Engine, task_ids: Sequence[int] = (0, 1, 2), graphed: bool = True):
+    def __init__(self, engine: Engine, task_ids: Sequence[int] = (0, 1, 2), graphed: bool = True, graph_cache_size: int = 8,
+                 capture_after: int = 1):
         self.engine, self.dev, self.graphed = engine, engine.device, graphed
         nt = max(1, engine.cfg.multi_task)
         self.onehots = torch.eye(nt, dtype=F32, device=self.dev)[list(task_ids)].contiguous()
-        self._key = None
+        self.graph_cache_size, self.capture_after = int(graph_cache_size), int(capture_after)
+        self._cache: "OrderedDict[tuple, dict]" = OrderedDict()
+        self._visits: Dict[tuple, int] = {}
+        self._static_key = None
+        self._pool = None
+        self.graph_replays = 0
         self.patch_size_lv0 = 1024          # TITAN configuration only (titan_adapter.py:335)
+
+    @property
+    def _graph(self):
+        """The most recently used captured graph (None while nothing is captured)."""
+        live = [e["graph"] for e in self._cache.values() if e.get("graph") is not None]
+        return live[-1] if live else None
 
     @torch.no_grad()
     def __call__(self, x, coords, genes: Sequence[torch.Tensor], clinical=None) -> torch.Tensor:
         """Logits (= the slide embeddings the probes consume) [len(task_ids), output_dim], on the device (a fresh
         tensor per call: replays write a static buffer that is copied out)."""
         eng = self.engine
+        titan = hasattr(eng, "forward_slide")
         if not eng._caches_ready:
             eng._build_caches()
         x = x.reshape(-1, x.shape[-1])
         L, B = x.shape[0], self.onehots.shape[0]
         if isinstance(genes, dict):
             genes = [genes[k] for k in sorted(genes.keys())]
-        if hasattr(eng, "forward_slide"):      # TITAN configuration: the token count is known only after the gridding -> eager
-            return eng.forward_slide(x, coords, list(genes), self.onehots, patch_size_lv0=self.patch_size_lv0, need_grad=False,
-                                     clinical=clinical)
-        if not self.graphed:
+        replayable = self.graphed and (not titan or (getattr(eng, "native", False) and getattr(eng.backbone, "embed_w", None) is not None))
+        if not replayable:      # (TITAN on the module's own torch blocks: nothing to capture)
+            if titan:
+                return eng.forward_slide(x, coords, list(genes), self.onehots, patch_size_lv0=self.patch_size_lv0, need_grad=False,
+                                         clinical=clinical)
             return eng.forward(x, coords, list(genes), self.onehots, need_grad=False, clinical=clinical)
         gflat = genes.reshape(-1) if torch.is_tensor(genes) else torch.cat([g.reshape(-1) for g in genes])
-        eng.stage_inputs(x, coords, B=B)          # (may grow the workspace: bumps eng.generation)
-        # the engine's generation is part of the key: a workspace that grew under another user of the engine (the trainer
-        # shares the B = 3 storage), rebuilt weight caches (load_state_dict) or a stochastic toggle retire the capture
-        key = (L, int(gflat.numel()), eng.generation)
-        if key != self._key:
-            self._key, self._graph, self._warm = key, None, 0
-            self._sgenes = torch.empty(int(gflat.numel()), dtype=F32, device=self.dev)     # one flat static buffer
+        if titan:
+            Lv = eng.stage_slide(x, coords, self.patch_size_lv0)      # eager gridding + the one read-back -> token count
+            eng._workspace(B, Lv)                                     # (may grow the workspace: bumps eng.generation)
+        else:
+            Lv = L
+            eng.stage_inputs(x, coords, B=B)                          # (may grow the workspace: bumps eng.generation)
+        skey = int(gflat.numel())
+        if self._static_key != skey:
+            self._static_key = skey
+            self._sgenes = torch.empty(skey, dtype=F32, device=self.dev)     # one flat static buffer
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
-        self._sgenes.copy_(gflat)
+            self._cache.clear()
+        self._sgenes.copy_(gflat, non_blocking=True)
         if self._sclin is not None:
-            self._sclin.copy_(clinical.reshape(1, -1))
-        run = lambda: eng.forward(None, None, self._sgenes, self.onehots, need_grad=False, staged=True, geometry=(B, L),
-                                  clinical=self._sclin)
-        if self._graph is None and self._warm < 1:
-            self._warm += 1
-            return run()
-        if self._graph is None:
+            self._sclin.copy_(clinical.reshape(1, -1), non_blocking=True)
+        # the engine's generation is part of the key: a workspace that grew under another user of the engine (the trainer
+        # shares the B = 3 storage), rebuilt weight caches (load_state_dict) or a stochastic toggle retire the captures
+        key = (L, Lv, eng.generation)
+        for k in [k for k in self._cache if k[2] != eng.generation]:
+            del self._cache[k]
+        if titan:
+            run = lambda: eng.forward_slide(None, None, self._sgenes, self.onehots, patch_size_lv0=self.patch_size_lv0, need_grad=False,
+                                            clinical=self._sclin, staged=True)
+        else:
+            run = lambda: eng.forward(None, None, self._sgenes, self.onehots, need_grad=False, staged=True, geometry=(B, L),
+                                      clinical=self._sclin)
+        ent = self._cache.get(key)
+        if ent is None:
+            seen = self._visits.get(key, 0)
+            if seen < self.capture_after:
+                if len(self._visits) > 4096:
+                    self._visits.clear()
+                self._visits[key] = seen + 1
+                return run()
             torch.cuda.synchronize()
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                self._out = run()
-        self._graph.replay()
-        return self._out.clone()
+            if self._pool is None or not self._cache:
+                self._pool = torch.cuda.graph_pool_handle()           # one pool for all captures (they never run concurrently)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+                out = run()
+            ent = self._cache[key] = {"graph": g, "out": out}
+            while len(self._cache) > max(1, self.graph_cache_size):
+                self._cache.popitem(last=False)
+        else:
+            self._cache.move_to_end(key)
+        ent["graph"].replay()
+        self.graph_replays += 1
+        return ent["out"].clone()
 
 
 def get_features(extractor: EmbeddingExtractor, slides: Iterable[Dict]) -> Tuple[np.ndarray, List]:

@@ -103,6 +103,12 @@ def test_titan_gridding_and_ragged_bags(golden_dir, impl):
         xs, cs = torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda()
         gl = [torch.from_numpy(a).cuda() for a in inp["genes"]]
         emb = ext(xs, cs, gl)
+        if impl == "native":      # a geometry that comes back is captured per (patches, tokens) and replayed (gridding + read-back stay eager)
+            again = [ext(xs, cs, gl) for _ in range(3)]
+            assert ext.graph_replays >= 2 and all(float((a - emb).abs().max()) < 1e-5 * float(emb.abs().max()) for a in again)
+            other = synth.synth_inputs_titan(211, sizes, seed + 5, grid=24)
+            eo = ext(torch.from_numpy(other["x"]).cuda(), torch.from_numpy(other["coords"]).cuda(), [torch.from_numpy(a).cuda() for a in other["genes"]])
+            assert torch.isfinite(eo).all() and float((ext(xs, cs, gl) - emb).abs().max()) < 1e-5 * float(emb.abs().max())
         model.speculate = False
         one = torch.cat([model(x=xs, coords=cs, genes=gl, task_token=torch.eye(3)[t].cuda()) for t in (0, 1, 2)], dim=0)
         model.speculate = True
