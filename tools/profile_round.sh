@@ -17,7 +17,9 @@ python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd > $out/pmc_attn_bwd.txt
 python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd/f > $out/pmc_hbm_f.txt; python tools/pmc_summary.py gpurun_out/pmc_${tag}_bwd/w > $out/pmc_hbm_w.txt
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 # the reference trainer's own loop on the drop-in nn.Module (3 model calls, torch loss / GradScaler / AdamW)
-python bench.py --api module > $out/bench_module.json 2>/dev/null
+python bench.py --api module --optim fused > $out/bench_module.json 2>/dev/null
+python bench.py --api module --optim torch > $out/bench_module_torch_adamw.json 2>/dev/null
+python tools/diag/module_phases.py 10000 fused host > $out/module_phases_host.txt 2>/dev/null
 python tools/diag/module_phases.py > $out/module_phases.txt 2>/dev/null
 # BASELINE config 4 (TITAN configuration, mixed bag lengths): bench line + rocprofv3 kernel-trace stats of the same command
 python bench.py --config titan --patches 4096 --ragged --steps 16 --warmup 8 > $out/titan_bench.json 2> $out/titan_bench.err
