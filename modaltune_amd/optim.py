@@ -10,9 +10,10 @@ same layout, so the whole update is one `mt_adamw_step` launch (csrc/optim.hip) 
     opt = AdamW(params, lr=..., weight_decay=..., betas=...)
     scaler.step(opt)                                # GradScaler hands over `grad_scale` / `found_inf` (no unscale pass, no read-back)
 
-It IS a `torch.optim.AdamW` (schedulers, `state_dict()`, `zero_grad()`, param groups behave as before); whenever the fused
-precondition does not hold -- parameters of some other module, gradients that are not views of one flat buffer (e.g. a DDP reducer
-that owns them), amsgrad / maximize / per-group hyper-parameters that differ -- the step is torch's own, on the same state.
+It IS a `torch.optim.AdamW` (schedulers, `state_dict()`, `zero_grad()`, param groups behave as before).  Gradients that are not
+views of one flat buffer (autograd cloned them, a DDP reducer owns them) are gathered by one multi-tensor copy first; whenever the
+fused precondition does not hold at all -- parameters of some other module, a parameter without a gradient, amsgrad / maximize /
+per-group hyper-parameters that differ -- the step is torch's own, on the same state.
 """
 from __future__ import annotations
 
@@ -82,7 +83,22 @@ class AdamW(torch.optim.AdamW):
             s.setdefault("step", torch.tensor(0.0, dtype=torch.float32))
         flat_p = torch.empty(0, dtype=torch.float32, device=dev).set_(st, (lo - base) // 4, (n,), (1,))
         step_dev = torch.full((1,), self._host_steps, dtype=torch.int32, device=dev)
-        return {"lo": lo, "n": n, "p": flat_p, "m": m, "v": v, "step_dev": step_dev}
+        return {"lo": lo, "n": n, "p": flat_p, "m": m, "v": v, "step_dev": step_dev, "gbuf": None, "gviews": None}
+
+    def _gathered_grad(self, fl) -> Optional[torch.Tensor]:
+        """Gradients that exist for every parameter but live in their own allocations (autograd clones them when several nodes feed
+        one parameter -- the per-task calls of a slide run one by one --, a DDP reducer owns them, ...): ONE multi-tensor copy into a
+        flat buffer laid out like the parameters, then the fused step as usual.  None when some parameter has no gradient (torch's
+        AdamW leaves such a parameter alone; the flat kernel would still decay it)."""
+        ps = self._all_params()
+        grads = [p.grad for p in ps]
+        if any(g is None or g.dtype != torch.float32 or not g.is_cuda or g.shape != p.shape for g, p in zip(grads, ps)):
+            return None
+        if fl["gbuf"] is None:
+            fl["gbuf"] = torch.zeros(fl["n"], dtype=torch.float32, device=ps[0].device)      # (the padding between slots stays zero)
+            fl["gviews"] = [fl["gbuf"][(p.data_ptr() - fl["lo"]) // 4:(p.data_ptr() - fl["lo"]) // 4 + p.numel()].view(p.shape) for p in ps]
+        torch._foreach_copy_(fl["gviews"], grads)
+        return fl["gbuf"]
 
     def _flat_grad(self, fl) -> Optional[torch.Tensor]:
         """The gradients as ONE flat tensor laid out like the parameters (what the module bridge hands autograd), else None."""
@@ -136,6 +152,8 @@ class AdamW(torch.optim.AdamW):
                 self._flat_failed = self._flat is None
             fl = self._flat
         g = self._flat_grad(fl) if fl is not None else None
+        if g is None and fl is not None:
+            g = self._gathered_grad(fl)
         if g is not None:
             grp = self.param_groups[0]
             b1, b2 = grp["betas"]

@@ -833,8 +833,21 @@ def test_fused_adamw_is_torch_adamw_on_the_models_flat_buffers():
         opt.zero_grad(); ref.zero_grad()
     for (k, _), p, q in zip(((k, p) for k, p in model.named_parameters() if p.requires_grad), train, twins):
         assert float((p.detach() - q.detach()).abs().max()) <= 1e-6, k
+    # the per-task calls run one by one (no batched pass): autograd hands every parameter its own gradient tensor -- gathered by one
+    # multi-tensor copy, still ONE fused launch
+    model.speculate = False
+    logits = torch.cat([model(x=x, coords=c, genes=genes, task_token=eye[t]) for t in range(3)])
+    logits.square().sum().backward()
+    for p, q in zip(train, twins):
+        q.grad = p.grad.detach().clone()
+    opt.step(); ref.step()
+    assert opt.last_step_fused is True
+    opt.zero_grad(); ref.zero_grad()
+    model.speculate = True
+    for (k, _), p, q in zip(((k, p) for k, p in model.named_parameters() if p.requires_grad), train, twins):
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-6, k
     sd = opt.state_dict()
-    assert {float(s["step"]) for s in sd["state"].values()} == {3.0}           # the skipped step does not count
+    assert {float(s["step"]) for s in sd["state"].values()} == {4.0}           # the skipped step does not count
     ref_sd = ref.state_dict()
     for i in sd["state"]:
         for nm in ("exp_avg", "exp_avg_sq"):      # (torch forms them by lerp_ / addcmul_: other fp32 roundings of the same sums)

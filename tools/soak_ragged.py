@@ -45,14 +45,17 @@ else:
     model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3, **GIGAPATH_JSON).to(dev)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, sizes, seed=0).items()}, strict=True)
     model.train()
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
-    scaler = torch.cuda.amp.GradScaler()
+    from modaltune_amd.optim import AdamW          # (round 5: the fused drop-in; `torch` as a third argument keeps torch.optim.AdamW)
+    Opt = torch.optim.AdamW if (len(sys.argv) > 3 and sys.argv[3] == "torch") else AdamW
+    opt = Opt([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    scaler = torch.amp.GradScaler("cuda")
     eye = torch.eye(3, device=dev)
     tgt = torch.softmax(torch.randn(3, 256, device=dev), dim=1)
     last = [0.0]
     def one(L):
         gd = {i: g for i, g in enumerate(genes)}
-        logits = torch.cat([model(x=X[:L].float().unsqueeze(0), coords=C[:L].unsqueeze(0), genes=gd, task_token=eye[t]) for t in range(3)])
+        xs, cs = X[:L].float().unsqueeze(0), C[:L].unsqueeze(0)          # ONE tensor for the three calls, as the reference passes `images`
+        logits = torch.cat([model(x=xs, coords=cs, genes=gd, task_token=eye[t]) for t in range(3)])
         logits = logits / logits.norm(dim=-1, keepdim=True)
         loss = torch.nn.functional.kl_div(torch.log_softmax(logits, dim=1), tgt, reduction="batchmean")
         scaler.scale(loss).backward(); scaler.step(opt); scaler.update(); opt.zero_grad()
@@ -73,4 +76,7 @@ for i in range(steps):
         print(f"step {i + 1}: loss {v:.5f} alloc {torch.cuda.memory_allocated() / 2**30:.2f} GiB reserved {marks[-1][0]:.2f} GiB host RSS {marks[-1][1]:.2f} GiB ({time.time() - t0:.1f} s)", flush=True)
 assert marks[-1][0] <= marks[len(marks) // 2][0] * 1.05 + 0.25, "device memory keeps growing"
 assert marks[-1][1] <= marks[len(marks) // 2][1] * 1.05 + 0.25, "host memory keeps growing"
+if mode == "module":
+    model._drain_decodes(block=True)
+    print("read-back-free speculation:", model._nosync_rows, "fused optimiser steps:", getattr(opt, "last_step_fused", None))
 print("soak ok")
