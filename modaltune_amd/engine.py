@@ -80,6 +80,19 @@ class ParamStore:
     def param(self, k: str) -> Param:
         return Param(self.tensors[k], self.grads.get(k))
 
+    def new_grad_set(self):
+        """A second flat gradient buffer with its per-tensor views: (flat, views).  TrainStep's pass groups each accumulate into their
+        own (their token-side weight gradients are read-modify-write, not atomic) and the sets are summed before the optimiser."""
+        flat = torch.zeros(self.n_flat, dtype=F32, device=self.device)
+        return flat, {k: flat[o:o + n].view(shape) for k, (o, n, shape) in self.slots.items()}
+
+    def use_grad_set(self, flat, views):
+        """Point the gradient side of the store at (flat, views) -- every Param / closure created from now on binds to it -- and
+        return the previous pair (hand it back the same way)."""
+        old = (self.flat_grad, self.grads)
+        self.flat_grad, self.grads = flat, views
+        return old
+
 
 class _Lease:
     """Hands a fresh call's workspace store back to the engine's pool when the last holder (workspace dict, tape, share dict) dies."""
@@ -399,7 +412,8 @@ class Engine:
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, coords, genes: Sequence[torch.Tensor], task_onehots: torch.Tensor,
                 need_grad: bool = True, fresh: bool = False, staged: bool = False, geometry=None,
-                clinical: Optional[torch.Tensor] = None, share: Optional[dict] = None) -> torch.Tensor:
+                clinical: Optional[torch.Tensor] = None, share: Optional[dict] = None, tape: Optional[Tape] = None,
+                site_group: int = 0) -> torch.Tensor:
         """x [L, in_chans] (or [1,L,in]); coords [L,2] (host or device); genes: list of [1, n_i]; task_onehots [B, num_tasks].
         Returns logits [B, output_dim] (fp32, device).  fresh=True gives this call its own tape and workspace so that
         several forwards can precede one backward (the reference calls the model 3x before loss.backward(), TM:175-177);
@@ -424,7 +438,9 @@ class Engine:
         ws = self._workspace(B, L, fresh=fresh)
         # fresh: this call owns its tape (several forwards alive at once); the engine's long-lived tape -- whose gradient
         # arena captured graphs point into -- is put back before returning
-        self.tape = Tape(self.device, shared=self._fresh_arenas) if fresh else self._main_tape
+        # (tape=: a long-lived tape of the caller's -- TrainStep runs the task passes of a step as two concurrent groups, each with
+        # its own tape, workspace geometry (B differs) and, through site_group, its own dropout masks)
+        self.tape = tape if tape is not None else (Tape(self.device, shared=self._fresh_arenas) if fresh else self._main_tape)
         tape = self.tape
         if fresh:
             tape.lease = ws["_lease"]             # the backward closures read views of the leased store
@@ -436,7 +452,7 @@ class Engine:
         self._ext_calls = 0
         if fresh and self._drop_now:     # several forwards may precede one backward (TM:175-177): the masks of a call are
             self._fresh_calls += 1       # tied to the call, not to the device step counter alone
-        self._site_base = 4096 * (self._fresh_calls & 0xFFFFF) if fresh else 0
+        self._site_base = 4096 * (self._fresh_calls & 0xFFFFF) if fresh else 1024 * int(site_group)
         self._ctx = dict(B=B, L=L, N=N, M=M, Mp=Mp, ws=ws)
         self._ctx["plan"] = self._attention_plan(N, B)
         P = self.store.param
@@ -661,10 +677,12 @@ class Engine:
                          alpha_drop=adrop, passes=Pn)
         z0 = z          # (closures bind late: `z` is rebound by the mixer loop below)
 
+        fgrad = st.flat_grad      # (bound NOW: the store's gradient side may point elsewhere by the time the backward runs)
+
         def bwd_networks():
             if z0.grad is None:
                 return
-            ops.gene_snn_bwd(st.flat, st.flat_grad, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim,
+            ops.gene_snn_bwd(st.flat, fgrad, self._gene_offs, self._gene_sizes, self._gene_goff, gflat, G, g.latent_dim,
                              a1, a2, z0.grad, alpha_drop=adrop, passes=Pn)
         tape.record(bwd_networks)
         for k in range(g.depth):

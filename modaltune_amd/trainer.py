@@ -10,6 +10,7 @@ for just before AdamW -- the collectives of the upper blocks run under the backw
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Dict, Optional, Sequence
 
@@ -36,7 +37,7 @@ class TrainStep:
     def __init__(self, engine: Engine, lr: float = 1e-4 / 20, weight_decay: float = 0.01, betas=(0.9, 0.999),
                  eps: float = 1e-8, init_scale: float = 2.0 ** 15, growth_interval: int = 2000,
                  process_group=None, task_ids: Sequence[int] = (0, 1, 2), text_rows: Sequence[int] = (0, 1, 3),
-                 graph_cache_size: int = 8, capture_after: int = 2):
+                 graph_cache_size: int = 8, capture_after: int = 2, split_passes: bool = True):
         self.engine, self.dev = engine, engine.device
         self.wd, self.betas, self.eps = weight_decay, betas, eps
         n = engine.store.n_flat
@@ -85,6 +86,18 @@ class TrainStep:
         # compute stream -- ("grad", e0, e1): last backward kernel -> the optimiser may start (bucket all-reduces / the last bucket's
         # reduce-scatter not hidden under the backward); ("param", e0, e1): the next step's wait for the sharded parameter all-gather
         self.comm_events: Optional[list] = None
+        # The task passes of a step as TWO concurrent groups (B = 2 and B = 1 on two HIP streams) instead of one batched B = 3 pass: one
+        # group's HBM-bound kernels (LayerNorm family, branch mix, combine) run under the other's MFMA-bound ones (GEMMs, attention) and
+        # the tails of one group's launches fill with the other's workgroups -- same-box, eager: 42.0 -> 40.4-40.8 ms at L = 10 000
+        # (tools/experiments/pass_overlap.py; the same two groups one after the other on ONE stream: 45.0).  The groups share the staged
+        # input and the patch embedding (computed once before the fork), own their workspace / tape / dropout masks, and accumulate
+        # into their own flat gradient buffers (summed before the optimiser: the token-side dW products are read-modify-write).
+        # The loss is a sum over the task rows (TM:225-233), so each group runs loss + backward behind its own forward; the streams
+        # meet once, in front of the optimiser.  MT_SPLIT_PASSES=0 / split_passes=False: the batched pass.
+        B = int(self.onehots.shape[0])
+        self.split_passes = bool(split_passes) and B >= 2 and not hasattr(engine, "forward_slide") and os.environ.get("MT_SPLIT_PASSES", "1") != "0"
+        self._groups = [(0, B - B // 3 if B >= 3 else 1), (B - B // 3 if B >= 3 else 1, B)] if B >= 2 else [(0, B)]
+        self._pass_streams = self._grad_sets = self._group_tapes = self._loss_parts = None
 
     # ------------------------------------------------------------------ learning-rate schedule hook
     @property
@@ -137,8 +150,83 @@ class TrainStep:
         else:
             self.reducer.start(b)
 
+    def _split_setup(self):
+        eng = self.engine
+        self._pass_streams = [torch.cuda.Stream(device=self.dev) for _ in self._groups]
+        self._grad_sets = [(eng.store.flat_grad, eng.store.grads)] + [eng.store.new_grad_set() for _ in self._groups[1:]]
+        from .tape import Tape
+        self._group_tapes = []
+        for _ in self._groups:
+            t = Tape(self.dev)
+            t.on_realloc = eng._bump_generation          # captured graphs point into the tapes' gradient arenas
+            self._group_tapes.append(t)
+        self._loss_parts = [torch.zeros(1, dtype=F32, device=self.dev) for _ in self._groups]
+
+    def _fwd_bwd_split(self, x, coords, genes, text, clinical, staged_geometry=None):
+        """_fwd_bwd with the task passes in two concurrent groups (see __init__)."""
+        eng = self.engine
+        if self._pass_streams is None:
+            self._split_setup()
+        self._wait_params()
+        eng.grad_ready_hook = None            # (world > 1: the buckets start behind the join, optimizer_step -> start_rest)
+        if eng.stochastic:
+            ops.rng_advance(eng.rng)
+        target = self.project_text(text)
+        if eng.store.sync is not None:
+            eng.store.sync()
+        if not eng._caches_ready:
+            eng._build_caches()
+        gB = [b - a for a, b in self._groups]
+        if staged_geometry is None:
+            x = x.reshape(-1, x.shape[-1])
+            L = x.shape[0]
+            ws0 = eng._workspace(gB[0], L)
+            eng.stage_inputs(x, coords, ws0)
+        else:
+            L = staged_geometry[1]
+            ws0 = eng._workspace(gB[0], L)         # (step_graphed staged the slide into the first group's workspace)
+        for nb in gB[1:]:
+            eng._workspace(nb, L)                   # (grown before the fork: a growth bumps the generation)
+        eng._embed_patches(None, None, ws0, True, L)        # task-independent: once, in front of the fork
+        share = {"x0": ws0["x0"]}
+        R, O = target.shape
+        logits_all = torch.empty(R, O, dtype=F32, device=self.dev)
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        try:
+            for gi, (a, b) in enumerate(self._groups):
+                st = self._pass_streams[gi]
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    old = eng.store.use_grad_set(*self._grad_sets[gi])
+                    try:
+                        self._grad_sets[gi][0].zero_()
+                        logits = eng.forward(None, None, genes, self.onehots[a:b], need_grad=True, staged=True, geometry=(b - a, L),
+                                             clinical=clinical, share=share, tape=self._group_tapes[gi], site_group=gi + 1)
+                        call = eng.last_call
+                        dlogits = torch.empty_like(logits)
+                        ops.distill_loss(logits, target[a:b], self._loss_parts[gi], dlogits, b - a, O, 1.0, self.scale)
+                        eng.backward(dlogits, call=call)
+                        logits_all[a:b].copy_(logits)
+                    finally:
+                        eng.store.use_grad_set(*old)
+        finally:
+            for st in self._pass_streams:
+                main.wait_stream(st)
+        # the streams have met: one gradient buffer, one loss
+        fg = eng.store.flat_grad
+        for flat, _ in self._grad_sets[1:]:
+            ops.axpy(fg, flat, 1.0, fg)
+        ops.axpy(self._loss_parts[0], self._loss_parts[1], 1.0, self.loss)
+        for part in self._loss_parts[2:]:
+            ops.axpy(self.loss, part, 1.0, self.loss)
+        self.last_logits = logits_all
+
     def _fwd_bwd(self, x, coords, genes, text, clinical, staged_geometry=None, reduce: bool = True):
         eng = self.engine
+        if self.split_passes and not eng.collect_taps and self.onehots.shape[0] == self._groups[-1][1] and eng.cfg.is_multi:
+            return self._fwd_bwd_split(x, coords, genes, text, clinical, staged_geometry)
         self._wait_params()               # the all-gather of the last step's sharded parameter update (no-op otherwise)
         eng.grad_ready_hook = self._on_grad_ready if (reduce and self._world() > 1) else None
         if eng.stochastic:
@@ -259,7 +347,11 @@ class TrainStep:
             eng._workspace(B, Lv)                 # (may grow the workspace: bumps eng.generation)
         else:
             Lv = L
-            eng.stage_inputs(x, coords, B=B)      # (may grow the workspace: bumps eng.generation)
+            split = self.split_passes and not eng.collect_taps and eng.cfg.is_multi
+            gB = [b - a for a, b in self._groups] if split else [B]
+            for nb in gB[1:]:
+                eng._workspace(nb, L)             # (all groups' workspaces exist -- and have grown -- before anything is captured)
+            eng.stage_inputs(x, coords, B=gB[0])  # (may grow the workspace: bumps eng.generation)
         self._wait_params()                       # last step's sharded parameter all-gather ran under the staging above
         self._sgenes.copy_(gflat, non_blocking=True)
         self._stext.copy_(text, non_blocking=True)
