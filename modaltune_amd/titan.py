@@ -595,6 +595,12 @@ class NativeBackbone:
                 ops.layernorm_bwd(dcur, ws[f"pool_x{j}"], w_, ws[f"pool_st{j}"], tmp, M, D)
                 dcur = tmp
 
+    def plan_with(self, keep, N: int, B: int):
+        """A plan for another pass count on the slide's existing distance table (`keep` as returned by make_plan)."""
+        if not self.alibi or not keep:
+            return ops.make_dense_plan(N, B, self.H)
+        return ops.make_dense_plan(N, B, self.H, keep[0], self.nslope)
+
     def make_plan(self, cells: torch.Tensor, dims: torch.Tensor, N: int, B: int, err: Optional[torch.Tensor] = None):
         """Dense-attention plan of one slide: the fp16 distance table of the token cells (one per slide: every head, pass, block
         and kernel of the step reads the same one).  Returns (plan, tensors to keep alive)."""
@@ -749,21 +755,30 @@ class TitanEngine(Engine):
         return self._grid_stage.run(x, coords, patch_size_lv0, self._titan_err)      # (ONE copy: host / device, any float dtype -> the static fp32 buffer)
 
     def forward_slide(self, x, coords, genes, task_onehots, patch_size_lv0: int = 1024, need_grad: bool = True, fresh: bool = False,
-                      clinical=None, share: Optional[dict] = None, staged: bool = False) -> torch.Tensor:
+                      clinical=None, share: Optional[dict] = None, staged: bool = False, tape=None, site_group: int = 0,
+                      prologue_only: bool = False) -> Optional[torch.Tensor]:
         """x [1, L, C] tile embeddings, coords [1, L, 2] level-0 pixels (TA:329-353) -> logits [B, output_dim].
-        share: see Engine.forward -- here the whole task-independent prologue (gridding, embedding, ALiBi tables) is reused by
-        the later calls of one slide."""
+        share: see Engine.forward -- here the whole task-independent prologue (gridding, embedding, the ALiBi distance table) is
+        reused by the later calls of one slide; a call with another pass count builds its plan on the shared table.
+        prologue_only: run just that prologue into `share` (TrainStep's pass groups fork behind it); tape / site_group: Engine.forward."""
         bb = self.backbone
         if bb is None:
             raise RuntimeError("titan_gene_adapter needs the TITAN slide encoder: pass backbone=<VisionTransformer from the "
                                "MahmoodLab/TITAN snapshot> (its source is not part of ModalTune; parity unpinned)")
         B = int(task_onehots.shape[0])
         self._need = need_grad
-        if not staged:
+        if not staged and x is not None:
             x = x.to(self.device)
-        if share is not None and share.get("titan_B") == B:
-            self._tok, self._plan, self._plan_keep = share["tok"], share["plan"], share["keep"]
+        if share is not None and "tok" in share:
+            self._tok = share["tok"]
             self._bias, self._mask = share.get("bias"), share.get("mask")
+            if share.get("titan_B") == B:
+                self._plan, self._plan_keep = share["plan"], share["keep"]
+            elif self.native:
+                self._plan_keep = share["keep"]
+                self._plan = bb.plan_with(share["keep"], self._tok.shape[0], B)
+            else:
+                self._plan = self._plan_keep = None
         elif self.native:
             if bb.embed_w is not None:
                 if staged:          # stage_slide() has run the gridding: start at the token gather (capturable)
@@ -785,13 +800,16 @@ class TitanEngine(Engine):
             tok, bias, mask = bb.embed(fg, cg, bgm)
             self._tok, self._bias, self._mask = tok[0].to(F32).contiguous(), bias, mask
             self._plan = self._plan_keep = None
-        if share is not None and share.get("titan_B") != B:
+        if share is not None and "tok" not in share:
             share.update(titan_B=B, tok=self._tok, plan=self._plan, keep=self._plan_keep, bias=getattr(self, "_bias", None),
                          mask=getattr(self, "_mask", None))
         patches = self._tok[1:]
         if patches.shape[0] < 1:
             raise ValueError("slide has no foreground cell")
-        return self.forward(patches, None, genes, task_onehots, need_grad=need_grad, fresh=fresh, clinical=clinical, share=share)
+        if prologue_only:
+            return None
+        return self.forward(patches, None, genes, task_onehots, need_grad=need_grad, fresh=fresh, clinical=clinical, share=share,
+                            tape=tape, site_group=site_group)
 
     # -- image-side hooks
     def _embed_patches(self, x, coords, ws, staged, L):

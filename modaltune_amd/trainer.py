@@ -95,9 +95,12 @@ class TrainStep:
         # The loss is a sum over the task rows (TM:225-233), so each group runs loss + backward behind its own forward; the streams
         # meet once, in front of the optimiser.  MT_SPLIT_PASSES=0 / split_passes=False: the batched pass.
         B = int(self.onehots.shape[0])
-        self.split_passes = bool(split_passes) and B >= 2 and not hasattr(engine, "forward_slide") and os.environ.get("MT_SPLIT_PASSES", "1") != "0"
+        self.split_passes = bool(split_passes) and B >= 2 and os.environ.get("MT_SPLIT_PASSES", "1") not in ("0", "off")
         self._groups = [(0, B - B // 3 if B >= 3 else 1), (B - B // 3 if B >= 3 else 1, B)] if B >= 2 else [(0, B)]
         self._pass_streams = self._grad_sets = self._group_tapes = self._loss_parts = None
+        # same-box, hipGraph replay, ms per step batched -> split: L = 16 000: 69.5 -> 67.6; 12 000: 51.4 -> 50.6; 10 000: 41.8 -> 40.5;
+        # 9 000: 37.7 -> 36.5; 8 000: 33.7 -> 32.9; 6 500: 26.6 -> 27.4 (!); 4 096: 18.2 -> 18.1; 2 500: 12.1 -> 12.2; 1 024: 8.2 -> 8.1
+        self.split_min_patches = 7500
 
     # ------------------------------------------------------------------ learning-rate schedule hook
     @property
@@ -150,6 +153,20 @@ class TrainStep:
         else:
             self.reducer.start(b)
 
+    def _split_now(self, L: Optional[int] = None) -> bool:
+        eng = self.engine
+        if not (self.split_passes and eng.cfg.is_multi and not eng.collect_taps):
+            return False
+        if L is not None and L < self.split_min_patches and os.environ.get("MT_SPLIT_PASSES") != "force":
+            return False
+        if hasattr(eng, "forward_slide"):
+            # TITAN configuration: built (native backbone with its native embedding), parity-green -- and 0.2-0.3 ms SLOWER at ~4k
+            # tokens (12.88 -> 13.06-13.19 ms same-box: twice the token-side launches for half-sized big kernels): only on request
+            bb = getattr(eng, "backbone", None)
+            return bool(os.environ.get("MT_SPLIT_PASSES") == "force" and getattr(eng, "native", False) and bb is not None
+                        and getattr(bb, "embed_w", None) is not None)
+        return True
+
     def _split_setup(self):
         eng = self.engine
         self._pass_streams = [torch.cuda.Stream(device=self.dev) for _ in self._groups]
@@ -177,18 +194,29 @@ class TrainStep:
         if not eng._caches_ready:
             eng._build_caches()
         gB = [b - a for a, b in self._groups]
-        if staged_geometry is None:
-            x = x.reshape(-1, x.shape[-1])
-            L = x.shape[0]
-            ws0 = eng._workspace(gB[0], L)
-            eng.stage_inputs(x, coords, ws0)
+        titan = hasattr(eng, "forward_slide")
+        if titan:
+            # TITAN configuration: gridding, token gather, patch-embedding MLP and the ALiBi distance table once, in front of the fork
+            share = {}
+            eng.forward_slide(x, coords, genes, self.onehots[:gB[0]], patch_size_lv0=self.patch_size_lv0, need_grad=True, clinical=clinical,
+                              staged=staged_geometry is not None, share=share, prologue_only=True)
+            share["x0"] = share["tok"][1:]
+            L = int(share["tok"].shape[0]) - 1
+            for nb in gB:
+                eng._workspace(nb, L)
         else:
-            L = staged_geometry[1]
-            ws0 = eng._workspace(gB[0], L)         # (step_graphed staged the slide into the first group's workspace)
-        for nb in gB[1:]:
-            eng._workspace(nb, L)                   # (grown before the fork: a growth bumps the generation)
-        eng._embed_patches(None, None, ws0, True, L)        # task-independent: once, in front of the fork
-        share = {"x0": ws0["x0"]}
+            if staged_geometry is None:
+                x = x.reshape(-1, x.shape[-1])
+                L = x.shape[0]
+                ws0 = eng._workspace(gB[0], L)
+                eng.stage_inputs(x, coords, ws0)
+            else:
+                L = staged_geometry[1]
+                ws0 = eng._workspace(gB[0], L)         # (step_graphed staged the slide into the first group's workspace)
+            for nb in gB[1:]:
+                eng._workspace(nb, L)                   # (grown before the fork: a growth bumps the generation)
+            eng._embed_patches(None, None, ws0, True, L)        # task-independent: once, in front of the fork
+            share = {"x0": ws0["x0"]}
         R, O = target.shape
         logits_all = torch.empty(R, O, dtype=F32, device=self.dev)
         main = torch.cuda.current_stream()
@@ -202,8 +230,12 @@ class TrainStep:
                     old = eng.store.use_grad_set(*self._grad_sets[gi])
                     try:
                         self._grad_sets[gi][0].zero_()
-                        logits = eng.forward(None, None, genes, self.onehots[a:b], need_grad=True, staged=True, geometry=(b - a, L),
-                                             clinical=clinical, share=share, tape=self._group_tapes[gi], site_group=gi + 1)
+                        if titan:
+                            logits = eng.forward_slide(None, None, genes, self.onehots[a:b], patch_size_lv0=self.patch_size_lv0, need_grad=True,
+                                                       clinical=clinical, share=share, staged=True, tape=self._group_tapes[gi], site_group=gi + 1)
+                        else:
+                            logits = eng.forward(None, None, genes, self.onehots[a:b], need_grad=True, staged=True, geometry=(b - a, L),
+                                                 clinical=clinical, share=share, tape=self._group_tapes[gi], site_group=gi + 1)
                         call = eng.last_call
                         dlogits = torch.empty_like(logits)
                         ops.distill_loss(logits, target[a:b], self._loss_parts[gi], dlogits, b - a, O, 1.0, self.scale)
@@ -225,7 +257,8 @@ class TrainStep:
 
     def _fwd_bwd(self, x, coords, genes, text, clinical, staged_geometry=None, reduce: bool = True):
         eng = self.engine
-        if self.split_passes and not eng.collect_taps and self.onehots.shape[0] == self._groups[-1][1] and eng.cfg.is_multi:
+        Lnow = staged_geometry[1] if staged_geometry is not None else (x.reshape(-1, x.shape[-1]).shape[0] if torch.is_tensor(x) else None)
+        if self._split_now(Lnow):
             return self._fwd_bwd_split(x, coords, genes, text, clinical, staged_geometry)
         self._wait_params()               # the all-gather of the last step's sharded parameter update (no-op otherwise)
         eng.grad_ready_hook = self._on_grad_ready if (reduce and self._world() > 1) else None
@@ -344,11 +377,11 @@ class TrainStep:
             # TITAN configuration: the gridding kernels and the one host read-back (the token count: every shape downstream depends
             # on it) run eagerly; the captured part starts at the token gather and is keyed on (patches, TOKENS).
             Lv = eng.stage_slide(x, coords, self.patch_size_lv0)
-            eng._workspace(B, Lv)                 # (may grow the workspace: bumps eng.generation)
+            for nb in ([b - a for a, b in self._groups] if self._split_now(Lv) else [B]):
+                eng._workspace(nb, Lv)            # (may grow the workspace: bumps eng.generation)
         else:
             Lv = L
-            split = self.split_passes and not eng.collect_taps and eng.cfg.is_multi
-            gB = [b - a for a, b in self._groups] if split else [B]
+            gB = [b - a for a, b in self._groups] if self._split_now(L) else [B]
             for nb in gB[1:]:
                 eng._workspace(nb, L)             # (all groups' workspaces exist -- and have grown -- before anything is captured)
             eng.stage_inputs(x, coords, B=gB[0])  # (may grow the workspace: bumps eng.generation)

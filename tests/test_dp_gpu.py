@@ -31,10 +31,11 @@ def _free_port():
     return p
 
 
-def _run_ranks(mode, tmp_path, world=2, timeout=600, backend="gloo"):
+def _run_ranks(mode, tmp_path, world=2, timeout=600, backend="gloo", extra_env=None):
     port = str(_free_port())
     outs = [str(tmp_path / f"{mode}_{backend}_{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MT_TEST_BACKEND=backend)
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, WORKER, mode, str(r), str(world), port, outs[r]], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
@@ -60,6 +61,14 @@ def test_two_rank_trainstep_matches_gradient_averaging(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     _check_trainstep(_run_ranks("trainstep", tmp_path))
+
+
+def test_two_rank_trainstep_with_pass_groups_on_two_streams(tmp_path):
+    """The same with the task passes of every rank's step split into two concurrent groups (forced on at test size): no bucket
+    starts before the groups' streams have met (ONE captured segment), the collectives run behind the join; same result."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _check_trainstep(_run_ranks("trainstep", tmp_path, extra_env={"MT_SPLIT_PASSES": "force"}), nseg=1)
 
 
 def _check_ragged(res):
@@ -96,7 +105,7 @@ def test_two_rank_trainstep_over_rccl(tmp_path):
     _check_trainstep(_run_ranks("trainstep", tmp_path, backend="nccl"))
 
 
-def _check_trainstep(results):
+def _check_trainstep(results, nseg=4):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dp_worker as W
     from modaltune_amd import synth
@@ -104,7 +113,7 @@ def _check_trainstep(results):
     from modaltune_amd.trainer import TrainStep
     r0, r1 = results
     assert int(r0["steps"]) == W.STEPS and int(r0["replays"]) == W.STEPS - 1      # one eager visit, then capture + replays
-    assert int(r0["nseg"]) == int(r0["buckets"]) == 4                              # the backward was cut at every bucket boundary
+    assert int(r0["buckets"]) == 4 and int(r0["nseg"]) == nseg                     # (4: the backward was cut at every bucket boundary)
     assert np.array_equal(r0["flat"], r1["flat"])                                  # same reduced gradient -> same weights, bitwise
     assert not np.allclose(r0["losses"], r1["losses"])                             # (different slides)
     # single-process reference: gradients of both slides summed, AdamW with grad_mult = 1/2

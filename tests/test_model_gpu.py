@@ -95,6 +95,84 @@ def test_train_step_matches_reference_golden(golden_dir, name):
             assert err < (3.5e-2 if key == "gene_encoder.pathway_compression.weight" else 1e-2), (k, err)
 
 
+@pytest.mark.parametrize("name", ["L37_d3", "L1500_d3", "L37_d3_clin_cat"])
+def test_pass_groups_on_two_streams_match_the_batched_step(golden_dir, name):
+    """Round 5: TrainStep runs the task passes of a long bag as two concurrent groups (B = 2 and B = 1 on two HIP streams, own
+    workspaces / tapes / gradient buffers, loss + backward per group, streams meeting in front of the optimiser).  Forced on at
+    fixture size: same logits and loss as the batched B = 3 pass (the per-row arithmetic is identical), gradients equal to the
+    rounding of two accumulation orders, the reference golden's tolerances hold, and the hipGraph replay of the forked schedule
+    reproduces the eager one."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(golden_dir, f"model_{name}.npz")
+    g, cfg, eng, ts, inp = _build(path)
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"])
+    clin = torch.from_numpy(inp["clinical"]).cuda() if cfg.clinical else None
+    ts.split_min_patches = 1 << 30                    # batched
+    ts.step(x, inp["coords"], genes, text, update=False, clinical=clin)
+    torch.cuda.synchronize()
+    l0, loss0, g0 = ts.last_logits.clone(), float(ts.loss), {k: v.clone() for k, v in ts.unscaled_grads().items()}
+    ts.split_min_patches = 0                          # two groups
+    assert ts._split_now(int(g["L"]))
+    ts.step(x, inp["coords"], genes, text, update=False, clinical=clin)
+    torch.cuda.synchronize()
+    l1, loss1, g1 = ts.last_logits.clone(), float(ts.loss), ts.unscaled_grads()
+    assert ts._pass_streams is not None and torch.equal(l0, l1) and abs(loss0 - loss1) <= 1e-6 * abs(loss0)
+    for k in g0:
+        n = float(g0[k].norm())
+        assert float((g0[k] - g1[k]).norm()) <= 2e-3 * n + 1e-7 * max(float(v.norm()) for v in g0.values()), k
+    assert _rel(l1.cpu().numpy(), g["f64_logits"]) < 1e-3
+    names = [str(n) for n in g["f64_grad_names"]]
+    ours = np.array([float(g1[n].double().norm()) for n in names])
+    ref = g["f64_grad_norms"]
+    bad = [(n, o, r) for n, o, r in zip(names, ours, ref) if abs(o - r) > GRAD_TOL_NAMED.get(n, 1e-2) * r + 1e-6 * ref.max()]
+    assert not bad, bad[:5]
+    # hipGraph replay of the forked schedule (lr 0: the weights stay, every visit must reproduce the same loss)
+    ts.set_lr(0.0); ts.wd = 0.0
+    losses = []
+    for _ in range(5):
+        ts.step_graphed(x, inp["coords"], genes, text, clinical=clin)
+        torch.cuda.synchronize()
+        losses.append(float(ts.loss))
+    assert ts.graph_replays >= 2 and max(losses) - min(losses) <= 1e-6 * abs(loss0) and abs(losses[-1] - loss0) <= 1e-6 * abs(loss0)
+
+
+def test_pass_groups_draw_their_own_masks_and_stay_consistent_in_train_mode(golden_dir):
+    """With Dropout / DropPath on, each group draws its own masks (site groups) and its backward regenerates them: with the step
+    counter pinned the step repeats, and the analytic gradient predicts the loss change along itself, as for the batched pass."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(golden_dir, "model_L1500_d3.npz")
+    g, cfg, eng, ts, inp = _build(path)
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"]).cuda()
+    eng.set_stochastic(True, seed=77)
+    ts.split_min_patches = 0
+
+    def run(step_no):
+        eng.rng[2] = step_no - 1                 # TrainStep.step advances the counter first
+        return float(ts.step(x, inp["coords"], genes, text, update=False))
+    l5 = run(5)
+    grad = eng.store.flat_grad.clone() / float(ts.scale)
+    assert run(5) == l5 and ts._pass_streams is not None
+    gn = float(grad.norm())
+    base = eng.store.flat.clone()
+    eps = 2e-2 * l5 / gn
+    vals = []
+    for sgn in (+1.0, -1.0):
+        eng.store.flat.copy_(base + sgn * eps * grad / gn)
+        eng.refresh_trainable_caches()
+        vals.append(run(5))
+    eng.store.flat.copy_(base)
+    eng.refresh_trainable_caches()
+    assert abs((vals[0] - vals[1]) / (2 * eps) / gn - 1.0) < 0.05, (vals, l5, gn)
+    ts.split_min_patches = 1 << 30               # the batched pass of the same step draws other masks (site group 0)
+    assert run(5) != l5
+
+
 def test_gradient_exceptions_follow_the_forward_fp16_rounding(golden_dir):
     """the named gradient exceptions of `test_train_step_matches_reference_golden` (three gene-encoder tensors whose
     gradients are sums that cancel almost completely) are measured against the oracle run with the patch-row products rounded to
