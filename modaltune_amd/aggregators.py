@@ -12,6 +12,7 @@ The module-level forward is the compatibility path (one pass per call, any numbe
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Any, Dict, Iterator, Sequence, Tuple
 
@@ -74,6 +75,7 @@ def _bridge_backward(ctx, dlogits):
     module, eng, grp = ctx.module, ctx.module.engine, ctx.group
     store = eng.store
     nparams = len(module._slots)
+    split = getattr(ctx, "split", None)          # a batched pass that ran as two concurrent pass groups (_ModelFn.forward)
     if dlogits is not None:
         if ctx.call is None:
             raise RuntimeError("backward through a forward that ran with gradients disabled (or a second backward through the same call"
@@ -92,7 +94,23 @@ def _bridge_backward(ctx, dlogits):
         ops.axpy_dev(None, dl, grp.scale[0:1], scaled)
         hook, eng.grad_ready_hook = eng.grad_ready_hook, None      # (a TrainStep sharing the engine must not see this pass)
         try:
-            eng.backward(scaled, call=ctx.call)
+            if split is None:
+                eng.backward(scaled, call=ctx.call)
+            else:        # every group replays its tape on its own stream into its own gradient set; the sets are summed behind the join
+                main = torch.cuda.current_stream()
+                fork = torch.cuda.Event()
+                fork.record(main)
+                for (a, b), call, st, (gflat, _) in zip(split["groups"], ctx.call, split["streams"], split["sets"]):
+                    st.wait_event(fork)
+                    with torch.cuda.stream(st):
+                        if gflat is not store.flat_grad:
+                            gflat.zero_()
+                        eng.backward(scaled[a:b], call=call)
+                for st in split["streams"]:
+                    main.wait_stream(st)
+                for gflat, _ in split["sets"]:
+                    if gflat is not store.flat_grad:
+                        ops.axpy(store.flat_grad, gflat, 1.0, store.flat_grad)
         finally:
             eng.grad_ready_hook = hook
         ctx.call = None                                            # the tape and its private workspace are dead from here
@@ -121,6 +139,36 @@ class _ModelFn(torch.autograd.Function):
         eng = module.engine
         ctx.set_materialize_grads(False)
         grp = module._group if need else None
+        B = int(onehots.shape[0])
+        L = int(x.reshape(-1, x.shape[-1]).shape[0])
+        ctx.split = None
+        if need and grp is not None and B >= 3 and L >= module.split_min_patches and module.split_passes and not eng.collect_taps:
+            # A batched pass over a long bag runs as TWO concurrent pass groups (B - B // 3 and B // 3 task passes on two HIP streams:
+            # trainer.TrainStep._fwd_bwd_split has the measurements) -- own workspace, tape, dropout masks and gradient set per group,
+            # the task-independent patch embedding once in front of the fork.
+            sp = module._split_state()
+            groups = [(0, B - B // 3), (B - B // 3, B)]
+            eng.prepare_shared(x, coords, grp.share)
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            calls, parts = [], []
+            for (a, b), st, gset in zip(groups, sp["streams"], sp["sets"]):
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    old = eng.store.use_grad_set(*gset)
+                    try:
+                        parts.append(eng.forward(x, coords, genes, onehots[a:b], need_grad=True, fresh=True, clinical=clinical, share=grp.share))
+                        calls.append(eng.last_call)
+                    finally:
+                        eng.store.use_grad_set(*old)
+            for st in sp["streams"]:
+                main.wait_stream(st)
+            logits = torch.cat(parts, dim=0)
+            ctx.split = {"groups": groups, "streams": sp["streams"], "sets": sp["sets"]}
+            ctx.module, ctx.call, ctx.group, ctx.has_pred = module, calls, grp, token is not None
+            ctx.batched = True
+            return logits, torch.zeros((), dtype=F32, device=logits.device)
         logits = eng.forward(x, coords, genes, onehots, need_grad=need, fresh=need, clinical=clinical,
                              share=grp.share if grp is not None else None)
         ctx.module, ctx.call, ctx.group, ctx.has_pred = module, (eng.last_call if need else None), grp, token is not None
@@ -169,7 +217,18 @@ class LongNetGeneAdapter(Aggregator):
         self._init_nosync()
         self.train(True)
 
+    def _split_state(self):
+        """Streams and gradient sets of the two pass groups a long batched pass runs as (created on first use)."""
+        if getattr(self, "_split", None) is None:
+            eng = self.engine
+            self._split = {"streams": [torch.cuda.Stream(device=eng.device) for _ in range(2)],
+                           "sets": [(eng.store.flat_grad, eng.store.grads), eng.store.new_grad_set()]}
+        return self._split
+
     def _init_nosync(self):
+        self.split_passes = os.environ.get("MT_SPLIT_PASSES", "1") not in ("0", "off")      # (see _ModelFn.forward)
+        self.split_min_patches = 7500
+        self._split = None
         self.nosync_after = 2              # slides served in full by the same prediction before task tokens stop being read back (0: never)
         self._nosync_rows = self._ns_eye = self._ns_stream = self._ns_seen = None
         self._ns_pending, self._ns_pins, self._ns_slide, self._streak = [], [], 0, 0

@@ -533,6 +533,21 @@ class Engine:
         self.tape = self._main_tape
         return logits.data
 
+    def prepare_shared(self, x, coords, share: dict):
+        """The task-independent part of a slide's forward (input cast, grid indices, patch-embed GEMM + positional term) into buffers
+        of its own, left in `share` for the calls that follow: callers that run those calls on SEVERAL streams (the module bridge's
+        pass groups) do this once on the stream they fork from."""
+        cfg, dev = self.cfg, self.device
+        x = x.reshape(-1, x.shape[-1])
+        L = x.shape[0]
+        ws = {"x16": torch.empty(L, cfg.in_chans, dtype=H16, device=dev), "x0": torch.empty(L, cfg.embed_dim, dtype=F32, device=dev),
+              "prow": torch.empty(L, dtype=torch.int32, device=dev), "pcol": torch.empty(L, dtype=torch.int32, device=dev)}
+        if not self._caches_ready:
+            self._build_caches()
+        self.stage_inputs(x, coords, ws)
+        Engine._embed_patches(self, None, None, ws, True, L)
+        share["x0"], share["_x0_keep"] = ws["x0"], ws
+
     # -- overridable pieces of the image side (modaltune_amd/titan.py plugs the TITAN backbone in here)
     def _attention_plan(self, N: int, B: int):
         return ops.make_plan(branch_table(N, self.seg_lengths, DILATED_RATIOS), N, B)

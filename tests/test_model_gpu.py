@@ -515,6 +515,53 @@ def test_speculation_stops_reading_task_tokens_back_once_the_pattern_holds(golde
     assert model._nosync_rows is None and n == 1
 
 
+def test_module_batched_pass_runs_as_two_pass_groups(golden_dir):
+    """Round 5: the drop-in module's batched (speculative) pass over a long bag runs as two concurrent pass groups, like
+    TrainStep's (forced on at fixture size): same logits as the single batched pass, same parameter gradients, one hand-over."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    g = np.load(os.path.join(golden_dir, "model_L1500_d3.npz"))
+    L, seed, ngrids = int(g["L"]), int(g["seed"]), int(g["ngrids"])
+    sizes = [int(s) for s in g["sizes"]]
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3,
+                              **dict(GIGAPATH_JSON, depth=3, slide_ngrids=ngrids, interaction_indexes=[[0, 0], [1, 1], [2, 2]], dropout=0.0,
+                                     drop_path_rate=0.0))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(model.cfg, sizes, seed).items()}, strict=True)
+    inp = synth.synth_inputs(L, sizes, seed, grid=ngrids)
+    x, coords = torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda()
+    genes = {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])}
+    w = torch.randn(3, 256, generator=torch.Generator().manual_seed(1)).cuda()
+    eye = torch.eye(3).cuda()
+    model.train()
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    params = dict(model.named_parameters())
+
+    def grads():
+        torch.cuda.synchronize()
+        out = torch.cat([params[k].grad.reshape(-1).double() for k in names])
+        for k in names:
+            params[k].grad = None
+        return out
+
+    def slide():
+        xs = x.clone()
+        ys = [model(x=xs, coords=coords, genes=genes, clinical=[], task_token=eye[t].clone()) for t in (0, 1, 2)]
+        sum((y * w[t]).sum() for t, y in enumerate(ys)).backward()
+        return torch.cat([y.detach() for y in ys]), grads()
+    model.split_min_patches = 1 << 30
+    slide()                                      # learning
+    y_ref, g_ref = slide()                       # one batched pass
+    assert model._split is None
+    model.split_min_patches = 0
+    y_two, g_two = slide()                       # two groups on two streams
+    assert model._split is not None and torch.equal(y_ref, y_two)
+    assert float((g_two - g_ref).norm() / g_ref.norm()) < 2e-3
+    y_again, g_again = slide()
+    assert torch.equal(y_again, y_two) and float((g_again - g_ref).norm() / g_ref.norm()) < 2e-3
+
+
 def test_graph_replay_matches_eager(golden_dir):
     """hipGraph replay of the whole train step reproduces the eager step (same kernels, same order; the fp32-atomic
     weight-gradient reductions make two runs agree to rounding, not bitwise, and AdamW's normalised update amplifies
