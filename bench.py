@@ -658,12 +658,21 @@ def main():
     replays, eager_steps = ts.graph_replays, ts.eager_steps
     # per-kernel durations: HIP events on the launch stream around every launch of an eager, instrumented pass of the
     # same step (events cannot be recorded inside a replayed graph); not part of the timed region above
+    # The timed region above runs the task passes of a long bag as two concurrent groups (TrainStep.split_passes): kernels of the two
+    # groups overlap there, so a per-launch duration would be that of a kernel sharing the chip.  The per-kernel table and the roofline
+    # are taken on the BATCHED schedule (one B = 3 pass, every kernel alone on the chip): comparable with rounds 1-4 and with
+    # `rocprofv3 --kernel-trace --stats` of `MT_SPLIT_PASSES=0 python3 bench.py` (profiles/).
+    pass_groups = {"on": bool(ts._split_now(L)), "groups": [list(g) for g in ts._groups], "min_patches": ts.split_min_patches,
+                   "kernel_table": "batched schedule (one kernel at a time)"}
+    split_was, ts.split_passes = ts.split_passes, False
+    if pass_groups["on"]:
+        run(2, graphed=False, first=nwarm + args.steps)          # (the batched geometry's workspace and gradient arena: untimed)
     prof_steps = min(args.steps, 3)
     ops.TIMER = {}
     run(prof_steps, graphed=False, first=nwarm + args.steps)
     barrier()
     timer, ops.TIMER = ops.TIMER, None
-    skipped = nwarm + args.steps + prof_steps - int(ts.step_dev)
+    skipped = nwarm + args.steps + prof_steps + (2 if pass_groups["on"] else 0) - int(ts.step_dev)
     # the token side on its own: every token-side launch of ONE step recorded in order, captured as a hipGraph on the same buffers and
     # replayed -- what the ~220 small dependent launches cost INSIDE the replayed step (HIP events around each launch of the eager pass
     # above add the event overhead to every one of them: that table's `token_side` row is an upper bound)
@@ -696,6 +705,7 @@ def main():
         finally:
             ops.RECORD = None
             ops.RECORD_KEEP[:] = []
+    ts.split_passes = split_was
     if world > 1:
         host = args.backend != "nccl"
         tt = torch.tensor([dt, comm["comm_exposed_ms"], comm["param_gather_exposed_ms"]], device="cpu" if host else dev, dtype=torch.float64)
@@ -740,12 +750,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"Prov-GigaPath ModalAdapter train step, {L} patches x 1536-d, {args.pathways} pathways -> "
                                    f"{T - 1} gene tokens + 1 task token, 3 task passes, fp16 operands / fp32 accumulate, "
-                                   f"1 slide per GPU per step, train mode: "
+                                   f"1 slide per GPU per step"
+                                   + (", task passes as two concurrent groups (B = 2 | 1 on two HIP streams)" if pass_groups["on"] else "")
+                                   + ", train mode: "
                                    + ("dropout / drop-path off (parity configuration)" if args.no_dropout else
                                       f"Dropout({cfg.dropout}) on the embedded input and both backbone branches, DropPath(0..{cfg.drop_path_rate}) "
                                       f"per layer and on the Extractor FFN (Philox masks regenerated in backward)")
                                    + ("; ragged: bag lengths " + "/".join(str(v) for v in lengths) + " in rotation" if args.ragged else ""),
-                       "patches": L, "tokens": T, "parallelism": f"dp{world}", "dropout": not args.no_dropout,
+                       "patches": L, "tokens": T, "parallelism": f"dp{world}", "dropout": not args.no_dropout, "pass_groups": pass_groups,
                        "backend": args.backend if world > 1 else None},
             "loss": loss, "skipped_steps": skipped,
             "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / world / 1e12 / PEAK_F16_MFMA_TFLOPS,
@@ -760,7 +772,9 @@ def main():
                          "traffic_source": (f"{traffic_file}: rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs), "
                                             "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 tallies 128-B read requests at 64 B)"
                                             if traffic is not None else None),
-                         "measured": f"HIP events around each launch, eager instrumented pass of {prof_steps} steps after the timed region"},
+                         "measured": f"HIP events around each launch, eager instrumented pass of {prof_steps} steps after the timed region"
+                                     + (", on the batched schedule (one B = 3 pass: each kernel alone on the chip; the timed region overlaps two pass groups)"
+                                        if pass_groups["on"] else "")},
             "mfma_peak_measured": peak_meas,
             "roofline_worst": worst,
             "roofline_kernels": table,

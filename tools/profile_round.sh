@@ -8,7 +8,13 @@ cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 python bench.py --kernel-times > $out/bench.json 2> $out/kernel_times.txt
 python bench.py --no-cpu-baseline --no-legs --ragged > $out/bench_ragged.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-legs --eager > $out/bench_eager.json 2>/dev/null
+# kernel stats on the BATCHED schedule (every kernel alone on the chip: what `roofline` / `roofline_kernels` are taken on) ...
+export MT_SPLIT_PASSES=0
 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-legs > $out/stats.log 2>&1
+unset MT_SPLIT_PASSES
+# ... and of the default command (task passes as two concurrent groups: kernels of the groups overlap, durations are not per-kernel costs)
+rocprofv3 --kernel-trace --stats -d $out/stats_groups -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-legs > $out/stats_groups.log 2>&1
+find $out/stats_groups -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_pass_groups.csv \;
 bash tools/pmc.sh ${tag}_fwd tools/fwd_microbench.py
 bash tools/pmc.sh ${tag}_bwd tools/kv_microbench.py
 bash tools/pmc_hbm.sh ${tag}_bwd tools/kv_microbench.py
