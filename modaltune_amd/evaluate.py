@@ -8,6 +8,7 @@ The probes themselves (sklearn LogisticRegression / lifelines Cox, TM:329-458) a
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -47,6 +48,36 @@ class EmbeddingExtractor:
         self._pool = None
         self.graph_replays = 0
         self.patch_size_lv0 = 1024          # TITAN configuration only (titan_adapter.py:335)
+        self.split_passes = os.environ.get("MT_SPLIT_PASSES", "1") not in ("0", "off")
+        self.split_min_patches = 7500
+        self._streams = self._tapes = None
+
+    def _forward_groups(self, B: int, L: int) -> torch.Tensor:
+        """The forward of a long bag as two concurrent pass groups (trainer.TrainStep._fwd_bwd_split, forward half): the patch
+        embedding once in front of the fork, own workspace and tape per group, logits joined behind it."""
+        eng = self.engine
+        if self._streams is None:
+            from .tape import Tape
+            self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(2)]
+            self._tapes = [Tape(self.dev) for _ in range(2)]
+        a = B - B // 3
+        ws0 = eng._workspace(a, L)
+        eng._embed_patches(None, None, ws0, True, L)
+        share = {"x0": ws0["x0"]}
+        out = torch.empty(B, eng.cfg.output_dim, dtype=F32, device=self.dev)
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for gi, (lo, hi) in enumerate(((0, a), (a, B))):
+            st = self._streams[gi]
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                lg = eng.forward(None, None, self._sgenes, self.onehots[lo:hi], need_grad=False, staged=True, geometry=(hi - lo, L),
+                                 clinical=self._sclin, share=share, tape=self._tapes[gi], site_group=gi + 1)
+                out[lo:hi].copy_(lg)
+        for st in self._streams:
+            main.wait_stream(st)
+        return out
 
     @property
     def _graph(self):
@@ -66,6 +97,7 @@ class EmbeddingExtractor:
         L, B = x.shape[0], self.onehots.shape[0]
         if isinstance(genes, dict):
             genes = [genes[k] for k in sorted(genes.keys())]
+        split = False
         replayable = self.graphed and (not titan or (getattr(eng, "native", False) and getattr(eng.backbone, "embed_w", None) is not None))
         if not replayable:      # (TITAN on the module's own torch blocks: nothing to capture)
             if titan:
@@ -78,7 +110,12 @@ class EmbeddingExtractor:
             eng._workspace(B, Lv)                                     # (may grow the workspace: bumps eng.generation)
         else:
             Lv = L
-            eng.stage_inputs(x, coords, B=B)                          # (may grow the workspace: bumps eng.generation)
+            # long bags: the task passes as two concurrent groups (B - B // 3 and B // 3 passes on two HIP streams), as in the train step
+            split = self.split_passes and B >= 3 and L >= self.split_min_patches and eng.cfg.is_multi and not eng.collect_taps
+            gB = [B - B // 3, B // 3] if split else [B]
+            for nb in gB[1:]:
+                eng._workspace(nb, L)
+            eng.stage_inputs(x, coords, B=gB[0])                      # (may grow the workspace: bumps eng.generation)
         skey = int(gflat.numel())
         if self._static_key != skey:
             self._static_key = skey
@@ -96,6 +133,8 @@ class EmbeddingExtractor:
         if titan:
             run = lambda: eng.forward_slide(None, None, self._sgenes, self.onehots, patch_size_lv0=self.patch_size_lv0, need_grad=False,
                                             clinical=self._sclin, staged=True)
+        elif split:
+            run = lambda: self._forward_groups(B, L)
         else:
             run = lambda: eng.forward(None, None, self._sgenes, self.onehots, need_grad=False, staged=True, geometry=(B, L),
                                       clinical=self._sclin)

@@ -654,6 +654,12 @@ def test_eval_embedding_path_matches_training_forward(golden_dir):
                               [dict(x=x, coords=inp["coords"], genes=genes, case_id="c0")])
     assert feats.shape == (1, 3, 256) and ids == ["c0"]
     assert _rel(feats[0], g["f64_logits"]) < 1e-3
+    # long bags run the task passes as two concurrent groups (forced on here): the same logits, eager and replayed
+    ex2 = EmbeddingExtractor(eng)
+    ex2.split_min_patches = 0
+    outs2 = [ex2(x, inp["coords"], genes).clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    assert ex2._streams is not None and ex2.graph_replays >= 1 and all(torch.equal(o, outs[1]) for o in outs2)
 
 
 def test_full_size_properties_L10000():
