@@ -385,6 +385,10 @@ int mt_act_bwd(const float* x, const float* dy, float* dx, long n, int act, mt_s
 int mt_axpy(const float* a, const float* b, float alpha, float* y, long n, mt_stream_t stream);
 /* y[i] = a[i] + alpha * b[i % period]: a [period] row block broadcast over the batch (with_pos_embed, AM:64-65) */
 int mt_axpy_bcast(const float* a, const float* b, float alpha, float* y, long n, long period, mt_stream_t stream);
+/* out[i] += sum_r x[r * period + i] (r ascending): the gradient of the broadcast operand of mt_axpy_bcast and of the rows
+ * mt_layernorm_fwd adds per period (d level / position embeddings summed over the task passes, AM:64-65); period % 4 == 0,
+ * 16-byte aligned pointers */
+int mt_fold_rows(const float* x, int reps, long period, float* out, mt_stream_t stream);
 /* strided row copies between fp32 buffers: dst(map(m), :) (+)= src(map(m), :) */
 int mt_copy_rows_f32(const float* src, long lds, const MtRowMap* smap, float* dst, long ldd, const MtRowMap* dmap,
                      int M, int D, int accumulate, mt_stream_t stream);

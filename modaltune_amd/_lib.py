@@ -116,6 +116,7 @@ SIGNATURES = {
     "mt_act_bwd": [P, P, P, L, I, P],
     "mt_axpy": [P, P, F, P, L, P],
     "mt_axpy_bcast": [P, P, F, P, L, L, P],
+    "mt_fold_rows": [P, I, L, P, P],
     "mt_copy_rows_f32": [P, L, RM, P, L, RM, I, I, I, P],
     "mt_inject_resid_bwd": [P, L, RM, P, L, RM, P, P, P, L, RM, I, P, P, I, I, P],
     "mt_l2norm_rows": [P, P, I, I, P],

@@ -500,97 +500,128 @@ __global__ __launch_bounds__(256) void extract_attn_bwd_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------- token self-attention -----------
-// grid (heads, B); thread = query token.  probs [B, heads, T, T] saved for the backward.
-__global__ __launch_bounds__(128) void token_mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+// grid (heads, B), 512 threads: four threads per query token (sub = tid & 3), all T <= 128 tokens in ONE sweep.  K, V and the
+// T x T score matrix live in LDS: the scores are written once, normalised in place, and leave as probs [B, heads, T, T] (saved
+// for the backward) in one pass.  (The first form -- a thread per query looping over the keys with the score row in GLOBAL
+// memory, written and re-read three times -- ran 24 us for 36 workgroups of 65 tokens; the step launches it between dependent
+// token-side products, so its latency is exposed.  256 threads = 64 tokens per sweep: 13 us at T = 65, the 65th token costs a
+// whole second sweep.)
+MT_DEVINL f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__global__ __launch_bounds__(512) void token_mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             int T, int E, int heads, float* __restrict__ out, float* __restrict__ probs) {
-  __shared__ float ks[TMAX * AD], vs[TMAX * AD];
-  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-  for (int i = t; i < T * AD; i += 128) {
-    const int tt = i / AD, d = i % AD;
-    ks[i] = k[((long)b * T + tt) * E + h * AD + d];
-    vs[i] = v[((long)b * T + tt) * E + h * AD + d];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ks = smem;                 // [T][16]
+  float* vs = ks + T * AD;
+  float* ss = vs + T * AD;          // [T][T + 1]
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, sub = tid & 3, S1 = T + 1;
+  for (int i = tid; i < T * 4; i += 512) {
+    const int tt = i >> 2, c = (i & 3) * 4;
+    const long o = ((long)b * T + tt) * E + h * AD + c;
+    *reinterpret_cast<f32x4*>(ks + tt * AD + c) = ld4(k + o);
+    *reinterpret_cast<f32x4*>(vs + tt * AD + c) = ld4(v + o);
+  }
+  const int t = tid >> 2;
+  const bool act = t < T;
+  float qv[AD];
+  if (act) {
+    const float* qr = q + ((long)b * T + t) * E + h * AD;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 x = ld4(qr + 4 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qv[4 * c + e] = x[e] * ASCALE;
+    }
   }
   __syncthreads();
-  if (t >= T) return;
-  float qv[AD], acc[AD];
+  if (act) {
+    float mx = -1.0e30f;
+    for (int j = sub; j < T; j += 4) {
+      const float* kr = ks + j * AD;
+      float s = 0.f;
 #pragma unroll
-  for (int d = 0; d < AD; ++d) { qv[d] = q[((long)b * T + t) * E + h * AD + d] * ASCALE; acc[d] = 0.f; }
-  float* pr = probs + (((long)b * heads + h) * T + t) * T;
-  float mx = -1.0e30f;
-  for (int j = 0; j < T; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < AD; ++d) s = fmaf(qv[d], ks[j * AD + d], s);
-    pr[j] = s;
-    mx = fmaxf(mx, s);
+      for (int d = 0; d < AD; ++d) s = fmaf(qv[d], kr[d], s);
+      ss[t * S1 + j] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float l = 0.f;
+    for (int j = sub; j < T; j += 4) { const float p = __expf(ss[t * S1 + j] - mx); ss[t * S1 + j] = p; l += p; }
+    l += __shfl_xor(l, 1, 64);
+    l += __shfl_xor(l, 2, 64);
+    const float inv = 1.0f / l;
+    float* pr = probs + (((long)b * heads + h) * T + t) * T;
+    for (int j = sub; j < T; j += 4) { const float p = ss[t * S1 + j] * inv; ss[t * S1 + j] = p; pr[j] = p; }
   }
-  float l = 0.f;
-  for (int j = 0; j < T; ++j) { const float p = __expf(pr[j] - mx); pr[j] = p; l += p; }
-  const float inv = 1.0f / l;
-  for (int j = 0; j < T; ++j) {
-    const float p = pr[j] * inv;
-    pr[j] = p;
-#pragma unroll
-    for (int d = 0; d < AD; ++d) acc[d] = fmaf(p, vs[j * AD + d], acc[d]);
+  __syncthreads();          // a row's four writers -> its four readers
+  if (act) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < T; ++j) acc += ss[t * S1 + j] * ld4(vs + j * AD + 4 * sub);
+    *reinterpret_cast<f32x4*>(out + ((long)b * T + t) * E + h * AD + 4 * sub) = acc;
   }
-#pragma unroll
-  for (int d = 0; d < AD; ++d) out[((long)b * T + t) * E + h * AD + d] = acc[d];
 }
 
-__global__ __launch_bounds__(128) void token_mha_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+// dq / dk / dv of the above from the saved probs: dP = dO V^T, dS = P (dP - rowsum(P dP)) scale, dQ = dS K, dK = dS^T Q, dV = P^T dO.
+// Q, K, V, dO and dS in LDS -- and P too while both T x T images fit (PL: T <= 127; beyond that P is read from global memory);
+// four threads per token, each owning four of the sixteen head dimensions in the output sweeps.
+template <bool PL>
+__global__ __launch_bounds__(512) void token_mha_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             const float* __restrict__ probs, const float* __restrict__ dout, int T, int E,
                                                             int heads, float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qs = smem;                 // [T][16]
-  float* ks = qs + TMAX * AD;
-  float* vs = ks + TMAX * AD;
-  float* dos = vs + TMAX * AD;
-  float* dss = dos + TMAX * AD;     // [T][T+1]  dS (already scaled)
-  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-  for (int i = t; i < T * AD; i += 128) {
-    const int tt = i / AD, d = i % AD;
-    const long o = ((long)b * T + tt) * E + h * AD + d;
-    qs[i] = q[o]; ks[i] = k[o]; vs[i] = v[o]; dos[i] = dout[o];
-  }
-  __syncthreads();
+  float* ks = qs + T * AD;
+  float* vs = ks + T * AD;
+  float* dos = vs + T * AD;
+  float* dss = dos + T * AD;        // [T][T + 1]  dS (already scaled)
+  float* pls = dss + T * (T + 1);   // [T][T + 1]  P (PL only)
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, sub = tid & 3, S1 = T + 1;
   const float* pbase = probs + ((long)b * heads + h) * T * T;
-  if (t < T) {
-    const float* pr = pbase + (long)t * T;
+  for (int i = tid; i < T * 4; i += 512) {
+    const int tt = i >> 2, c = (i & 3) * 4;
+    const long o = ((long)b * T + tt) * E + h * AD + c;
+    *reinterpret_cast<f32x4*>(qs + tt * AD + c) = ld4(q + o);
+    *reinterpret_cast<f32x4*>(ks + tt * AD + c) = ld4(k + o);
+    *reinterpret_cast<f32x4*>(vs + tt * AD + c) = ld4(v + o);
+    *reinterpret_cast<f32x4*>(dos + tt * AD + c) = ld4(dout + o);
+  }
+  if (PL)
+    for (int i = tid; i < T * T; i += 512) pls[(i / T) * S1 + i % T] = pbase[i];
+  __syncthreads();
+  const int t = tid >> 2;
+  const bool act = t < T;
+  const float* pr = PL ? pls + t * S1 : pbase + (long)t * T;      // row t of P
+  const long pst = PL ? S1 : T;
+  const float* pc = PL ? pls + t : pbase + t;                      // column t of P
+  if (act) {          // a thread writes and re-reads only its own entries (j = sub mod 4) here
+    float dov[AD];
+#pragma unroll
+    for (int d = 0; d < AD; ++d) dov[d] = dos[t * AD + d];
     float delta = 0.f;
-    for (int j = 0; j < T; ++j) {
+    for (int j = sub; j < T; j += 4) {
+      const float* vr = vs + j * AD;
       float dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) dp = fmaf(dos[t * AD + d], vs[j * AD + d], dp);
-      dss[t * (T + 1) + j] = dp;
+      for (int d = 0; d < AD; ++d) dp = fmaf(dov[d], vr[d], dp);
+      dss[t * S1 + j] = dp;
       delta = fmaf(pr[j], dp, delta);
     }
-    float dqv[AD];
-#pragma unroll
-    for (int d = 0; d < AD; ++d) dqv[d] = 0.f;
-    for (int j = 0; j < T; ++j) {
-      const float ds = pr[j] * (dss[t * (T + 1) + j] - delta) * ASCALE;
-      dss[t * (T + 1) + j] = ds;
-#pragma unroll
-      for (int d = 0; d < AD; ++d) dqv[d] = fmaf(ds, ks[j * AD + d], dqv[d]);
-    }
-#pragma unroll
-    for (int d = 0; d < AD; ++d) dq[((long)b * T + t) * E + h * AD + d] = dqv[d];
+    delta += __shfl_xor(delta, 1, 64);
+    delta += __shfl_xor(delta, 2, 64);
+    for (int j = sub; j < T; j += 4) dss[t * S1 + j] = pr[j] * (dss[t * S1 + j] - delta) * ASCALE;
   }
   __syncthreads();
-  if (t < T) {   // thread = key j = t
-    float dkv_[AD], dvv[AD];
-#pragma unroll
-    for (int d = 0; d < AD; ++d) { dkv_[d] = 0.f; dvv[d] = 0.f; }
-    for (int i = 0; i < T; ++i) {
-      const float ds = dss[i * (T + 1) + t], p = pbase[(long)i * T + t];
-#pragma unroll
-      for (int d = 0; d < AD; ++d) { dkv_[d] = fmaf(ds, qs[i * AD + d], dkv_[d]); dvv[d] = fmaf(p, dos[i * AD + d], dvv[d]); }
+  if (act) {          // dQ: thread (query t, dims 4 sub ..);  dK, dV: thread (key t, dims 4 sub ..)
+    f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < T; ++j) {
+      aq += dss[t * S1 + j] * ld4(ks + j * AD + 4 * sub);
+      ak += dss[j * S1 + t] * ld4(qs + j * AD + 4 * sub);
+      av += pc[j * pst] * ld4(dos + j * AD + 4 * sub);
     }
-#pragma unroll
-    for (int d = 0; d < AD; ++d) {
-      dk[((long)b * T + t) * E + h * AD + d] = dkv_[d];
-      dv[((long)b * T + t) * E + h * AD + d] = dvv[d];
-    }
+    const long o = ((long)b * T + t) * E + h * AD + 4 * sub;
+    *reinterpret_cast<f32x4*>(dq + o) = aq;
+    *reinterpret_cast<f32x4*>(dk + o) = ak;
+    *reinterpret_cast<f32x4*>(dv + o) = av;
   }
 }
 
@@ -655,25 +686,44 @@ extern "C" int mt_extract_attn_bwd(const float* q, const mt_half* kv, const floa
   return MT_OK;
 }
 
+static bool mha_ptrs_ok(const float* const* ps, int n, int E) {
+  for (int i = 0; i < n; ++i)
+    if (!ps[i] || ((uintptr_t)ps[i] & 15)) return false;
+  return (E & 3) == 0;
+}
 extern "C" int mt_token_mha_fwd(const float* q, const float* k, const float* v, int B, int T, int E, int heads,
                                 float* out, float* probs, mt_stream_t stream) {
-  if (!q || !k || !v || !out || !probs || B < 1 || T < 1 || T > TMAX || E != heads * AD) return MT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(token_mha_fwd_kernel, dim3(heads, B), dim3(128), 0, (hipStream_t)stream, q, k, v, T, E, heads, out, probs);
+  const float* ps[] = {q, k, v, out};
+  if (!mha_ptrs_ok(ps, 4, E) || !probs || B < 1 || T < 1 || T > TMAX || E != heads * AD) return MT_ERR_BAD_ARG;
+  const size_t shm = sizeof(float) * (2 * T * AD + T * (T + 1));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)token_mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(token_mha_fwd_kernel, dim3(heads, B), dim3(512), shm, (hipStream_t)stream, q, k, v, T, E, heads, out, probs);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
 
 extern "C" int mt_token_mha_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                                 int B, int T, int E, int heads, float* dq, float* dk, float* dv, mt_stream_t stream) {
-  if (!q || !k || !v || !probs || !dout || !dq || !dk || !dv || B < 1 || T < 1 || T > TMAX || E != heads * AD) return MT_ERR_BAD_ARG;
-  const size_t shm = sizeof(float) * (4 * TMAX * AD + T * (T + 1));
+  const float* ps[] = {q, k, v, dout, dq, dk, dv};
+  if (!mha_ptrs_ok(ps, 7, E) || !probs || B < 1 || T < 1 || T > TMAX || E != heads * AD) return MT_ERR_BAD_ARG;
+  const bool pl = sizeof(float) * (4 * T * AD + 2 * T * (T + 1)) <= 160 * 1024;      // both T x T images (dS, P) fit up to T = 127
+  const size_t shm = sizeof(float) * (4 * T * AD + (pl ? 2 : 1) * T * (T + 1));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)token_mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)token_mha_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)token_mha_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(token_mha_bwd_kernel, dim3(heads, B), dim3(128), shm, (hipStream_t)stream, q, k, v, probs, dout, T, E,
-                     heads, dq, dk, dv);
+  if (pl)
+    hipLaunchKernelGGL(token_mha_bwd_kernel<true>, dim3(heads, B), dim3(512), shm, (hipStream_t)stream, q, k, v, probs, dout, T, E,
+                       heads, dq, dk, dv);
+  else
+    hipLaunchKernelGGL(token_mha_bwd_kernel<false>, dim3(heads, B), dim3(512), shm, (hipStream_t)stream, q, k, v, probs, dout, T, E,
+                       heads, dq, dk, dv);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

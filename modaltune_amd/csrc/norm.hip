@@ -491,6 +491,14 @@ __global__ void axpy_bcast_kernel(const float* a, const float* b, float alpha, f
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = a[i] + alpha * b[i % period];
 }
+// out[i] += sum_r x[r * period + i], r ascending: the adjoint of axpy_bcast (period % 4 == 0, 16-byte aligned)
+__global__ void fold_rows_kernel(const float* __restrict__ x, int reps, long period, float* __restrict__ out) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < period; i += (long)gridDim.x * blockDim.x * 4) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(x + i);
+    for (int r = 1; r < reps; ++r) s += *reinterpret_cast<const f32x4*>(x + r * period + i);
+    *reinterpret_cast<f32x4*>(out + i) += s;
+  }
+}
 __global__ void copy_rows_kernel(const float* src, long lds, RowMap smap, float* dst, long ldd, RowMap dmap, int M,
                                  int D, int accumulate) {
   const int per_row = D / 4;
@@ -764,6 +772,12 @@ extern "C" int mt_axpy(const float* a, const float* b, float alpha, float* y, lo
 extern "C" int mt_axpy_bcast(const float* a, const float* b, float alpha, float* y, long n, long period, mt_stream_t stream) {
   if (!a || !b || !y || n <= 0 || period <= 0) return MT_ERR_BAD_ARG;
   hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, y, n, period);
+  MT_CHECK_LAUNCH();
+  return MT_OK;
+}
+extern "C" int mt_fold_rows(const float* x, int reps, long period, float* out, mt_stream_t stream) {
+  if (!x || !out || reps < 1 || period <= 0 || (period & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return MT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(fold_rows_kernel, dim3(ew_grid(period / 4)), dim3(256), 0, (hipStream_t)stream, x, reps, period, out);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

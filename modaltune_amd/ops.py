@@ -434,6 +434,11 @@ def absmax_scale(x, s, target=1024.0, n=None):
     check(_lib.load().mt_absmax_scale(_p(x), n if n is not None else x.numel(), float(target), _p(s), _s()), "absmax_scale")
 
 
+def fold_rows(x, reps, period, out):
+    """out[i] += sum_r x[r * period + i] (the adjoint of axpy_bcast)."""
+    check(_lib.load().mt_fold_rows(_p(x), reps, period, _p(out), _s()), "fold_rows")
+
+
 def axpy_dev(a, b, alpha_dev, y, n=None):
     """y = a + (*alpha_dev) * b; a may be None."""
     check(_lib.load().mt_axpy_dev(_p(a), _p(b), _p(alpha_dev), _p(y), n if n is not None else b.numel(), _s()), "axpy_dev")
@@ -537,6 +542,7 @@ adamw_step = _timed(lambda *a, **k: "adamw")(adamw_step)
 _small = lambda n: "token_side" if n <= (1 << 20) else "elementwise"
 axpy = _timed(lambda a, b, alpha, y, n=None: _small(n if n is not None else b.numel()))(axpy)
 axpy_bcast = _timed(lambda a, b, alpha, y, period, n=None: _small(n if n is not None else a.numel()))(axpy_bcast)
+fold_rows = _timed(lambda x, reps, period, out: _small(reps * period))(fold_rows)
 copy_rows = _timed(lambda src, dst, M, D, **k: "token_side" if M <= 1024 else "copy_rows")(copy_rows)
 droppath_rows = _timed(lambda x, M, D, drop: "token_side" if M <= 1024 else "droppath_rows")(droppath_rows)
 dropout_f32 = _timed(lambda x, y, M, D, drop, **k: "token_side" if M <= 1024 else "dropout_f32")(dropout_f32)

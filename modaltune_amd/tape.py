@@ -262,7 +262,7 @@ class Tape:
                 return
             if add_rows is not None and add_rows.grad is not None:   # d pe[t] += sum over the batch of dy
                 reps, per = R // period, period * D
-                ops.sgemm(self._ones, (0, 1), y.grad, (1, per), add_rows.grad, (per, 1), 1, per, reps, accumulate=True)
+                ops.fold_rows(y.grad, reps, per, add_rows.grad)
             train = w.grad is not None
             dx = x.g() if x.needs_grad else self.new(*x.data.shape)
             ops.layernorm_bwd(y.grad, x.data, w.data, stats, dx, R, D, accumulate=x.needs_grad,
@@ -300,8 +300,8 @@ class Tape:
         def bwd():
             if y.grad is None:
                 return
-            if p.grad is not None:       # dp[t, :] += sum_b dy[b, t, :] : a [1, Bb] x [Bb, per] product
-                ops.sgemm(self._ones, (0, 1), y.grad, (1, per), p.grad, (per, 1), 1, per, Bb, accumulate=True)
+            if p.grad is not None:       # dp[t, :] += sum_b dy[b, t, :]
+                ops.fold_rows(y.grad, Bb, per, p.grad)
             if a.needs_grad:
                 if a.grad is None:
                     a.grad = y.grad      # y.grad is dead after this closure

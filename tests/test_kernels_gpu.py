@@ -357,6 +357,16 @@ def test_pack_weights_grouped_and_broadcast_add(ops):
     ops.axpy_bcast(a.to(DEV), pe.to(DEV), 1.0, y, 65 * 768)
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), a + pe)
+    # its adjoint: d pe += sum over the passes (mt_fold_rows, passes in ascending order)
+    dpe0 = torch.randn(65, 768, generator=g)
+    dpe = dpe0.to(DEV)
+    ops.fold_rows(a.to(DEV), 3, 65 * 768, dpe)
+    one = torch.randn(1, 4, generator=g)
+    d1 = torch.zeros(4, device=DEV)
+    ops.fold_rows(one.to(DEV), 1, 4, d1)
+    torch.cuda.synchronize()
+    assert torch.equal(dpe.cpu(), dpe0 + ((a[0] + a[1]) + a[2]))
+    assert torch.equal(d1.cpu(), one[0])
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
@@ -704,7 +714,7 @@ def test_extract_attention(ops, T, L, nsplit):
     assert rel(dkv.view(B, L, 384), kvd.grad) < 3e-3
 
 
-@pytest.mark.parametrize("T", [65, 7])
+@pytest.mark.parametrize("T", [65, 7, 64, 127, 128, 1])
 def test_token_mha(ops, T):
     g = rng(T + 100)
     B, E = 3, 192

@@ -47,3 +47,27 @@ for (M, N, K) in ((T, 192, 768), (T, 768, 192), (T, 192, 192), (T, 576, 192), (T
     bench(f"fwd  M={M} N={N} K={K}", fwd(M, N, K))
 for (M, N, K) in ((T, 192, 768), (T, 768, 192), (T, 192, 192)):
     bench(f"bwd  M={M} N={N} K={K} (dX + dW)", bwd(M, N, K))
+
+
+# ---- the step's other forms (tools/diag/token_launches.py prints where they come from)
+def act_fwd(M, N, K, act, pre, drop):      # the mixer's first dense: GELU, saved pre-activation, element dropout
+    def mk():
+        x, w, y = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.empty(M, N, device=dev)
+        b, p = torch.randn(N, device=dev), torch.empty(M, N, device=dev)
+        rng = torch.tensor([1, 2, 3, 0], dtype=torch.int32, device=dev)
+        d = ops.dropout_spec(rng, 5, 0.1) if drop else None
+        return [ops.sgemm_problem(x, (K, 1), w, (K, 1), y, (N, 1), M, N, K, bias=b, act=act, pre_out=p if pre else None, c_drop=d)], (x, w, y, b, p, rng)
+    return mk
+
+
+def pass_sum(P, n):      # d(broadcast rows) += sum over the task passes: [1, n] += ones[1, P] . dy[P, n]
+    def mk():
+        dy, ones, out = torch.randn(P, n, device=dev), torch.ones(1, P, device=dev), torch.zeros(1, n, device=dev)
+        return [ops.sgemm_problem(ones, (P, 1), dy, (1, n), out, (n, 1), 1, n, P, accumulate=True)], (dy, ones, out)
+    return mk
+
+
+for act, pre, drop in ((0, False, False), (ops.ACT_GELU, False, False), (ops.ACT_GELU, True, False), (ops.ACT_GELU, True, True), (ops.ACT_RELU, True, True)):
+    bench(f"fwd  M=18 N=128 K=256 act={act} pre={int(pre)} drop={int(drop)}", act_fwd(18, 128, 256, act, pre, drop))
+    bench(f"fwd  M={T} N=192 K=768 act={act} pre={int(pre)} drop={int(drop)}", act_fwd(T, 192, 768, act, pre, drop))
+bench("pass sum [1, 49920] += 1[1,3] dy[3, 49920]", pass_sum(3, 49920))
