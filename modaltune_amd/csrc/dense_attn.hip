@@ -36,20 +36,37 @@ struct DenseArgs {
 };
 
 struct DItem { int b, h, qt; bool live; };
-// Workgroup -> (pass, head, 128-row tile): blocks b and b + 8 share an XCD, so XCD x owns the (pass, head) groups x, x + 8, ... and
-// walks them with their tiles interleaved (tile 0 of each of its groups, then tile 1 of each, ...): every tile of a group
-// re-reads the same K / V rows from ONE L2 (4-5 groups x 1 MB at N = 4097 stay resident), and the workgroups of one tile index
-// that run side by side share that tile's stripe of the distance table (same-box: -1..-3 % on all three kernels against
-// group after group; two groups at a time: +10 %, tools/experiments/README.md).
+// Workgroup -> (pass, head, 128-row tile).  Blocks b and b + 8 share an XCD.  The B * H (pass, head) groups do not divide by the eight
+// XCDs (36 = 4 x 8 + 4): with whole groups per XCD four XCDs carry five groups and four carry four -- at N = 4 097 (33 tiles) that is
+// 165 against 132 workgroups on 96 slots, the launch ends when the loaded half is done, and the 33rd tile pushes its CUs from five
+// workgroups to six (measured: 4 096 -> 4 097 tokens costs the forward 13 %, tools/experiments/README.md).  So: XCD x owns the whole groups
+// x, x + 8, ... (every tile of a group re-reads the same K / V rows from ONE L2; 4-5 groups x 1 MB at N = 4 097 stay resident) and an
+// EQUAL share of the tiles of the B * H mod 8 left-over groups (a contiguous run of the (group, tile) list: a left-over group's
+// K / V are read through two L2s at most).  An XCD walks its lanes -- whole groups, plus the left-over run -- with their tiles
+// interleaved (tile 0 of each, then tile 1 of each, ...): the workgroups of one tile index that run side by side share that tile's
+// stripe of the distance table (same-box: -1..-3 % on all three kernels against group after group; two groups at a time: +10 %).
 MT_DEVINL DItem ddecode(const DenseArgs& a, int bid) {
   const int x = bid & 7, j = bid >> 3;
-  const int ng = (a.B * a.H + 7) >> 3;      // groups per XCD
+  const int G = a.B * a.H, full = G >> 3, rem = G & 7;
+  const int nl = full + (rem ? 1 : 0);      // lanes per XCD
+  const int lane = __builtin_amdgcn_readfirstlane(j % nl), pos = __builtin_amdgcn_readfirstlane(j / nl);
+  int gid, qt;
+  bool live = true;
+  if (lane < full) {
+    gid = lane * 8 + x;
+    qt = pos;
+  } else {
+    const int items = rem * a.qtiles, share = (items + 7) >> 3;
+    const int e = x * share + pos;
+    live = pos < share && e < items;
+    gid = full * 8 + e / a.qtiles;
+    qt = e % a.qtiles;
+  }
   DItem w;
-  w.qt = __builtin_amdgcn_readfirstlane(j / ng);
-  const int gid = __builtin_amdgcn_readfirstlane((j % ng) * 8 + x);
-  w.live = gid < a.B * a.H;
-  w.h = __builtin_amdgcn_readfirstlane(gid % a.H);
-  w.b = __builtin_amdgcn_readfirstlane(gid / a.H);
+  w.live = live;
+  w.qt = __builtin_amdgcn_readfirstlane(qt);
+  w.h = __builtin_amdgcn_readfirstlane(live ? gid % a.H : 0);
+  w.b = __builtin_amdgcn_readfirstlane(live ? gid / a.H : 0);
   return w;
 }
 
