@@ -54,24 +54,36 @@ MT_DEVINL int cell_key(const int* cells, int i) { return (cells[2 * i] << 16) | 
 // Patches that share a cell form a chain in patch order: first[i] = no earlier patch has i's cell; next[i] = the next later
 // patch of the same cell (or -1).  O(L^2) integer compares (L = 10^4: 10^8), no sort, no global atomics -- the sums below come out
 // in patch order, bitwise reproducible (index_add_ on the CPU adds in that order).  One workgroup = 64 patches (one per lane) x 16
-// waves, wave w scanning the w-th sixteenth of the keys (wave-uniform index: the keys come through the scalar cache); the sixteen
-// partial answers meet in LDS.  (One thread per patch scanning all L keys left 26 workgroups on the chip at L = 6 500: 220-350 us;
-// this form: L / 64 x 16 waves.)
+// waves: the workgroup stages 1024 keys at a time in LDS (one coalesced load per thread) and wave w scans the w-th 64 of them, four
+// keys per broadcast ds_read_b128; the sixteen partial answers meet in LDS.  (Keys through the scalar cache, one dependent s_load
+// pair per key: 47 us at L = 4 369 -- the kernel sits between two graph launches of the replayed step; one thread per patch
+// scanning all L keys left 26 workgroups on the chip at L = 6 500: 220-350 us.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(1024) void titan_chain_kernel(const int* __restrict__ cells, int L, int* __restrict__ first, int* __restrict__ next) {
   __shared__ int s_first[64], s_next[64];
+  __shared__ __attribute__((aligned(16))) int keys[1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const int mine = i < L ? cell_key(cells, i) : -1;
   if (wave == 0) { s_first[lane] = 1; s_next[lane] = 0x7fffffff; }
-  __syncthreads();
-  const int seg = (L + 15) / 16, j0 = __builtin_amdgcn_readfirstlane(wave * seg), j1 = min(L, j0 + seg);
   bool fst = true;
   int nxt = 0x7fffffff;
-  for (int j = j0; j < j1; ++j) {
-    const int kj = cell_key(cells, j);          // uniform address
-    if (kj == mine) {
-      if (j < i) fst = false;
-      else if (j > i) nxt = min(nxt, j);
+  for (int base = 0; base < L; base += 1024) {
+    __syncthreads();
+    const int jl = base + (int)threadIdx.x;
+    keys[threadIdx.x] = jl < L ? cell_key(cells, jl) : -2;      // (-2: matches no patch, not even the -1 of the lanes past L)
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      const i32x4 kk = *reinterpret_cast<const i32x4*>(&keys[wave * 64 + k]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = base + wave * 64 + k + e;
+        if (kk[e] == mine) {
+          if (j < i) fst = false;
+          else if (j > i) nxt = min(nxt, j);
+        }
+      }
     }
   }
   if (!fst) s_first[lane] = 0;                  // (racing stores of the same value)
@@ -103,12 +115,18 @@ __global__ __launch_bounds__(256) void titan_cell_sum_kernel(const float* __rest
 
 // Token position of every occupied cell = its rank among the occupied cells in row-major order (the order `x[bg_mask]` keeps,
 // TA:282-291); pos[i] = -1 for patches that own no token.  count[0] = number of tokens (without cls); cells_tok[pos] = (row, col).
+// One workgroup = 64 patches (one per lane) x 4 waves: 1024 candidate keys at a time in LDS, wave w counts the smaller ones in its
+// quarter (four keys per broadcast ds_read_b128); the four partial ranks meet in LDS.  (256 patches per workgroup, each thread walking
+// every key one LDS read at a time: 18 workgroups and 53 us at L = 4 369.)
 __global__ __launch_bounds__(256) void titan_order_kernel(const int* __restrict__ cells, const int* __restrict__ first, const int* __restrict__ nz,
                                                           int L, int* __restrict__ pos, int* __restrict__ cells_tok, int* __restrict__ count) {
-  __shared__ int keys[1024];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) int keys[1024];
+  __shared__ int s_rank[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   const bool own = i < L && first[i] && nz[i];
   const int mine = i < L ? cell_key(cells, i) : 0;
+  if (wave == 0) s_rank[lane] = 0;
   int rank = 0;
   for (int base = 0; base < L; base += 1024) {
     __syncthreads();
@@ -117,10 +135,16 @@ __global__ __launch_bounds__(256) void titan_order_kernel(const int* __restrict_
       keys[k] = (j < L && first[j] && nz[j]) ? cell_key(cells, j) : 0x7fffffff;
     }
     __syncthreads();
-    const int n = min(1024, L - base);
-    for (int k = 0; k < n; ++k) rank += keys[k] < mine ? 1 : 0;
+#pragma unroll 4
+    for (int k = 0; k < 256; k += 4) {
+      const i32x4 kk = *reinterpret_cast<const i32x4*>(&keys[wave * 256 + k]);
+      rank += (kk[0] < mine ? 1 : 0) + (kk[1] < mine ? 1 : 0) + (kk[2] < mine ? 1 : 0) + (kk[3] < mine ? 1 : 0);
+    }
   }
-  if (i < L) {
+  atomicAdd(&s_rank[lane], rank);
+  __syncthreads();
+  rank = s_rank[lane];
+  if (wave == 0 && i < L) {
     pos[i] = own ? rank : -1;
     if (own) {
       cells_tok[2 * rank] = cells[2 * i]; cells_tok[2 * rank + 1] = cells[2 * i + 1];
@@ -313,7 +337,7 @@ extern "C" int mt_titan_token_order(const int* cells, const int* first, const in
   if (!cells || !first || !nz || !pos || !cells_tok || !count || L < 1) return MT_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(count, 0, sizeof(int), s) != hipSuccess) return MT_ERR_LAUNCH;
-  hipLaunchKernelGGL(titan_order_kernel, dim3((L + 255) / 256), dim3(256), 0, s, cells, first, nz, L, pos, cells_tok, count);
+  hipLaunchKernelGGL(titan_order_kernel, dim3((L + 63) / 64), dim3(256), 0, s, cells, first, nz, L, pos, cells_tok, count);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }
