@@ -184,6 +184,171 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
   }
 }
 
+// ---- few pathways (the 6-pathway configuration of the headline bench): a workgroup per pathway leaves the chip to 6 workgroups that
+// each pull a 256 KB W2 through one CU (fwd 37 us, bwd 83 us inside the step).  Here GS workgroups share a pathway by INDEX RANGES that
+// need no reduction across workgroups: forward = GR = 256 / GS rows of the second layer each (the small first layer is recomputed by
+// all of them); backward = rows [GR s, GR s + GR) of dW2 / db2 and COLUMNS [GR s, ...) of W2^T da2, hence of da1, db1 and the rows of dW1.
+constexpr int GS = 8, GR = GL / GS;      // 8 workgroups x 32 rows / columns
+
+template <int P>
+__global__ __launch_bounds__(GL) void gene_snn_fwd_split_kernel(GeneArgs a) {
+  __shared__ float Ws[GL][GC + 1];
+  __shared__ float xs[P][GL];
+  const int i = blockIdx.x / GS, sp = blockIdx.x % GS, j = threadIdx.x;
+  const int n = a.sizes[i];
+  const long* o = a.offs + 4L * i;
+  const float* g = a.genes + a.goff[i];
+  float acc = a.params[o[1] + j];
+  for (int p0 = 0; p0 < n; p0 += GL) {        // first layer, as gene_snn_fwd_kernel
+    const int pn = min(GL, n - p0);
+    __syncthreads();
+    if (j < pn) xs[0][j] = g[p0 + j];
+    __syncthreads();
+    for (int k0 = 0; k0 < pn; k0 += GC) {
+      const int kc = min(GC, pn - k0);
+      __syncthreads();
+      for (int t = j; t < GL * GC; t += GL) {
+        const int r = t / GC, c = t - r * GC;
+        Ws[r][c] = c < kc ? a.params[o[0] + (long)r * n + p0 + k0 + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int c = 0; c < GC; ++c) acc = fmaf(Ws[j][c], (k0 + c < pn) ? xs[0][k0 + c] : 0.f, acc);
+    }
+  }
+  if (sp == 0) a.a1[(long)i * GL + j] = acc;
+  __syncthreads();
+  const bool ad = a.adrop.active() && a.adrop.p > 0.f;
+  const AlphaAff af = alpha_affine(a.adrop.p);
+  const float e1 = elu(acc);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    float h1 = e1;
+    if (ad) h1 = fmaf(af.a, drop_keep1(a.adrop, a.adrop.site, ((uint64_t)i * P + p) * GL + j) ? h1 : ALPHA_P, af.b);
+    xs[p][j] = h1;
+  }
+  __syncthreads();
+  // second layer, rows [GR sp, GR sp + GR): the rows are staged in LDS by all threads (8 per row: a wave reads 8 rows x 1 KB,
+  // contiguous), then ONE thread per row runs the k = 0 .. 255 chain in the order of gene_snn_fwd_kernel (bias first, k ascending):
+  // the two kernels give the same bits, so a model does not change with the number of pathways it is grouped into
+  float (*Wl)[GL + 1] = reinterpret_cast<float (*)[GL + 1]>(&Ws[0][0]);      // [GR][GL + 1] in the chunk buffer (8 224 of its 8 448 floats)
+  {
+    const int r = j >> 3, part = j & 7;
+    const float* wr = a.params + o[2] + (long)(GR * sp + r) * GL + part * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Wl[r][part * 32 + c + e] = w4[e];
+    }
+  }
+  __syncthreads();
+  if (j < GR) {
+    const int r = GR * sp + j;
+    float a2[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) a2[p] = a.params[o[3] + r];
+#pragma unroll 8
+    for (int k = 0; k < GL; ++k) {
+      const float w = Wl[j][k];
+#pragma unroll
+      for (int p = 0; p < P; ++p) a2[p] = fmaf(w, xs[p][k], a2[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const long e = ((long)i * P + p) * GL + r;
+      a.a2[e] = a2[p];
+      float zz = elu(a2[p]);
+      if (ad) zz = fmaf(af.a, drop_keep1(a.adrop, a.adrop.site + 1, (uint64_t)e) ? zz : ALPHA_P, af.b);
+      a.z[e] = zz;
+    }
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(GL) void gene_snn_bwd_split_kernel(GeneArgs a) {
+  __shared__ float da2s[P][GL], h1s[P][GL], Wc[GL][GR + 1], da1s[GR];
+  const int i = blockIdx.x / GS, sp = blockIdx.x % GS, j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const int n = a.sizes[i];
+  const long* o = a.offs + 4L * i;
+  const float pre1 = a.a1[(long)i * GL + j];
+  const bool ad = a.adrop.active() && a.adrop.p > 0.f;
+  const AlphaAff af = alpha_affine(a.adrop.p);
+  float db2 = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const long e = ((long)i * P + p) * GL + j;
+    const float pre2 = a.a2[e];
+    const bool keep1 = !ad || drop_keep1(a.adrop, a.adrop.site, (uint64_t)e);
+    const bool keep2 = !ad || drop_keep1(a.adrop, a.adrop.site + 1, (uint64_t)e);
+    const float g2 = ad ? (keep2 ? af.a : 0.f) : 1.f;
+    const float da2 = a.dz[e] * g2 * elu_grad(pre2);
+    da2s[p][j] = da2;
+    h1s[p][j] = ad ? fmaf(af.a, keep1 ? elu(pre1) : ALPHA_P, af.b) : elu(pre1);
+    db2 += da2;
+  }
+  if (j / GR == sp) a.grads[o[3] + j] += db2;
+  __syncthreads();
+  // dW2 rows [GR sp, GR sp + GR): one wave per row, 16-byte accesses
+  for (int r = GR * sp + wave; r < GR * sp + GR; r += 4) {
+    float* dst = a.grads + o[2] + (long)r * GL + lane * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float d = da2s[p][r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(d, h1s[p][lane * 4 + e], v[e]);
+    }
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+  // dh1_p[k] = sum_r W2[r][k] da2_p[r] for the columns k in [GR sp, GR sp + GR): the 256 x GR block of W2 is staged in LDS (each
+  // row's 128 bytes by 8 threads), then one thread per column runs r = 0 .. 255 in the order of gene_snn_bwd_kernel (same bits)
+  {
+    const int part = j & 7;
+    for (int r = j >> 3; r < GL; r += GL / 8) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.params + o[2] + (long)r * GL + GR * sp + part * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Wc[r][part * 4 + e] = w4[e];
+    }
+  }
+  __syncthreads();
+  if (j < GR) {
+    const int k = GR * sp + j;
+    float dh1[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) dh1[p] = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < GL; ++r) {
+      const float w = Wc[r][j];
+#pragma unroll
+      for (int p = 0; p < P; ++p) dh1[p] = fmaf(w, da2s[p][r], dh1[p]);
+    }
+    const float prek = a.a1[(long)i * GL + k];
+    float da1 = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const bool keep1 = !ad || drop_keep1(a.adrop, a.adrop.site, (uint64_t)(((long)i * P + p) * GL + k));
+      da1 += dh1[p] * (ad ? (keep1 ? af.a : 0.f) : 1.f);
+    }
+    da1 *= elu_grad(prek);
+    a.grads[o[1] + k] += da1;
+    da1s[j] = da1;
+  }
+  __syncthreads();
+  // dW1 rows [GR sp, GR sp + GR): dW1[r][c] += da1[r] g[c]
+  const float* g = a.genes + a.goff[i];
+  for (long t = j; t < (long)GR * n; t += GL) {
+    const int r = (int)(t / n), c = (int)(t - (long)r * n);
+    a.grads[o[0] + ((long)GR * sp + r) * n + c] += da1s[r] * g[c];
+  }
+}
+
+// below this many pathways a pathway is shared by GS workgroups (a workgroup per pathway fills the chip from a few hundred on)
+#ifndef MT_GENE_SPLIT_BELOW
+#define MT_GENE_SPLIT_BELOW 64
+#endif
+constexpr int GENE_SPLIT_BELOW = MT_GENE_SPLIT_BELOW;
+
 }  // namespace
 
 extern "C" int mt_gene_snn_fwd(const float* params, const long* offs, const int* sizes, const long* goff, const float* genes,
@@ -193,6 +358,16 @@ extern "C" int mt_gene_snn_fwd(const float* params, const long* offs, const int*
   if (latent != GL || passes > GP_MAX) return MT_ERR_UNSUPPORTED;
   GeneArgs a{params, nullptr, offs, sizes, goff, genes, a1, a2, z, nullptr, make_drop(alpha_drop), G, passes};
   hipStream_t s = (hipStream_t)stream;
+  if (G < GENE_SPLIT_BELOW) {
+    switch (passes) {
+      case 1: hipLaunchKernelGGL(gene_snn_fwd_split_kernel<1>, dim3(G * GS), dim3(GL), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(gene_snn_fwd_split_kernel<2>, dim3(G * GS), dim3(GL), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(gene_snn_fwd_split_kernel<3>, dim3(G * GS), dim3(GL), 0, s, a); break;
+      default: hipLaunchKernelGGL(gene_snn_fwd_split_kernel<4>, dim3(G * GS), dim3(GL), 0, s, a); break;
+    }
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+  }
   switch (passes) {
     case 1: hipLaunchKernelGGL(gene_snn_fwd_kernel<1>, dim3(G), dim3(GL), 0, s, a); break;
     case 2: hipLaunchKernelGGL(gene_snn_fwd_kernel<2>, dim3(G), dim3(GL), 0, s, a); break;
@@ -211,6 +386,16 @@ extern "C" int mt_gene_snn_bwd(const float* params, float* grads, const long* of
   GeneArgs a{params, grads, offs, sizes, goff, genes, const_cast<float*>(a1), const_cast<float*>(a2), nullptr, dz,
              make_drop(alpha_drop), G, passes};
   hipStream_t s = (hipStream_t)stream;
+  if (G < GENE_SPLIT_BELOW) {
+    switch (passes) {
+      case 1: hipLaunchKernelGGL(gene_snn_bwd_split_kernel<1>, dim3(G * GS), dim3(GL), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(gene_snn_bwd_split_kernel<2>, dim3(G * GS), dim3(GL), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(gene_snn_bwd_split_kernel<3>, dim3(G * GS), dim3(GL), 0, s, a); break;
+      default: hipLaunchKernelGGL(gene_snn_bwd_split_kernel<4>, dim3(G * GS), dim3(GL), 0, s, a); break;
+    }
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+  }
   switch (passes) {
     case 1: hipLaunchKernelGGL(gene_snn_bwd_kernel<1>, dim3(G), dim3(GL), 0, s, a); break;
     case 2: hipLaunchKernelGGL(gene_snn_bwd_kernel<2>, dim3(G), dim3(GL), 0, s, a); break;

@@ -799,9 +799,10 @@ def test_elementwise(ops):
 
 
 # ------------------------------------------------------------------------------------------ grouped pathway networks
-@pytest.mark.parametrize("sizes", [[1, 5, 199, 33, 64, 300, 7], [9] * 40])
+@pytest.mark.parametrize("sizes", [[1, 5, 199, 33, 64, 300, 7], [9] * 40, [5] * 70 + [130, 1]])
 def test_gene_snn_grouped(ops, sizes):
-    """All pathway networks in one launch vs per-pathway torch (gene_encoder.py:97-131): forward and weight grads."""
+    """All pathway networks in one launch vs per-pathway torch (gene_encoder.py:97-131): forward and weight grads.
+    Fewer than 64 pathways run the kernels that share a pathway among 8 workgroups, more the workgroup-per-pathway ones."""
     g = rng(len(sizes))
     G, Lt = len(sizes), 256
     offs, pieces, cur = [], [], 0
@@ -958,10 +959,12 @@ def test_dropout_masks_statistics_determinism_and_consistency(ops):
         assert rel(st2[:, 1], 1.0 / torch.sqrt(href.double().var(-1, unbiased=False) + 1e-5)) < 1e-5
 
 
-def test_gene_snn_alpha_dropout(ops):
+@pytest.mark.parametrize("G", [40, 72])
+def test_gene_snn_alpha_dropout(ops, G):
     """nn.AlphaDropout(p) after the pathway ELUs: dropped units take the constant a * alpha' + b, kept ones a * elu + b;
-    the backward regenerates the same masks (gradient of a kept unit = a * upstream, of a dropped one = 0)."""
-    G, Lt, n = 40, 256, 9
+    the backward regenerates the same masks (gradient of a kept unit = a * upstream, of a dropped one = 0).
+    (G = 40: the shared-pathway kernels; 72: a workgroup per pathway.)"""
+    Lt, n = 256, 9
     gen = _rng(11)
     sizes = [n] * G
     W1 = torch.randn(G, Lt, n, generator=gen) * 0.3
