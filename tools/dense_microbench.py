@@ -33,3 +33,22 @@ for name, ph in (("delta", ops.DENSE_BWD_DELTA), ("kv", ops.DENSE_BWD_KV), ("q",
     out[name] = t(lambda: ops._dense_attn_bwd_phase(qkv, o, d_o, lse, plan, delta, dqkv, ph))
 fl = 4.0 * N * N * D * B
 print(" ".join(f"{k} {v:.4f}" for k, v in out.items()), "| TF/s fwd %.0f kv %.0f q %.0f" % (fl / out["fwd"] / 1e9, 2 * fl / out["kv"] / 1e9, 1.5 * fl / out["q"] / 1e9))
+
+# dK/dV and dQ are independent given delta: one after the other on one stream vs side by side on two streams (do the tail rounds of one
+# launch fill with the other's workgroups?)
+if os.environ.get("MT_DENSE_OVERLAP"):
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def seq():
+        ops._dense_attn_bwd_phase(qkv, o, d_o, lse, plan, delta, dqkv, ops.DENSE_BWD_KV)
+        ops._dense_attn_bwd_phase(qkv, o, d_o, lse, plan, delta, dqkv, ops.DENSE_BWD_Q)
+
+    def par():
+        cur = torch.cuda.current_stream()
+        s1.wait_stream(cur); s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            ops._dense_attn_bwd_phase(qkv, o, d_o, lse, plan, delta, dqkv, ops.DENSE_BWD_KV)
+        with torch.cuda.stream(s2):
+            ops._dense_attn_bwd_phase(qkv, o, d_o, lse, plan, delta, dqkv, ops.DENSE_BWD_Q)
+        cur.wait_stream(s1); cur.wait_stream(s2)
+    print("kv then q: %.4f ms   kv || q: %.4f ms" % (t(seq), t(par)))
