@@ -12,7 +12,8 @@ python bench.py --no-cpu-baseline --no-legs --eager > $out/bench_eager.json 2>/d
 export MT_SPLIT_PASSES=0
 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-legs > $out/stats.log 2>&1
 unset MT_SPLIT_PASSES
-# ... and of the default command (task passes as two concurrent groups: kernels of the groups overlap, durations are not per-kernel costs)
+# ... and of the default command (task passes as two groups: under the profiler the two graph branches run one after the other,
+# so this prices the groups' smaller launches, not their overlap)
 rocprofv3 --kernel-trace --stats -d $out/stats_groups -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-legs > $out/stats_groups.log 2>&1
 find $out/stats_groups -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_pass_groups.csv \;
 bash tools/pmc.sh ${tag}_fwd tools/fwd_microbench.py
