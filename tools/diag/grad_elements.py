@@ -1,8 +1,13 @@
+"""Which ELEMENTS of a gradient tensor carry its deviation from the fp64 golden: python tools/diag/grad_elements.py
+Runs the golden step of fixture L37_d3_clin_cat and prints, for the Extractor FFN's linear1 tensors, the relative L2 error, the six largest
+element deviations (index, |diff|, reference, ours) and the share of the squared error in the largest one.  (A single ReLU gate of the
+Extractor FFN decided the other way shows as ~100 % of the error in ONE hidden unit: tools/experiments/README.md.)"""
 import os, sys, json, numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_model_gpu as T
 name = "L37_d3_clin_cat"
-gd = os.path.join("/root/repo/tests/golden")
+gd = os.path.join(ROOT, "tests", "golden")
 g, cfg, eng, ts, inp = T._build(os.path.join(gd, f"model_{name}.npz"))
 x = torch.from_numpy(inp["x"]).cuda(); genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
 clin = torch.from_numpy(inp["clinical"]).cuda() if cfg.clinical else None
