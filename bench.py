@@ -782,6 +782,9 @@ def main():
             "graph_replays": replays, "eager_steps": eager_steps, "comm": comm, "token_side_in_graph": token_graph,
             "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]},
         }
+        from modaltune_amd import _lib
+        bi = _lib.build_info()       # which binary this line timed: the sha256 of (csrc/*, include/*, flags) it was built from
+        out["build_id"], out["build_id_matches_tree"], out["lib"] = bi["build_id"], bi["build_id_matches_tree"], bi["lib"]
         default_line = world == 1 and not (args.ragged or args.eager)
         if default_line and not args.no_legs:
             # secondary configurations as short sub-records of the SAME driver-observed line (each <= ~10 s; never the headline)

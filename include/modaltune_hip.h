@@ -39,6 +39,9 @@ typedef struct { int seg_rows, seg_stride, row0; } MtRowMap;
 
 int mt_version(void);
 const char* mt_status_string(int status);
+/* Build provenance: sha256 (hex) over the kernel sources, this header and the compiler flags the library was built from
+ * (modaltune_amd/_build_id.py: tree_build_id); `build()` rebuilds when it differs from the tree's. */
+const char* mt_build_id(void);
 
 /* ---------------------------------------------------------------- GEMMs ---------------------------- */
 enum { MT_EPI_BIAS = 0,        /* C = acc + bias                                   (nn.Linear)            */

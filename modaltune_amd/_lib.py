@@ -82,6 +82,7 @@ DP = C.POINTER(MtDensePlan)
 SIGNATURES = {
     "mt_version": [],
     "mt_status_string": [I],
+    "mt_build_id": [],
     "mt_gemm_nt_f16": [P, L, RM, P, I, I, I, I, EP, P, L, RM, I, P],
     "mt_gemm_tn_f16": [P, L, RM, P, L, RM, I, I, I, P, L, P, P],
     "mt_colsum_f16": [P, L, RM, I, I, P, P],
@@ -148,7 +149,7 @@ SIGNATURES = {
     "mt_scatter_rows_f32": [P, P, P, P, I, I, I, P],
     "mt_row_absmax_f32": [P, P, I, I, P],
 }
-_RESTYPE = {"mt_status_string": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long, "mt_pool_attn_workspace_floats": C.c_long,
+_RESTYPE = {"mt_status_string": C.c_char_p, "mt_build_id": C.c_char_p, "mt_dilated_attn_bwd_workspace_bytes": C.c_long, "mt_pool_attn_workspace_floats": C.c_long,
              "mt_alibi_dist_halves": C.c_long}
 
 _lib = None
@@ -171,6 +172,17 @@ def load():
         fn.restype = _RESTYPE.get(name, I)
     _lib = lib
     return lib
+
+
+def build_info() -> dict:
+    """{"build_id": what the LOADED binary was built from, "build_id_matches_tree": whether that is the tree next to it}."""
+    from ._build_id import tree_build_id
+    bid = load().mt_build_id().decode()
+    try:
+        ok = bid == tree_build_id()
+    except Exception:      # (sources not shipped next to the binary)
+        ok = None
+    return {"build_id": bid, "build_id_matches_tree": ok, "lib": os.path.relpath(LIB_PATH, os.path.dirname(_HERE))}
 
 
 def check(status: int, what: str = ""):

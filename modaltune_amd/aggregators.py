@@ -253,6 +253,8 @@ class LongNetGeneAdapter(Aggregator):
         """model.train() leaves Dropout / DropPath active in the reference (frozen != eval); eval() and
         no_grad forwards run without them.  Set the config's dropout / drop_path_rate to 0 for parity comparisons."""
         super().train(mode)
+        if getattr(self, "_ns_pending", None):
+            self._drain_decodes(block=True)      # a mode switch ends a loop: every deferred task-token check has to have been seen
         if hasattr(self, "engine"):
             self.engine.stochastic = bool(mode) and (self.cfg.dropout > 0 or self.cfg.drop_path_rate > 0)
         return self
@@ -264,6 +266,8 @@ class LongNetGeneAdapter(Aggregator):
 
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         out = destination if destination is not None else OrderedDict()
+        if getattr(self, "_ns_pending", None):
+            self._drain_decodes(block=True)      # (checkpointing: raise for a mis-served task token before the weights are written)
         for k, p in self._params.items():
             out[prefix + k] = p if keep_vars else p.detach()
         return out
@@ -344,8 +348,10 @@ class LongNetGeneAdapter(Aggregator):
         rows and each call takes its row by a DEVICE-side index (`_serve_nosync`) -- a host sync in front of every call would
         otherwise drain the queue three times per step and leave the GPU waiting for the host at the start of the forward and
         of the backward (round 5: 2 ms per step at L = 10 000).  The one-hots are still copied back, asynchronously, and checked
-        when they have arrived (`_drain_decodes`): a task id outside the learnt rows raises there (one or two calls late, never
-        silently); a pattern that merely shrank or changed order sends the module back to learning."""
+        when they have arrived (`_drain_decodes`; `train()` / `eval()` / `state_dict()` wait for the outstanding ones): a task id
+        outside the learnt rows raises there (one or two calls late) and the call itself returns NaN logits (a device-side validity
+        flag: never silently wrong, not even for the last call of a loop); a pattern that merely shrank or changed order sends the
+        module back to learning."""
         genes = self._gene_list(genes)
         if not self.speculate:
             return self.forward_tasks(x, coords, genes, onehot, clinical=clinical)
@@ -422,8 +428,13 @@ class LongNetGeneAdapter(Aggregator):
             done = torch.cuda.Event()
             done.record()
         self._ns_pending.append((done, pin, oh, rows, sp["slide"]))
-        idx = (oh[self._ns_eye[2]] == 1).to(torch.int64).argmax().reshape(1)       # position of this call's task id among `rows`
-        return sp["logits"].index_select(0, idx)
+        # position of this call's task id among `rows` -- and a device-side validity flag: a token that is not a one-hot of a learnt
+        # row would otherwise be answered with rows[0]'s logits until the deferred check lands (which the LAST call of a loop never
+        # sees): such a call returns NaN logits at once (0.0 added to the picked row otherwise: exact)
+        m, idx = oh[self._ns_eye[2]].to(F32).max(dim=0)
+        valid = (m == 1) & (torch.linalg.vector_norm(oh.to(F32), 1) == 1)
+        poison = torch.where(valid, 0.0, float("nan"))
+        return sp["logits"].index_select(0, idx.reshape(1)) + poison
 
     def _drain_decodes(self, block: bool = False):
         """Consume the one-hots whose asynchronous read-back has completed (never blocks unless asked to): validate the calls they

@@ -58,15 +58,18 @@ __global__ __launch_bounds__(256) void distill_loss_kernel(const float* __restri
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                             float lr, float b1, float b2, float omb1, float omb2, float eps, float wd, float decay, float bc1, float bc2s,
-                             float grad_mult, const float* __restrict__ scale, const int* __restrict__ found_inf,
+                             float lr, float b1, float b2, float omb1, float omb2, float eps, double wd, float decay, float bc1, float bc2s,
+                             double b1d, double b2d, float grad_mult, const float* __restrict__ scale, const int* __restrict__ found_inf,
                              const int* __restrict__ step_dev, const float* __restrict__ lr_dev) {
   if (found_inf && *found_inf) return;       // GradScaler.step: skip the whole update when a grad is inf/nan
-  if (lr_dev) { lr = *lr_dev; decay = 1.0f - lr * wd; }   // the schedule's current learning rate lives on the device (graph replays read it)
+  // the schedule's current learning rate lives on the device (graph replays read it); 1 - lr * wd in double, as torch forms it
+  if (lr_dev) { lr = *lr_dev; decay = (float)(1.0 - (double)lr * wd); }
   if (step_dev) {                            // optimiser step count lives on the device (skipped steps do not count)
-    const float st = (float)(*step_dev + 1);
-    bc1 = 1.0f - powf(b1, st);
-    bc2s = sqrtf(1.0f - powf(b2, st));
+    // bias corrections in DOUBLE, as torch's Python arithmetic forms them (1 - beta ** step): powf in fp32 is ~1e-5 off in the first
+    // steps, where 1 - beta2 ** step is itself ~1e-3 (two pows per thread against >= 32 elements of 28 bytes each: not measurable)
+    const double st = (double)(*step_dev + 1);
+    bc1 = (float)(1.0 - pow(b1d, st));
+    bc2s = (float)sqrt(1.0 - pow(b2d, st));
   }
   const float inv_scale = grad_mult * (scale ? 1.0f / *scale : 1.0f);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -237,8 +240,8 @@ extern "C" int mt_adamw_step(float* p, const float* g, float* m, float* v, long 
   const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step_count));
   const int grid = (int)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)beta1, (float)beta2,
-                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(1.0 - lr * weight_decay), bc1, bc2s,
-                     grad_mult, scale, (const int*)found_inf, step_dev, lr_dev);
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, weight_decay, (float)(1.0 - lr * weight_decay), bc1, bc2s,
+                     beta1, beta2, grad_mult, scale, (const int*)found_inf, step_dev, lr_dev);
   MT_CHECK_LAUNCH();
   return MT_OK;
 }

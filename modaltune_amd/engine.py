@@ -163,8 +163,8 @@ class Engine:
         self.pos_table = torch.from_numpy(sincos_1d_table(cfg.slide_ngrids, cfg.embed_dim // 2)).to(self.device)
         self._frozen16: Dict[str, _W16] = {}
         self._train16: Dict[str, _W16] = {}
-        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}          # (B, L) -> views of the flat storage
-        self._ws_store: Dict[int, dict] = {}                          # B -> {cap, flat buffers}
+        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}          # (B, L, slot) -> views of the flat storage
+        self._ws_store: Dict[tuple, dict] = {}                        # (B, slot) -> {cap, flat buffers}
         self._caches_ready = False
         # Bumped whenever storage that a captured hipGraph may point to is replaced (workspace growth, rebuilt fp16 weight
         # caches, the stochastic toggle's extra buffer): graph owners (TrainStep, EmbeddingExtractor) key their captures on it.
@@ -320,12 +320,13 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, B: int, L: int, fresh: bool = False) -> Dict[str, torch.Tensor]:
+    def _workspace(self, B: int, L: int, fresh: bool = False, slot: int = 0) -> Dict[str, torch.Tensor]:
         """Activation / gradient buffers of one (B, L) geometry.  Bags are ragged (one slide per step, any L): the
         storage is ONE set of flat buffers sized for the largest bag seen so far (grown by >= 25 % when a bigger one
         arrives) and each geometry gets views of their heads -- no allocator traffic per step, no growth with the number
-        of distinct lengths.  fresh=True (module API: several forwards alive at once) allocates privately."""
-        key = (B, L)
+        of distinct lengths.  fresh=True (module API: several forwards alive at once) allocates privately.
+        slot: concurrent users of the SAME B (TrainStep's pass groups when both hold one pass) get storage of their own."""
+        key = (B, L, slot)
         if not fresh and key in self._ws:
             return self._ws[key]
         dev = self.device
@@ -363,14 +364,14 @@ class Engine:
             w = {k: store["flat"][k][:numel(shape)].view(shape) for k, (dt, shape) in want.items()}
             w["_lease"] = _Lease(pool, store)
             return w
-        store = self._ws_store.get(B)
+        store = self._ws_store.get((B, slot))
         if store is None or L > store["cap"] or (self.stochastic and "x0d" not in store["flat"]):
             cap = L if store is None else max(L, store["cap"] + store["cap"] // 4)
-            self._ws_store.pop(B, None)
+            self._ws_store.pop((B, slot), None)
             self._ws.clear()              # views of the old storage die with it
             self.generation += 1          # ... and so do the graphs captured on them
             store = {"cap": cap, "flat": {k: torch.empty(numel(shape), dtype=dt, device=dev) for k, (dt, shape) in spec(cap).items()}}
-            self._ws_store[B] = store
+            self._ws_store[(B, slot)] = store
         if len(self._ws) > 64:
             self._ws.clear()
         w = {k: store["flat"][k][:numel(shape)].view(shape) for k, (dt, shape) in spec(L).items()}
@@ -413,7 +414,7 @@ class Engine:
     def forward(self, x: torch.Tensor, coords, genes: Sequence[torch.Tensor], task_onehots: torch.Tensor,
                 need_grad: bool = True, fresh: bool = False, staged: bool = False, geometry=None,
                 clinical: Optional[torch.Tensor] = None, share: Optional[dict] = None, tape: Optional[Tape] = None,
-                site_group: int = 0) -> torch.Tensor:
+                site_group: int = 0, ws_slot: int = 0) -> torch.Tensor:
         """x [L, in_chans] (or [1,L,in]); coords [L,2] (host or device); genes: list of [1, n_i]; task_onehots [B, num_tasks].
         Returns logits [B, output_dim] (fp32, device).  fresh=True gives this call its own tape and workspace so that
         several forwards can precede one backward (the reference calls the model 3x before loss.backward(), TM:175-177);
@@ -435,7 +436,7 @@ class Engine:
             B = task_onehots.shape[0]
         N, D, Fd, E, T = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim, self.T
         M, Mp = B * N, B * L
-        ws = self._workspace(B, L, fresh=fresh)
+        ws = self._workspace(B, L, fresh=fresh, slot=ws_slot)
         # fresh: this call owns its tape (several forwards alive at once); the engine's long-lived tape -- whose gradient
         # arena captured graphs point into -- is put back before returning
         # (tape=: a long-lived tape of the caller's -- TrainStep runs the task passes of a step as two concurrent groups, each with

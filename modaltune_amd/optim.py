@@ -8,7 +8,8 @@ same layout, so the whole update is one `mt_adamw_step` launch (csrc/optim.hip) 
 
     from modaltune_amd.optim import AdamW          # instead of torch.optim.AdamW; same constructor, same state_dict
     opt = AdamW(params, lr=..., weight_decay=..., betas=...)
-    scaler.step(opt)                                # GradScaler hands over `grad_scale` / `found_inf` (no unscale pass, no read-back)
+    scaler.step(opt)                                # GradScaler hands over `grad_scale` / `found_inf`: no unscale (division) pass and
+                                                    # no read-back; its inf check over the gradients (_check_inf_per_device) still runs
 
 It IS a `torch.optim.AdamW` (schedulers, `state_dict()`, `zero_grad()`, param groups behave as before).  Gradients that are not
 views of one flat buffer (autograd cloned them, a DDP reducer owns them) are gathered by one multi-tensor copy first; whenever the
@@ -37,6 +38,14 @@ class AdamW(torch.optim.AdamW):
         self._host_steps = 0          # fused steps taken so far (the per-parameter `step` entries are brought up to date lazily)
         self._steps_dirty = False
         self.last_step_fused: Optional[bool] = None
+
+    def add_param_group(self, param_group):
+        """A new group changes the parameter set the flat views (moments, gathered-gradient views) were built for: rebind at the next step
+        (moments already accumulated are carried over through the per-parameter state, see _bind_flat)."""
+        if getattr(self, "_flat", None) is not None:
+            self._sync_steps()                # (the step counts of the parameters bound so far, before the set changes)
+        super().add_param_group(param_group)
+        self._flat, self._flat_failed = None, False
 
     # ------------------------------------------------------------------ the flat view of the parameters
     def _all_params(self) -> List[torch.Tensor]:
@@ -83,7 +92,8 @@ class AdamW(torch.optim.AdamW):
             s.setdefault("step", torch.tensor(0.0, dtype=torch.float32))
         flat_p = torch.empty(0, dtype=torch.float32, device=dev).set_(st, (lo - base) // 4, (n,), (1,))
         step_dev = torch.full((1,), self._host_steps, dtype=torch.int32, device=dev)
-        return {"lo": lo, "n": n, "p": flat_p, "m": m, "v": v, "step_dev": step_dev, "gbuf": None, "gviews": None}
+        return {"lo": lo, "n": n, "p": flat_p, "m": m, "v": v, "step_dev": step_dev, "gbuf": None, "gviews": None,
+                "ids": tuple(id(p) for p in ps)}
 
     def _gathered_grad(self, fl) -> Optional[torch.Tensor]:
         """Gradients that exist for every parameter but live in their own allocations (autograd clones them when several nodes feed
@@ -147,6 +157,9 @@ class AdamW(torch.optim.AdamW):
         grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
         fl = None
         if not self._flat_failed and self._uniform_groups():
+            if self._flat is not None and self._flat["ids"] != tuple(id(p) for p in self._all_params()):
+                self._sync_steps()            # param_groups were edited in place: the cached views describe another parameter set
+                self._flat = None
             if self._flat is None:
                 self._flat = self._bind_flat()
                 self._flat_failed = self._flat is None

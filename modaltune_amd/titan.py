@@ -607,12 +607,18 @@ class NativeBackbone:
         if not self.alibi:
             return ops.make_dense_plan(N, B, self.H), ()
         need = 2 * ops.alibi_dist_halves(N)          # the table is O(N^2): 34 MB at N = 4097, 0.8 GB at 20 k, 4.3 GB at 46 k tokens
-        free = torch.cuda.mem_get_info(self.dev)[0] if self.dev.type == "cuda" else need
-        if need > self.alibi_table_budget_bytes or need > free:
+        # static budget first (the only check inside a captured region); then the allocation itself decides -- the driver's "free"
+        # figure does not count blocks the caching allocator holds (the previous slide's table among them), so a slide that fits
+        # would be refused after a few ragged ones
+        if need > self.alibi_table_budget_bytes:
             raise ValueError(f"TITAN slide with {N - 1} foreground cells: the ALiBi distance table needs {need / 2**30:.2f} GiB of fp16 "
-                             f"(2 N^2 bytes; budget `backbone.alibi_table_budget_bytes` = {self.alibi_table_budget_bytes / 2**30:.1f} GiB, "
-                             f"free device memory {free / 2**30:.1f} GiB): subsample the slide or raise the budget")
-        dist = torch.empty(ops.alibi_dist_halves(N), dtype=H16, device=self.dev)
+                             f"(2 N^2 bytes; budget `backbone.alibi_table_budget_bytes` = {self.alibi_table_budget_bytes / 2**30:.1f} GiB): "
+                             "subsample the slide or raise the budget")
+        try:
+            dist = torch.empty(ops.alibi_dist_halves(N), dtype=H16, device=self.dev)
+        except torch.OutOfMemoryError as e:
+            raise ValueError(f"TITAN slide with {N - 1} foreground cells: the ALiBi distance table needs {need / 2**30:.2f} GiB of fp16 "
+                             f"(2 N^2 bytes) and the device has no room for it: subsample the slide") from e
         ops.alibi_dist(cells.contiguous(), N, dist)
         return ops.make_dense_plan(N, B, self.H, dist, self.nslope), (dist,)
 
@@ -756,7 +762,7 @@ class TitanEngine(Engine):
 
     def forward_slide(self, x, coords, genes, task_onehots, patch_size_lv0: int = 1024, need_grad: bool = True, fresh: bool = False,
                       clinical=None, share: Optional[dict] = None, staged: bool = False, tape=None, site_group: int = 0,
-                      prologue_only: bool = False) -> Optional[torch.Tensor]:
+                      prologue_only: bool = False, ws_slot: int = 0) -> Optional[torch.Tensor]:
         """x [1, L, C] tile embeddings, coords [1, L, 2] level-0 pixels (TA:329-353) -> logits [B, output_dim].
         share: see Engine.forward -- here the whole task-independent prologue (gridding, embedding, the ALiBi distance table) is
         reused by the later calls of one slide; a call with another pass count builds its plan on the shared table.
@@ -809,7 +815,7 @@ class TitanEngine(Engine):
         if prologue_only:
             return None
         return self.forward(patches, None, genes, task_onehots, need_grad=need_grad, fresh=fresh, clinical=clinical, share=share,
-                            tape=tape, site_group=site_group)
+                            tape=tape, site_group=site_group, ws_slot=ws_slot)
 
     # -- image-side hooks
     def _embed_patches(self, x, coords, ws, staged, L):

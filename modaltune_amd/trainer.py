@@ -97,7 +97,11 @@ class TrainStep:
         B = int(self.onehots.shape[0])
         self.split_passes = bool(split_passes) and B >= 2 and os.environ.get("MT_SPLIT_PASSES", "1") not in ("0", "off")
         self._groups = [(0, B - B // 3 if B >= 3 else 1), (B - B // 3 if B >= 3 else 1, B)] if B >= 2 else [(0, B)]
+        # workspace slot per group: the engine keys its workspace storage on the pass count, so groups of EQUAL size (B = 2: one pass
+        # each) must not share it -- they run concurrently on two streams
+        self._group_slots = [sum(1 for (a2, b2) in self._groups[:gi] if b2 - a2 == b - a) for gi, (a, b) in enumerate(self._groups)]
         self._pass_streams = self._grad_sets = self._group_tapes = self._loss_parts = None
+        self._group_hook = None             # tests: called on the host after each group has been enqueued (throttles the interleaving)
         # same-box, hipGraph replay, ms per step batched -> split: L = 16 000: 69.5 -> 67.6; 12 000: 51.4 -> 50.6; 10 000: 41.8 -> 40.5;
         # 9 000: 37.7 -> 36.5; 8 000: 33.7 -> 32.9; 6 500: 26.6 -> 27.4 (!); 4 096: 18.2 -> 18.1; 2 500: 12.1 -> 12.2; 1 024: 8.2 -> 8.1
         self.split_min_patches = 7500
@@ -202,8 +206,8 @@ class TrainStep:
                               staged=staged_geometry is not None, share=share, prologue_only=True)
             share["x0"] = share["tok"][1:]
             L = int(share["tok"].shape[0]) - 1
-            for nb in gB:
-                eng._workspace(nb, L)
+            for nb, sl in zip(gB, self._group_slots):
+                eng._workspace(nb, L, slot=sl)
         else:
             if staged_geometry is None:
                 x = x.reshape(-1, x.shape[-1])
@@ -213,8 +217,8 @@ class TrainStep:
             else:
                 L = staged_geometry[1]
                 ws0 = eng._workspace(gB[0], L)         # (step_graphed staged the slide into the first group's workspace)
-            for nb in gB[1:]:
-                eng._workspace(nb, L)                   # (grown before the fork: a growth bumps the generation)
+            for nb, sl in list(zip(gB, self._group_slots))[1:]:
+                eng._workspace(nb, L, slot=sl)          # (grown before the fork: a growth bumps the generation)
             eng._embed_patches(None, None, ws0, True, L)        # task-independent: once, in front of the fork
             share = {"x0": ws0["x0"]}
         R, O = target.shape
@@ -232,10 +236,12 @@ class TrainStep:
                         self._grad_sets[gi][0].zero_()
                         if titan:
                             logits = eng.forward_slide(None, None, genes, self.onehots[a:b], patch_size_lv0=self.patch_size_lv0, need_grad=True,
-                                                       clinical=clinical, share=share, staged=True, tape=self._group_tapes[gi], site_group=gi + 1)
+                                                       clinical=clinical, share=share, staged=True, tape=self._group_tapes[gi], site_group=gi + 1,
+                                                       ws_slot=self._group_slots[gi])
                         else:
                             logits = eng.forward(None, None, genes, self.onehots[a:b], need_grad=True, staged=True, geometry=(b - a, L),
-                                                 clinical=clinical, share=share, tape=self._group_tapes[gi], site_group=gi + 1)
+                                                 clinical=clinical, share=share, tape=self._group_tapes[gi], site_group=gi + 1,
+                                                 ws_slot=self._group_slots[gi])
                         call = eng.last_call
                         dlogits = torch.empty_like(logits)
                         ops.distill_loss(logits, target[a:b], self._loss_parts[gi], dlogits, b - a, O, 1.0, self.scale)
@@ -243,6 +249,8 @@ class TrainStep:
                         logits_all[a:b].copy_(logits)
                     finally:
                         eng.store.use_grad_set(*old)
+                if self._group_hook is not None:
+                    self._group_hook(gi)
         finally:
             for st in self._pass_streams:
                 main.wait_stream(st)
@@ -377,13 +385,13 @@ class TrainStep:
             # TITAN configuration: the gridding kernels and the one host read-back (the token count: every shape downstream depends
             # on it) run eagerly; the captured part starts at the token gather and is keyed on (patches, TOKENS).
             Lv = eng.stage_slide(x, coords, self.patch_size_lv0)
-            for nb in ([b - a for a, b in self._groups] if self._split_now(Lv) else [B]):
-                eng._workspace(nb, Lv)            # (may grow the workspace: bumps eng.generation)
+            for nb, sl in (list(zip([b - a for a, b in self._groups], self._group_slots)) if self._split_now(Lv) else [(B, 0)]):
+                eng._workspace(nb, Lv, slot=sl)   # (may grow the workspace: bumps eng.generation)
         else:
             Lv = L
             gB = [b - a for a, b in self._groups] if self._split_now(L) else [B]
-            for nb in gB[1:]:
-                eng._workspace(nb, L)             # (all groups' workspaces exist -- and have grown -- before anything is captured)
+            for nb, sl in list(zip(gB, self._group_slots))[1:]:
+                eng._workspace(nb, L, slot=sl)    # (all groups' workspaces exist -- and have grown -- before anything is captured)
             eng.stage_inputs(x, coords, B=gB[0])  # (may grow the workspace: bumps eng.generation)
         self._wait_params()                       # last step's sharded parameter all-gather ran under the staging above
         self._sgenes.copy_(gflat, non_blocking=True)

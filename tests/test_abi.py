@@ -27,6 +27,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.mt_status_string(-1).decode().startswith("bad argument")
 
 
+def test_build_id_ties_the_binary_to_the_sources(tmp_path):
+    """the library carries the sha256 of (csrc/*, include/*, flags) it was built from; build() compares THAT with the
+    tree (not modification times) and a change to any source changes the id."""
+    import __graft_entry__ as ge
+    from modaltune_amd import _build_id, _lib
+    ge.build()
+    info = _lib.build_info()
+    assert len(info["build_id"]) == 64 and info["build_id_matches_tree"] is True
+    assert info["build_id"] == _build_id.tree_build_id()
+    assert not ge.stale_objects()                             # nothing to rebuild right after a build
+    flags = _build_id.flags_string(ge.FLAGS + ["-DX"], ge.FLAGS_PER_FILE, ge.NO_VGPR_FORM, ge.SOURCES)
+    assert _build_id.tree_build_id(flags) != info["build_id"]      # another flag set: another id
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from modaltune_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
@@ -41,7 +55,7 @@ sys.path.insert(0, %r)
 from modaltune_amd import _lib
 lib = _lib.load()
 for name, sig in _lib.SIGNATURES.items():
-    if name in ("mt_version", "mt_status_string", "mt_pool_attn_workspace_floats", "mt_alibi_dist_halves"):      # (plain value functions)
+    if name in ("mt_version", "mt_status_string", "mt_build_id", "mt_pool_attn_workspace_floats", "mt_alibi_dist_halves"):      # (plain value functions)
         continue
     args = [0 if t in (_lib.I, _lib.L) else 0.0 if t in (_lib.F, _lib.D) else None for t in sig]
     print(name, getattr(lib, name)(*args), flush=True)
@@ -60,6 +74,6 @@ def test_every_launcher_rejects_null_arguments_without_touching_the_device():
     assert p.returncode == 0, p.stdout[-400:] + p.stderr[-400:]
     rows = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("mt_")]
     from modaltune_amd import _lib
-    assert len(rows) == len(_lib.SIGNATURES) - 4
+    assert len(rows) == len(_lib.SIGNATURES) - 5
     wrong = [(n, rc) for n, rc in rows if int(rc) >= 0]
     assert not wrong, wrong

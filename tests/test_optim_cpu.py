@@ -47,3 +47,18 @@ def test_grad_scaler_attributes_are_honoured_by_the_fallback():
     oa.found_inf = torch.tensor(1.0)
     oa.step()
     assert all(torch.equal(x, y) for x, y in zip(a, before))  # skipped
+
+
+def test_add_param_group_and_edited_groups_drop_the_cached_flat_binding():
+    """the flat views (moments, gathered-gradient views) are built for ONE parameter set; add_param_group or an in-place edit
+    of param_groups must make the next step rebind instead of copying into stale views."""
+    a, _ = _pair(7)
+    oa = AdamW([{"params": a[:1], "lr": 1e-2}])
+    oa._flat = {"ids": (id(a[0]),), "step_dev": torch.zeros(1, dtype=torch.int32)}      # as a bound optimiser would hold
+    oa._flat_failed = True
+    oa.add_param_group({"params": a[1:]})
+    assert oa._flat is None and oa._flat_failed is False
+    for x in a:
+        x.grad = torch.ones_like(x)
+    oa.step()                                                   # CPU parameters: torch's own step, on both groups
+    assert oa.last_step_fused is False and all(float(oa.state[x]["step"]) == 1.0 for x in a)
