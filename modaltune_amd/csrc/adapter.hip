@@ -556,7 +556,9 @@ __global__ __launch_bounds__(512) void token_mha_fwd_kernel(const float* __restr
   __syncthreads();          // a row's four writers -> its four readers
   if (act) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < T; ++j) acc += ss[t * S1 + j] * ld4(vs + j * AD + 4 * sub);
+    // (4-byte LDS reads only: the 16-byte value rows next to the 4-byte probabilities put both banking classes in flight, and hipcc
+    // consumed them behind counted lgkmcnt waits -- unsafe beside another stream's transposed LDS reads: lds_f32, common.h)
+    for (int j = 0; j < T; ++j) acc += lds_f32(&ss[t * S1 + j]) * lds_f32x4_by_dword(vs + j * AD + 4 * sub);
     *reinterpret_cast<f32x4*>(out + ((long)b * T + t) * E + h * AD + 4 * sub) = acc;
   }
 }
@@ -597,26 +599,28 @@ __global__ __launch_bounds__(512) void token_mha_bwd_kernel(const float* __restr
     float dov[AD];
 #pragma unroll
     for (int d = 0; d < AD; ++d) dov[d] = dos[t * AD + d];
-    float delta = 0.f;
+    // One banking class of LDS reads per loop (lds_f32, common.h): dP from the 16-byte value rows first, then delta from the 4-byte
+    // probabilities and the thread's own dP entries.
     for (int j = sub; j < T; j += 4) {
       const float* vr = vs + j * AD;
       float dp = 0.f;
 #pragma unroll
       for (int d = 0; d < AD; ++d) dp = fmaf(dov[d], vr[d], dp);
       dss[t * S1 + j] = dp;
-      delta = fmaf(pr[j], dp, delta);
     }
+    float delta = 0.f;
+    for (int j = sub; j < T; j += 4) delta = fmaf(lds_f32(&pr[j]), lds_f32(&dss[t * S1 + j]), delta);
     delta += __shfl_xor(delta, 1, 64);
     delta += __shfl_xor(delta, 2, 64);
-    for (int j = sub; j < T; j += 4) dss[t * S1 + j] = pr[j] * (dss[t * S1 + j] - delta) * ASCALE;
+    for (int j = sub; j < T; j += 4) dss[t * S1 + j] = lds_f32(&pr[j]) * (lds_f32(&dss[t * S1 + j]) - delta) * ASCALE;
   }
   __syncthreads();
   if (act) {          // dQ: thread (query t, dims 4 sub ..);  dK, dV: thread (key t, dims 4 sub ..)
     f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < T; ++j) {
-      aq += dss[t * S1 + j] * ld4(ks + j * AD + 4 * sub);
-      ak += dss[j * S1 + t] * ld4(qs + j * AD + 4 * sub);
-      av += pc[j * pst] * ld4(dos + j * AD + 4 * sub);
+    for (int j = 0; j < T; ++j) {      // (4-byte LDS reads only, as in the forward's value sweep)
+      aq += lds_f32(&dss[t * S1 + j]) * lds_f32x4_by_dword(ks + j * AD + 4 * sub);
+      ak += lds_f32(&dss[j * S1 + t]) * lds_f32x4_by_dword(qs + j * AD + 4 * sub);
+      av += lds_f32(&pc[j * pst]) * lds_f32x4_by_dword(dos + j * AD + 4 * sub);
     }
     const long o = ((long)b * T + t) * E + h * AD + 4 * sub;
     *reinterpret_cast<f32x4*>(dq + o) = aq;

@@ -16,6 +16,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MT_WAVE 64
 #define MT_DEVINL __device__ __forceinline__
+// LDS reads of BOTH banking classes in flight (4-byte class: ds_read_b32 / ds_read2_b32; 8 / 16-byte class: ds_read_b64 / _b128) must
+// not be consumed behind a COUNTED `s_waitcnt lgkmcnt(N > 0)`: beside another kernel's ds_read_b64_tr_b16 on the same CU (two HIP
+// streams: the pass groups of the train step) the count was met while an older 16-byte read had not delivered lanes 48-63 -- stale
+// registers, wrong sums, once in ~10 launches of mt_token_mha_fwd beside mt_gemm_tn_f16 (round 6; tools/diag/victim_stress2.py,
+// profiles/r06_lds_counted_wait.txt).  The same instructions behind ONE full wait, or as 4-byte reads only, never failed.
+// hipcc places its waits itself (an asm wait does not hold back register-only arithmetic), so the token-side kernels whose loops mixed
+// the two classes read through these helpers instead: `volatile` 4-byte reads are never merged into 8 / 16-byte ones, every LDS read
+// of the loop is of ONE class and its counted waits mean what they say.  tests/test_isa_lds_waits.py scans the ISA of every kernel
+// for the pattern (tools/diag/lds_wait_scan.py).
+MT_DEVINL float lds_f32(const float* p) { return *reinterpret_cast<const volatile float*>(p); }
+MT_DEVINL f32x4 lds_f32x4_by_dword(const float* p) {
+  const volatile float* q = reinterpret_cast<const volatile float*>(p);
+  return (f32x4){q[0], q[1], q[2], q[3]};
+}
+#define MT_LDS_DRAIN_V1(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory")
+#define MT_LDS_DRAIN_V2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory")
+#define MT_LDS_DRAIN_V3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory")
+#define MT_LDS_DRAIN_V4(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]) : : "memory")
+#define MT_LDS_DRAIN_V8(a)                                                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                            \
+               : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]), "+v"((a)[4]), "+v"((a)[5]), "+v"((a)[6]), "+v"((a)[7]) \
+               :                                                                                                                  \
+               : "memory")
 
 // Logical row -> physical row of a "segmented" activation view: logical row m lives at
 // (m / seg_rows) * seg_stride + row0 + (m % seg_rows).  With seg_rows = L, seg_stride = N, row0 = 1 this is

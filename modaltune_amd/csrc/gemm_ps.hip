@@ -363,6 +363,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   drain_store1(integral_constant<int, c>{}, integral_constant<int, 2>{}); drain_store1(integral_constant<int, c>{}, integral_constant<int, 3>{});
   PS_DRAIN_OPEN(0) PS_DRAIN_OPEN(1) PS_DRAIN_OPEN(2) PS_DRAIN_OPEN(3) PS_DRAIN_OPEN(4) PS_DRAIN_OPEN(5)
 #undef PS_DRAIN_OPEN
+  // The DMA groups issued by the last three slices (the last tile "fetched again into slots nobody reads") are still in flight here.
+  // A wave must not end under them: when the workgroup is gone its LDS goes to the next workgroup the CU admits -- with two pass groups
+  // on two streams that is a kernel of the OTHER stream, at once -- and the late 1 KB pieces land in ITS image (round 6: found as a
+  // once-in-30-steps corruption of a 3 / 4 KB run of the prompt self-attention's score rows = one wave's A / W pieces; a single stream
+  // hides it, the next kernel starts only behind the end-of-kernel flush).
+  ps_wait_vmcnt<0>();
 }
 
 }  // namespace

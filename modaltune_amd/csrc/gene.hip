@@ -53,9 +53,9 @@ MT_DEVINL void gemv_rows(const float* __restrict__ W, int n, const float (*xs)[G
     __syncthreads();
 #pragma unroll 8
     for (int c = 0; c < GC; ++c) {
-      const float w = Ws[j][c];
+      const float w = lds_f32(&Ws[j][c]);      // (every LDS read of the loop in the 4-byte class: lds_f32, common.h)
 #pragma unroll
-      for (int p = 0; p < P; ++p) acc[p] = fmaf(w, (k0 + c < n) ? xs[p][k0 + c] : 0.f, acc[p]);
+      for (int p = 0; p < P; ++p) acc[p] = fmaf(w, (k0 + c < n) ? lds_f32(&xs[p][k0 + c]) : 0.f, acc[p]);
     }
   }
 }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(GL) void gene_snn_fwd_kernel(GeneArgs a) {
       }
       __syncthreads();
 #pragma unroll 8
-      for (int c = 0; c < GC; ++c) acc = fmaf(Ws[j][c], (k0 + c < pn) ? xs[0][k0 + c] : 0.f, acc);
+      for (int c = 0; c < GC; ++c) acc = fmaf(lds_f32(&Ws[j][c]), (k0 + c < pn) ? lds_f32(&xs[0][k0 + c]) : 0.f, acc);
     }
   }
   a.a1[(long)i * GL + j] = acc;
@@ -144,9 +144,9 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
     f32x4 v = *reinterpret_cast<const f32x4*>(dst);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const float d = da2s[p][r];
+      const float d = lds_f32(&da2s[p][r]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaf(d, h1s[p][lane * 4 + e], v[e]);
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(d, lds_f32(&h1s[p][lane * 4 + e]), v[e]);
     }
     *reinterpret_cast<f32x4*>(dst) = v;
   }
@@ -163,9 +163,9 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
     __syncthreads();
 #pragma unroll 8
     for (int r = 0; r < GC; ++r) {
-      const float w = Ws[r][j];
+      const float w = lds_f32(&Ws[r][j]);
 #pragma unroll
-      for (int p = 0; p < P; ++p) dh1[p] = fmaf(w, da2s[p][r0 + r], dh1[p]);
+      for (int p = 0; p < P; ++p) dh1[p] = fmaf(w, lds_f32(&da2s[p][r0 + r]), dh1[p]);
     }
   }
   // the first layer's input is the same in every pass: da1 = sum_p dh1_p * mask_p * elu'(pre1)
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_kernel(GeneArgs a) {
   const float* g = a.genes + a.goff[i];
   for (long t = j; t < (long)GL * n; t += GL) {
     const int r = (int)(t / n), k = (int)(t - (long)r * n);
-    a.grads[o[0] + t] += da1s[r] * g[k];
+    a.grads[o[0] + t] += lds_f32(&da1s[r]) * g[k];
   }
 }
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(GL) void gene_snn_fwd_split_kernel(GeneArgs a) {
       }
       __syncthreads();
 #pragma unroll 8
-      for (int c = 0; c < GC; ++c) acc = fmaf(Ws[j][c], (k0 + c < pn) ? xs[0][k0 + c] : 0.f, acc);
+      for (int c = 0; c < GC; ++c) acc = fmaf(lds_f32(&Ws[j][c]), (k0 + c < pn) ? lds_f32(&xs[0][k0 + c]) : 0.f, acc);
     }
   }
   if (sp == 0) a.a1[(long)i * GL + j] = acc;
@@ -250,9 +250,9 @@ __global__ __launch_bounds__(GL) void gene_snn_fwd_split_kernel(GeneArgs a) {
     for (int p = 0; p < P; ++p) a2[p] = a.params[o[3] + r];
 #pragma unroll 8
     for (int k = 0; k < GL; ++k) {
-      const float w = Wl[j][k];
+      const float w = lds_f32(&Wl[j][k]);
 #pragma unroll
-      for (int p = 0; p < P; ++p) a2[p] = fmaf(w, xs[p][k], a2[p]);
+      for (int p = 0; p < P; ++p) a2[p] = fmaf(w, lds_f32(&xs[p][k]), a2[p]);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -295,9 +295,9 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_split_kernel(GeneArgs a) {
     f32x4 v = *reinterpret_cast<const f32x4*>(dst);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const float d = da2s[p][r];
+      const float d = lds_f32(&da2s[p][r]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaf(d, h1s[p][lane * 4 + e], v[e]);
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(d, lds_f32(&h1s[p][lane * 4 + e]), v[e]);
     }
     *reinterpret_cast<f32x4*>(dst) = v;
   }
@@ -319,9 +319,9 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_split_kernel(GeneArgs a) {
     for (int p = 0; p < P; ++p) dh1[p] = 0.f;
 #pragma unroll 8
     for (int r = 0; r < GL; ++r) {
-      const float w = Wc[r][j];
+      const float w = lds_f32(&Wc[r][j]);
 #pragma unroll
-      for (int p = 0; p < P; ++p) dh1[p] = fmaf(w, da2s[p][r], dh1[p]);
+      for (int p = 0; p < P; ++p) dh1[p] = fmaf(w, lds_f32(&da2s[p][r]), dh1[p]);
     }
     const float prek = a.a1[(long)i * GL + k];
     float da1 = 0.f;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(GL) void gene_snn_bwd_split_kernel(GeneArgs a) {
   const float* g = a.genes + a.goff[i];
   for (long t = j; t < (long)GR * n; t += GL) {
     const int r = (int)(t / n), c = (int)(t - (long)r * n);
-    a.grads[o[0] + ((long)GR * sp + r) * n + c] += da1s[r] * g[c];
+    a.grads[o[0] + ((long)GR * sp + r) * n + c] += lds_f32(&da1s[r]) * g[c];
   }
 }
 

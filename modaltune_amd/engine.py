@@ -171,6 +171,7 @@ class Engine:
         self.generation = 0
         # backward stages whose parameter gradients are final (data-parallel bucket boundaries): set by TrainStep
         self.grad_ready_hook = None
+        self.record_markers = False           # mark the blocks on the tape even without a hook (TrainStep's pass groups run their backwards stage by stage)
         self._coord_err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._coord_err_host = None           # pinned mirror of _coord_err + the event of its last async read-back:
         self._coord_err_event = None          # bad coords raise at the next call WITHOUT a host sync (poll_inputs)
@@ -501,8 +502,8 @@ class Engine:
             # Everything recorded from here on belongs to interaction block i (and the blocks above): when the backward
             # reaches this marker, the gradients of interactions.{i}.* / prompt_selfattention.{i}.* (and of the head, for the
             # last block) are final -- the data-parallel reducer starts their all-reduce while the blocks below still run.
-            if need_grad and self.grad_ready_hook is not None:
-                tape.record(lambda i=i: self.grad_ready_hook is not None and (self._leaf_join(), self.grad_ready_hook(i)))
+            if need_grad and (self.grad_ready_hook is not None or self.record_markers):
+                tape.record_marker(i, lambda i=i: self.grad_ready_hook is not None and (self._leaf_join(), self.grad_ready_hook(i)))
             if i > 0 and cfg.use_prompt_sa:
                 c = self._prompt_self_attention(c, pe, f"prompt_selfattention.{i}.")
             hin = ws[f"hin{la}"]
@@ -1043,3 +1044,17 @@ class Engine:
         logits.grad = dlogits.to(self.device, F32).contiguous()
         tape.run_backward()
         self._leaf_join()                      # (side-stream weight-gradient leaves, if enabled: final before anything reads the flat gradient)
+
+    def backward_begin(self, dlogits: torch.Tensor, call):
+        """Stage-wise backward (TrainStep's pass groups with per-bucket joins): seed the gradient, then call backward_stage(call)
+        until it returns None."""
+        _, logits = call
+        logits.grad = dlogits.to(self.device, F32).contiguous()
+
+    def backward_stage(self, call):
+        """Runs `call`'s backward down to the next interaction-block marker and returns that block's index (the gradients of
+        interactions.{i}.* and of everything above are final on the current stream), or None when the backward has finished."""
+        tape, _ = call
+        blk = tape.run_backward_stage()
+        self._leaf_join()
+        return blk

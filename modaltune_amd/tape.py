@@ -16,6 +16,17 @@ from . import ops
 _ACTIVE: Optional["Tape"] = None      # the tape whose forward is being recorded (set by Tape.reset)
 
 
+class _Marker:
+    __slots__ = ("tag", "fn")
+
+    def __init__(self, tag, fn):
+        self.tag, self.fn = tag, fn
+
+    def __call__(self):
+        if self.fn is not None:
+            self.fn()
+
+
 class Var:
     """A contiguous fp32 activation [..., C] with an optional (lazily zero-allocated) gradient."""
     __slots__ = ("data", "grad", "needs_grad", "_tape")
@@ -126,10 +137,28 @@ class Tape:
         if self.grad_enabled:
             self.back.append(fn)
 
+    def record_marker(self, tag, fn: Optional[Callable[[], None]] = None):
+        """A stage boundary of the backward: run_backward() treats it as an ordinary closure (calls fn), run_backward_stage() stops
+        there and hands `tag` back (the engine marks its interaction blocks: everything recorded after the marker belongs to block
+        `tag` and the blocks above, so when the backward reaches it their parameter gradients are final)."""
+        if self.grad_enabled:
+            self.back.append(_Marker(tag, fn))
+
     def run_backward(self):
         for fn in reversed(self.back):
             fn()
         self.back.clear()
+
+    def run_backward_stage(self):
+        """Runs the recorded closures in reverse up to (and consuming) the next marker; returns its tag, or None once the tape is
+        exhausted.  The marker's own fn is NOT called: the caller owns what happens at the boundary."""
+        back = self.back
+        while back:
+            fn = back.pop()
+            if isinstance(fn, _Marker):
+                return fn.tag
+            fn()
+        return None
 
     def new(self, *shape) -> torch.Tensor:
         t = torch.empty(*shape, device=self.device, dtype=torch.float32)

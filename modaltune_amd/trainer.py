@@ -105,6 +105,16 @@ class TrainStep:
         # same-box, hipGraph replay, ms per step batched -> split: L = 16 000: 69.5 -> 67.6; 12 000: 51.4 -> 50.6; 10 000: 41.8 -> 40.5;
         # 9 000: 37.7 -> 36.5; 8 000: 33.7 -> 32.9; 6 500: 26.6 -> 27.4 (!); 4 096: 18.2 -> 18.1; 2 500: 12.1 -> 12.2; 1 024: 8.2 -> 8.1
         self.split_min_patches = 7500
+        # Data-parallel schedule of a long bag (world > 1).  "groups_joined": the two pass groups with PER-BUCKET joins -- their backwards
+        # run stage by stage (a stage = one interaction block); when both groups have left a block the main stream sums that bucket's
+        # ranges of the two gradient sets and starts its all-reduce, the groups keep running below (DDP's overlap of the reduction with
+        # the backward, base_trainer.py:205-211, under the two-stream schedule).  "groups_exposed": round 5's form -- every bucket starts
+        # behind the groups' final join, the whole reduction is exposed in front of AdamW.  "batched": one B = 3 pass, buckets started
+        # from inside its backward.  bench.py --gpus N times all three at start-up and keeps the fastest (`comm.schedule_chosen`).
+        # MT_DP_SCHEDULE overrides; on one GPU "groups_joined" only matters when forced (what the extra joins cost: DESIGN section 6).
+        self.dp_schedule = os.environ.get("MT_DP_SCHEDULE", "groups_joined")
+        self.force_bucket_joins = os.environ.get("MT_BUCKET_JOINS") == "force"
+        self.buckets_started_early = 0      # per step: buckets whose all-reduce was started before the last backward kernel was enqueued
 
     # ------------------------------------------------------------------ learning-rate schedule hook
     @property
@@ -161,6 +171,8 @@ class TrainStep:
         eng = self.engine
         if not (self.split_passes and eng.cfg.is_multi and not eng.collect_taps):
             return False
+        if self._world() > 1 and self.dp_schedule == "batched":
+            return False
         if L is not None and L < self.split_min_patches and os.environ.get("MT_SPLIT_PASSES") != "force":
             return False
         if hasattr(eng, "forward_slide"):
@@ -183,7 +195,7 @@ class TrainStep:
             self._group_tapes.append(t)
         self._loss_parts = [torch.zeros(1, dtype=F32, device=self.dev) for _ in self._groups]
 
-    def _fwd_bwd_split(self, x, coords, genes, text, clinical, staged_geometry=None):
+    def _fwd_bwd_split(self, x, coords, genes, text, clinical, staged_geometry=None, reduce: bool = True):
         """_fwd_bwd with the task passes in two concurrent groups (see __init__)."""
         eng = self.engine
         if self._pass_streams is None:
@@ -226,6 +238,12 @@ class TrainStep:
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
+        # per-bucket joins: the groups' backwards advance stage by stage so that a bucket's all-reduce starts as soon as BOTH groups
+        # have left its interaction block (see __init__: dp_schedule)
+        joined = (self._world() > 1 and self.dp_schedule == "groups_joined" and reduce) or self.force_bucket_joins
+        eng.record_markers = bool(joined)
+        calls = []
+        self.buckets_started_early = 0
         try:
             for gi, (a, b) in enumerate(self._groups):
                 st = self._pass_streams[gi]
@@ -245,19 +263,70 @@ class TrainStep:
                         call = eng.last_call
                         dlogits = torch.empty_like(logits)
                         ops.distill_loss(logits, target[a:b], self._loss_parts[gi], dlogits, b - a, O, 1.0, self.scale)
-                        eng.backward(dlogits, call=call)
+                        if joined:
+                            eng.backward_begin(dlogits, call)
+                            calls.append(call)
+                        else:
+                            eng.backward(dlogits, call=call)
                         logits_all[a:b].copy_(logits)
                     finally:
                         eng.store.use_grad_set(*old)
                 if self._group_hook is not None:
                     self._group_hook(gi)
+            fg = eng.store.flat_grad
+            summed = set()
+            if joined:
+                nint = self._nint
+                for stage in range(nint + 1):
+                    evs = []
+                    for gi, call in enumerate(calls):
+                        st = self._pass_streams[gi]
+                        with torch.cuda.stream(st):
+                            blk = eng.backward_stage(call)
+                            if stage < nint:
+                                if blk != nint - 1 - stage:
+                                    raise RuntimeError(f"pass group {gi}: backward stage {stage} ended at block marker {blk}")
+                                ev = torch.cuda.Event()
+                                ev.record(st)
+                                evs.append(ev)
+                            elif blk is not None:
+                                raise RuntimeError(f"pass group {gi}: a block marker ({blk}) below the last stage")
+                    if stage == nint:
+                        break
+                    # bucket `stage` (= the parameters of block nint - 1 - stage, and the head for stage 0) is final in every group's
+                    # set: sum its ranges on the main stream and start its all-reduce; the groups keep running their lower blocks
+                    for ev in evs:
+                        main.wait_event(ev)
+                    for o, n in self.reducer.buckets[stage]:
+                        for flat, _ in self._grad_sets[1:]:
+                            ops.axpy(fg[o:o + n], flat[o:o + n], 1.0, fg[o:o + n])
+                    summed.add(stage)
+                    self.buckets_started_early += 1
+                    if self._cap is not None:
+                        # under capture the graph is cut here (the collective is launched eagerly between two replays): a cut needs
+                        # every forked stream back on the capture stream, so the groups re-fork behind it
+                        self._segment_break(stage)
+                        fork = torch.cuda.Event()
+                        fork.record(main)
+                        for st in self._pass_streams:
+                            st.wait_event(fork)
+                    else:
+                        self.reducer.start(stage)
         finally:
+            eng.record_markers = False
             for st in self._pass_streams:
                 main.wait_stream(st)
-        # the streams have met: one gradient buffer, one loss
-        fg = eng.store.flat_grad
-        for flat, _ in self._grad_sets[1:]:
-            ops.axpy(fg, flat, 1.0, fg)
+        # the streams have met: one gradient buffer, one loss (buckets summed at their own joins are left alone: their all-reduce
+        # may be in flight)
+        if summed:
+            for b, bk in enumerate(self.reducer.buckets):
+                if b not in summed:
+                    for o, n in bk:
+                        for flat, _ in self._grad_sets[1:]:
+                            ops.axpy(fg[o:o + n], flat[o:o + n], 1.0, fg[o:o + n])
+        else:
+            for flat, _ in self._grad_sets[1:]:
+                ops.axpy(fg, flat, 1.0, fg)
         ops.axpy(self._loss_parts[0], self._loss_parts[1], 1.0, self.loss)
         for part in self._loss_parts[2:]:
             ops.axpy(self.loss, part, 1.0, self.loss)
@@ -267,7 +336,7 @@ class TrainStep:
         eng = self.engine
         Lnow = staged_geometry[1] if staged_geometry is not None else (x.reshape(-1, x.shape[-1]).shape[0] if torch.is_tensor(x) else None)
         if self._split_now(Lnow):
-            return self._fwd_bwd_split(x, coords, genes, text, clinical, staged_geometry)
+            return self._fwd_bwd_split(x, coords, genes, text, clinical, staged_geometry, reduce=reduce)
         self._wait_params()               # the all-gather of the last step's sharded parameter update (no-op otherwise)
         eng.grad_ready_hook = self._on_grad_ready if (reduce and self._world() > 1) else None
         if eng.stochastic:
