@@ -51,7 +51,8 @@ def trainstep(rank, world, out):
     assert all(torch.equal(sd[k], eng.store.tensors[k]) for k in sd)
     nseg = max(len(s) for s in ts._graphs) if ts._graphs else 0
     np.savez(out, flat=eng.store.flat.cpu().numpy(), losses=np.array(losses), replays=ts.graph_replays, nseg=nseg,
-             steps=int(ts.step_dev), buckets=len(ts.reducer.buckets))
+             steps=int(ts.step_dev), buckets=len(ts.reducer.buckets), early=int(ts.buckets_started_early),
+             split=int(ts._pass_streams is not None))
 
 
 def ragged(rank, world, out):

@@ -64,11 +64,35 @@ def test_two_rank_trainstep_matches_gradient_averaging(tmp_path):
 
 
 def test_two_rank_trainstep_with_pass_groups_on_two_streams(tmp_path):
-    """The same with the task passes of every rank's step split into two concurrent groups (forced on at test size): no bucket
-    starts before the groups' streams have met (ONE captured segment), the collectives run behind the join; same result."""
+    """The same with the task passes of every rank's step split into two concurrent groups (forced on at test size).  Round 6: the
+    groups' backwards run stage by stage and every bucket but the last is summed over the two gradient sets and handed to the
+    reducer as soon as BOTH groups have left its interaction block (`dp_schedule = "groups_joined"`, the default): >= 3 of the 4
+    buckets start before the last backward kernel is enqueued, the capture is cut at those joins (4 segments), and the ranks end
+    bit-identical and equal to the single-process reference."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    _check_trainstep(_run_ranks("trainstep", tmp_path, extra_env={"MT_SPLIT_PASSES": "force"}), nseg=1)
+    res = _run_ranks("trainstep", tmp_path, extra_env={"MT_SPLIT_PASSES": "force"})
+    assert all(int(r["split"]) == 1 and int(r["early"]) >= 3 for r in res), [(int(r["split"]), int(r["early"])) for r in res]
+    _check_trainstep(res, nseg=4)
+
+
+def test_two_rank_trainstep_with_pass_groups_and_exposed_reduction(tmp_path):
+    """Round 5's form of the above, still selectable (`MT_DP_SCHEDULE=groups_exposed`; bench.py --gpus N times it against the other two
+    schedules): no bucket starts before the groups' streams have met (ONE captured segment), the collectives run behind the join."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    res = _run_ranks("trainstep", tmp_path, extra_env={"MT_SPLIT_PASSES": "force", "MT_DP_SCHEDULE": "groups_exposed"})
+    assert all(int(r["split"]) == 1 and int(r["early"]) == 0 for r in res)
+    _check_trainstep(res, nseg=1)
+
+
+def test_two_rank_trainstep_with_the_batched_schedule_forced(tmp_path):
+    """`MT_DP_SCHEDULE=batched`: one B = 3 pass even where the pass groups would run (buckets started from inside its backward)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    res = _run_ranks("trainstep", tmp_path, extra_env={"MT_SPLIT_PASSES": "force", "MT_DP_SCHEDULE": "batched"})
+    assert all(int(r["split"]) == 0 for r in res)
+    _check_trainstep(res, nseg=4)
 
 
 def _check_ragged(res):

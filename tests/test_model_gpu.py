@@ -140,6 +140,41 @@ def test_pass_groups_on_two_streams_match_the_batched_step(golden_dir, name):
     assert ts.graph_replays >= 2 and max(losses) - min(losses) <= 1e-6 * abs(loss0) and abs(losses[-1] - loss0) <= 1e-6 * abs(loss0)
 
 
+def test_pass_groups_with_per_bucket_joins_match_the_batched_step(golden_dir):
+    """Round 6: the data-parallel form of the pass groups -- both groups' backwards advance stage by stage, each bucket's ranges of the
+    two gradient sets are summed at ITS join and (world > 1) handed to the reducer there -- forced on one GPU: same logits and loss
+    as the batched pass, gradients within the accumulation-order tolerance, three early buckets, and the captured step (cut at the
+    three joins: four segments + nothing else) replays the eager loss."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(golden_dir, "model_L1500_d3.npz")
+    g, cfg, eng, ts, inp = _build(path)
+    x = torch.from_numpy(inp["x"]).cuda()
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"])
+    ts.split_min_patches = 1 << 30
+    ts.step(x, inp["coords"], genes, text, update=False)
+    torch.cuda.synchronize()
+    l0, loss0, g0 = ts.last_logits.clone(), float(ts.loss), {k: v.clone() for k, v in ts.unscaled_grads().items()}
+    ts.split_min_patches, ts.force_bucket_joins = 0, True
+    for _ in range(2):
+        ts.step(x, inp["coords"], genes, text, update=False)
+        torch.cuda.synchronize()
+        l1, loss1, g1 = ts.last_logits.clone(), float(ts.loss), ts.unscaled_grads()
+        assert ts.buckets_started_early == 3 and torch.equal(l0, l1) and abs(loss0 - loss1) <= 1e-6 * abs(loss0)
+        for k in g0:
+            assert float((g0[k] - g1[k]).norm()) <= 2e-3 * float(g0[k].norm()) + 1e-7 * max(float(v.norm()) for v in g0.values()), k
+    ts.set_lr(0.0); ts.wd = 0.0
+    losses = []
+    for _ in range(5):
+        ts.step_graphed(x, inp["coords"], genes, text)
+        torch.cuda.synchronize()
+        losses.append(float(ts.loss))
+    assert ts.graph_replays >= 2 and max(len(sg) for sg in ts._graphs) == 4
+    assert max(abs(v - loss0) for v in losses) <= 1e-6 * abs(loss0), (losses, loss0)
+    assert torch.equal(ts.last_logits, l0)
+
+
 def test_two_task_passes_as_two_single_pass_groups_match_the_batched_step(golden_dir):
     """B = 2 (two task ids): the groups are (0, 1) and (1, 2), BOTH of one pass -- the engine keys its workspace storage on the pass
     count, so the two concurrent groups need storage of their own (they used to share hin / qkv / dh / scratch and
