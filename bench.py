@@ -632,6 +632,7 @@ def main():
         run(nwarm)
     eng.check_inputs()
     comm = None
+    extra_steps = 0
     if world > 1:
         # the collective path is real before anything is timed: an all-reduce of ones must come back as the world size
         probe = torch.ones(1, device=dev) if args.backend == "nccl" else torch.ones(1)
@@ -641,6 +642,38 @@ def main():
                 "last_bucket_sharded": bool(ts.reducer.sharded)}
         if comm["ranks_seen_by_all_reduce"] != world:
             raise RuntimeError(f"all_reduce of ones returned {float(probe)} on a world of {world}")
+        # Which data-parallel schedule of a long bag is fastest HERE (interconnect, payload, bag length)?  TrainStep.dp_schedule:
+        # "groups_joined" (two pass groups, every bucket summed and started at its own join), "groups_exposed" (round 5: the whole
+        # reduction behind the groups' final join), "batched" (one B = 3 pass, buckets started from inside its backward).  Each is
+        # captured and timed for a few steps; the choice is the minimum of the MAX-over-ranks times and is the same on every rank.
+        cands = ["groups_joined", "groups_exposed", "batched"] if (ts.split_passes and L >= ts.split_min_patches and not (args.eager or args.ragged)) \
+            else [ts.dp_schedule]
+        forced = os.environ.get("MT_DP_SCHEDULE")
+        if forced:
+            cands = [forced]
+        timings = {}
+        for sched in cands:
+            ts.dp_schedule = sched
+            extra_steps += 7
+            run(3, first=nwarm)                      # eager visits + capture of this schedule's graphs
+            ts.comm_events = []
+            barrier()
+            t0 = time.perf_counter()
+            run(4, first=nwarm)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if args.backend != "nccl" else dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            ev, ts.comm_events = ts.comm_events, None
+            exposed = [a.elapsed_time(b) for k, a, b in ev if k == "grad"]
+            timings[sched] = {"ms_per_step": round(1e3 * float(tt) / 4, 3), "comm_exposed_ms_this_rank": round(sum(exposed) / max(1, len(exposed)), 3)}
+        chosen = min(timings, key=lambda k: timings[k]["ms_per_step"])
+        ts.dp_schedule = chosen
+        comm["schedule_chosen"], comm["schedule_timings"] = chosen, timings
+        comm["schedule_how"] = ("each candidate captured, then 4 replayed steps between barriers, MAX over ranks; the timed region below runs the "
+                                "fastest" + (" (MT_DP_SCHEDULE forced the choice)" if forced else ""))
+        run(2, first=nwarm)
+        extra_steps += 2
+        comm["buckets_started_before_the_backward_ended"] = int(ts.buckets_started_early) if chosen == "groups_joined" else None
         ts.comm_events = []
     barrier()
     t0 = time.perf_counter()
@@ -672,7 +705,7 @@ def main():
     run(prof_steps, graphed=False, first=nwarm + args.steps)
     barrier()
     timer, ops.TIMER = ops.TIMER, None
-    skipped = nwarm + args.steps + prof_steps + (2 if pass_groups["on"] else 0) - int(ts.step_dev)
+    skipped = nwarm + args.steps + prof_steps + (2 if pass_groups["on"] else 0) + extra_steps - int(ts.step_dev)
     # the token side on its own: every token-side launch of ONE step recorded in order, captured as a hipGraph on the same buffers and
     # replayed -- what the ~220 small dependent launches cost INSIDE the replayed step (HIP events around each launch of the eager pass
     # above add the event overhead to every one of them: that table's `token_side` row is an upper bound)

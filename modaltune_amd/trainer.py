@@ -473,7 +473,8 @@ class TrainStep:
                 e.segs = e.logits = None
             self._opt_graph = None
             self._ggen = eng.generation
-        key = (L, Lv, world, bool(eng.stochastic))
+        # (the data-parallel schedule is part of the key: bench.py --gpus N times the three schedules one after the other)
+        key = (L, Lv, world, bool(eng.stochastic), self.dp_schedule if world > 1 else None, self.force_bucket_joins)
         ent = self._gcache.get(key)
 
         def fwd_bwd():

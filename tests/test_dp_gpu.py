@@ -218,10 +218,25 @@ def test_bench_two_gpus_over_rccl():
     _check_bench("nccl")
 
 
-def _check_bench(backend):
+def test_bench_two_ranks_choose_the_data_parallel_schedule_of_a_long_bag():
+    """Round 6: at a bag length where the pass groups run, `bench.py --gpus N` captures and times the three
+    data-parallel schedules and keeps the fastest; the line carries the choice, the three timings and -- when the joined schedule is
+    chosen -- how many buckets were started before the backward had ended."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = _check_bench("gloo", patches="7600")
+    c = out["comm"]
+    assert set(c["schedule_timings"]) == {"groups_joined", "groups_exposed", "batched"} and c["schedule_chosen"] in c["schedule_timings"]
+    assert all(v["ms_per_step"] > 0 for v in c["schedule_timings"].values())
+    assert c["schedule_timings"][c["schedule_chosen"]]["ms_per_step"] == min(v["ms_per_step"] for v in c["schedule_timings"].values())
+    if c["schedule_chosen"] == "groups_joined":
+        assert c["buckets_started_before_the_backward_ended"] >= 3
+
+
+def _check_bench(backend, patches="1024"):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", backend, "--patches", "1024",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", backend, "--patches", patches,
                         "--steps", "3", "--warmup", "3", "--no-cpu-baseline"], env=env, capture_output=True, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
@@ -236,4 +251,5 @@ def _check_bench(backend):
     assert len(c["bucket_bytes"]) == 4 and all(b > 0 for b in c["bucket_bytes"]) and sum(c["bucket_bytes"]) > 30e6
     assert c["comm_exposed_events"] == 3 and c["comm_exposed_ms"] >= 0.0
     assert c["param_gather_exposed_ms"] >= 0.0 and len(c["per_rank_ms_per_step"]) == 2
+    return out
     assert max(c["per_rank_ms_per_step"]) <= out["ms_per_step"] * 1.001
