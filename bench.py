@@ -46,7 +46,7 @@ def parse_args():
                                                     "grouping sizes (tests/golden/pathway_sizes_331.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short secondary legs the default 1-GPU run appends as sub-records "
-                                                           "(`module_api`, `pcie_inclusive`, `titan`)")
+                                                           "(`module_api`, `pcie_inclusive`, `sizes`, `titan`)")
     ap.add_argument("--cpu-baseline-child", type=int, default=0, help=argparse.SUPPRESS)      # internal: the CPU leg's own process
     ap.add_argument("--no-dropout", action="store_true", help="run the step with Dropout / DropPath off (the parity configuration); "
                                                              "default: on, as model.train() leaves them in the reference")
@@ -546,6 +546,129 @@ def leg_pcie(ts, eng, sizes, L, resident_value, steps=20):
             "how": "CasePrefetcher: pinned staging, H2D on a copy stream one case ahead of the running step, fp32 -> fp16 cast on the device"}
 
 
+MFMA_BOUND = ("gemm_nt[", "dilated_attn_fwd", "dilated_attn_bwd_kv", "dilated_attn_bwd_q", "dense_attn")
+HBM_BOUND = ("layernorm", "add_layernorm", "dilated_mix_ln", "dilated_attn_bwd_combine", "cast", "copy_rows", "dropout_f32", "inject_resid_bwd",
+             "elementwise", "gelu_f16", "adamw")
+
+
+def leg_overlap(ts, slide):
+    """What the two concurrent pass groups actually hide: HIP events around EVERY launch of one eager step of the
+    two-stream schedule (each group's events on its own stream; rocprofv3 serialises the two branches of the replayed graph and cannot
+    show this), once with the groups overlapping and once with the same two groups one after the other (host sync between them).
+    A kernel family is MFMA-bound (GEMMs, attention) or HBM-bound (LayerNorm family, branch mix, combine, casts, residual kernels);
+    `hbm_ms_hidden` = HBM-bound kernel time of one group that ran while an MFMA-bound kernel of the OTHER group was running."""
+    import torch
+    from modaltune_amd import ops
+    x, coords, genes, text = slide
+
+    def instrumented(serial):
+        ts._group_hook = (lambda gi: torch.cuda.synchronize()) if serial else None
+        ops.TIMER, ops.TIMELINE = {}, []
+        base = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        base.record()
+        ts.step(x, coords, genes, text, update=True)
+        torch.cuda.synchronize()
+        tl, ops.TIMER, ops.TIMELINE = ops.TIMELINE, None, None
+        ts._group_hook = None
+        rows = [(k, base.elapsed_time(e0), base.elapsed_time(e1), st) for k, e0, e1, st in tl]
+        return rows
+
+    def cls(k):
+        return "mfma" if k.startswith(MFMA_BOUND) else "hbm" if k.startswith(HBM_BOUND) else "other"
+
+    for _ in range(2):
+        ts.step(x, coords, genes, text, update=True)      # (eager warm-up of the split geometry)
+    alone = instrumented(True)
+    both = instrumented(False)
+    streams = sorted({st for _, _, _, st in both}, key=lambda s_: -sum(1 for r in both if r[3] == s_))[:2]
+    fam_alone, fam_both = {}, {}
+    for rows, acc in ((alone, fam_alone), (both, fam_both)):
+        for k, a, b, st in rows:
+            acc[k] = acc.get(k, 0.0) + (b - a)
+    iv = {st: [(a, b, cls(k)) for k, a, b, s2 in both if s2 == st] for st in streams}
+
+    def overlap_ms(xs, ys):      # total length of [intervals of xs] intersected with [union of ys]; both sorted by start, ys disjoint on one stream
+        tot, j = 0.0, 0
+        for a, b in xs:
+            while j < len(ys) and ys[j][1] <= a:
+                j += 1
+            i = j
+            while i < len(ys) and ys[i][0] < b:
+                tot += max(0.0, min(b, ys[i][1]) - max(a, ys[i][0]))
+                i += 1
+        return tot
+
+    hidden = 0.0
+    if len(streams) == 2:
+        for sa, sb in ((streams[0], streams[1]), (streams[1], streams[0])):
+            hb = sorted((a, b) for a, b, c in iv[sa] if c == "hbm")
+            mf = sorted((a, b) for a, b, c in iv[sb] if c == "mfma")
+            hidden += overlap_ms(hb, mf)
+    hbm_both = sum(v for k, v in fam_both.items() if cls(k) == "hbm")
+    hbm_alone = sum(v for k, v in fam_alone.items() if cls(k) == "hbm")
+    mf_both = sum(v for k, v in fam_both.items() if cls(k) == "mfma")
+    mf_alone = sum(v for k, v in fam_alone.items() if cls(k) == "mfma")
+    span = lambda rows: max(b for _, _, b, _ in rows) - min(a for _, a, _, _ in rows)
+    worst = sorted(((k, fam_both[k] - fam_alone.get(k, 0.0)) for k in fam_both), key=lambda kv: -kv[1])[:6]
+    return {"span_ms_overlapped": round(span(both), 3), "span_ms_groups_one_after_the_other": round(span(alone), 3),
+            "hbm_kernel_ms_alone": round(hbm_alone, 3), "hbm_kernel_ms_overlapped": round(hbm_both, 3), "hbm_ms_hidden": round(hidden, 3),
+            "hbm_hidden_frac": round(hidden / max(hbm_both, 1e-9), 3),
+            "mfma_kernel_ms_alone": round(mf_alone, 3), "mfma_kernel_ms_overlapped": round(mf_both, 3), "mfma_ms_slowed": round(mf_both - mf_alone, 3),
+            "most_slowed_families_ms": {k: round(v, 3) for k, v in worst}, "launches": len(both),
+            "how": "eager instrumented steps (HIP events around every launch, on the launching stream); spans include the event overhead of ~900 "
+                   "launches, so they are longer than the replayed step -- compare the two spans with each other, not with ms_per_step"}
+
+
+def leg_size(ts, eng, sizes, L, dropout, steps=8):
+    """One more bag length through the SAME TrainStep (hipGraph replay after the usual eager visits): the reference's loader feeds anything
+    from a few hundred to 25 000 patches per case (data_utils/datasets.py:274-281 `threshold`, scripts/submit_modaltune.sh:47-49)."""
+    import torch
+    from modaltune_amd import synth
+    from modaltune_amd.config import flops_per_slide_step
+    dev = eng.device
+    slides = []
+    for j in range(2):
+        inp = synth.synth_inputs(L, sizes, seed=5000 + 7 * j + L, grid=128 if L <= 128 * 128 else 512)
+        slides.append((torch.from_numpy(inp["x"]).to(dev).half().reshape(L, -1).contiguous(), torch.from_numpy(inp["coords"]).to(dev),
+                       [torch.from_numpy(a).to(dev) for a in inp["genes"]], torch.from_numpy(inp["text"]).to(dev)))
+    r0 = ts.graph_replays
+    for i in range(ts.capture_after + 2):
+        ts.step_graphed(*slides[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ts.step_graphed(*slides[i % 2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl = flops_per_slide_step(L, eng.cfg.num_tokens)
+    return {"patches": L, "pathways": len(sizes), "tokens": eng.cfg.num_tokens, "ms_per_step": round(1e3 * dt, 3), "value": round(1.0 / dt, 3),
+            "unit": "slides/s", "steps": steps, "step_tflops": round(fl["step"] / 1e12, 3),
+            "step_mfma_frac": round(fl["step"] / dt / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), "pass_groups": bool(ts._split_now(L)),
+            "graph_replays": ts.graph_replays - r0, "dropout": dropout}
+
+
+def leg_real_pathways(args, L, steps=8):
+    """The headline bag with the reference's REAL gene grouping (331 pathways, 33.5 M trainable parameters: the 134 MB gradient payload of
+    the data-parallel step) instead of the 6-pathway toy grouping BASELINE's "6 pathway tokens" names."""
+    import torch
+    from modaltune_amd import synth
+    from modaltune_amd.config import ModelConfig
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sizes = json.load(open(os.path.join(ROOT, "tests", "golden", "pathway_sizes_331.json")))
+    cfg = ModelConfig()
+    eng = Engine(cfg, sizes, dev)
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed=0))
+    eng.set_stochastic(not args.no_dropout, seed=20261)
+    ts = TrainStep(eng)
+    ts.set_projector(synth.projector_state(0))
+    rec = leg_size(ts, eng, sizes, L, not args.no_dropout, steps=steps)
+    rec["trainable_parameters"] = int(eng.store.n_flat)
+    return rec
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_child:
@@ -822,7 +945,13 @@ def main():
         if default_line and not args.no_legs:
             # secondary configurations as short sub-records of the SAME driver-observed line (each <= ~10 s; never the headline)
             out["pcie_inclusive"] = _leg(lambda: leg_pcie(ts, eng, sizes, L, value))
+            if pass_groups["on"]:
+                pass_groups["overlap"] = _leg(lambda: leg_overlap(ts, slides[0]))
+            # the bag lengths the reference's loader actually feeds (BASELINE config 1's 512, 4 096, the `threshold` 25 000), same model
+            out["sizes"] = [_leg(lambda Lx=Lx: leg_size(ts, eng, sizes, Lx, not args.no_dropout)) for Lx in (512, 4096, 25000) if Lx != L]
             del ts, eng, slides
+            torch.cuda.empty_cache()
+            out["sizes"].append(_leg(lambda: leg_real_pathways(args, L)))
             torch.cuda.empty_cache()
             def module_leg():
                 rec = run_module(args, steps=8, warmup=4, optim="fused")

@@ -203,6 +203,8 @@ def dilated_attn_bwd(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16):
         _dilated_attn_bwd_phase(qkv, dmixed, lse_tot, delta_br, plan, workspace, dqkv16, ph)
         e1.record()
         TIMER.setdefault(name, []).append((e0, e1))
+        if TIMELINE is not None:
+            TIMELINE.append((name, e0, e1, torch.cuda.current_stream().cuda_stream))
 
 
 # ---- dense attention with the 2-D ALiBi bias (one fp16 distance table per slide) + the other TITAN-side launchers (include/modaltune_hip.h)
@@ -493,6 +495,7 @@ def check_finite(g, n, found_inf):
 TIMER = None
 RECORD = None          # bench.py: list that receives (fn, args, kwargs) of every token-side launch of a step (replayed in isolation as a graph)
 RECORD_KEEP = []       # tensors the recorded launches point to (Tape.new appends while RECORD is set)
+TIMELINE = None        # bench.py: with TIMER set, also (key, start event, end event, stream handle) of every launch, in launch order
 
 
 def _timed(name_fn):
@@ -510,6 +513,8 @@ def _timed(name_fn):
             r = fn(*a, **k)
             e1.record()
             TIMER.setdefault(key, []).append((e0, e1))
+            if TIMELINE is not None:
+                TIMELINE.append((key, e0, e1, torch.cuda.current_stream().cuda_stream))
             return r
         wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
         return wrapper
