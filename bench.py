@@ -399,6 +399,14 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
                    "that has not been seen three times runs the eager schedule" if graphed else "eager"), "graph_replays": replays,
         "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:14]},
     }
+    if args.kernel_times:
+        fam = {}
+        for k, (n, m_) in summ.items():
+            f = re.sub(r"\[.*", "", k)
+            fam[f] = (fam.get(f, (0, 0.0))[0] + n, fam.get(f, (0, 0.0))[1] + m_)
+        tot = sum(v[1] for v in fam.values())
+        for k, (n, m_) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {k:28s} launches/step {n / prof_steps:7.1f}  ms/step {m_ / prof_steps:9.3f}  ({100 * m_ / tot:5.1f} %)", file=sys.stderr)
     if cpu_baseline and not args.no_cpu_baseline:
         out["cpu_baseline"] = titan_cpu_baseline(vit_cpu, int(sum(cells_per) / len(cells_per)) + 1, 6, 3)
     return out

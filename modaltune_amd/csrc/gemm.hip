@@ -468,14 +468,20 @@ int launch_nt(const GemmNtArgs& a, hipStream_t s) {
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
         ncu = 256;
     }
+    // Which rows get 256-row tiles: the cheapest of {all big, whole rounds of big tiles + one round of small ones, all small} under
+    // cost(round of big tiles) = 10, cost(round of small tiles) = 6 (a 128 x 256 tile takes 57 us at K = 3072, a 256 x 256 one 97).
+    // All-small matters below half a round of big tiles: N = 768, K = 3072 at M = 9 219 is 108 big tiles on 256 CUs -- 72.7 us whatever
+    // M is -- or 219 small ones (round 6; hipBLASLt: 50 us).
     const int nbn = cdiv(a.N, 256), nrt = cdiv(a.M, 256);
     int big_rt = nrt;                                     // row tiles covered by 256-row tiles
+    long best = 10L * cdiv(nrt * nbn, ncu);
     if (nrt * nbn > ncu) {
       const int full = (nrt * nbn) / ncu;                 // whole rounds of big tiles
       const int rt = (full * ncu) / nbn;
       const int rest_rows = a.M - rt * 256;
-      if (rest_rows > 0 && cdiv(rest_rows, 128) * nbn <= ncu) big_rt = rt;
+      if (rest_rows > 0 && cdiv(rest_rows, 128) * nbn <= ncu && 10L * full + 6 < best) { best = 10L * full + 6; big_rt = rt; }
     }
+    if (6L * cdiv(cdiv(a.M, 128) * nbn, ncu) < best) big_rt = 0;
     GemmNtArgs g1 = a;
     g1.m_begin = 0; g1.m_end = min(a.M, big_rt * 256);
     if (big_rt > 0) hipLaunchKernelGGL((gemm_nt_pp_kernel<128, EPI, OutT>), dim3(big_rt * nbn), dim3(512), 0, s, g1);

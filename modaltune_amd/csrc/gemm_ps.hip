@@ -406,6 +406,8 @@ int mt_gemm_ps_launch(const void* A, long lda, const void* W, int M, int N, int 
   // Worth it only when every CU walks at least a tile and a half on average and the last round is not mostly idle (the tiles are of
   // equal size and statically assigned): M = 30 003 gives 1884 / 1413 / 471 tiles for N = 3072 / 2304 / 768 = 92 % of 8 / 6 / 2 rounds.
   const int rounds = cdiv(ntiles, ncu);
+  // (a SINGLE round is not worth it either: the cold prologue and the drain in the open are not amortised -- round 6, M = 12 291:
+  // 768 x 768 on 195 tiles 37.6 us against 28.2 us for the 128 x 128 kernel, N = 768 / K = 2304 86.8 against 62.6 for the ping-pong kernel)
   if (2 * ntiles < 3 * ncu || 5L * ntiles < 4L * rounds * ncu) return MT_ERR_UNSUPPORTED;
   if (ldc != N && epilogue != MT_EPI_QKV_HM) return MT_ERR_UNSUPPORTED;      // (the store descriptor spans M * N contiguous halves)
   // K = 3072 (fc2, dX of fc1): the A operand is 184 MB that the previous kernel has just written; with operands from HBM the issue of

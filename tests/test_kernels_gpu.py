@@ -150,6 +150,31 @@ def test_gemm_nt_persistent_kernel_backbone_shapes(ops, M, N, K, kind, monkeypat
     assert float((got[0].float() - got[1].float()).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,resid", [(9219, 768, 3072, True), (9219, 768, 2304, False), (8243, 768, 3072, True), (22503, 768, 3072, True),
+                                           (6147, 3072, 768, False), (21753, 768, 2304, False)])
+def test_gemm_nt_pingpong_tile_height_choice(ops, M, N, K, resid):
+    """Round 6: the ping-pong kernel picks its tile heights by cost (gemm.hip launch_nt<256>): all 256-row tiles, whole rounds of them
+    plus ONE round of 128-row tiles for the rest, or 128-row tiles only where the big ones would leave more than half the chip idle
+    (M = 9 219, N = 768: 108 big tiles or 219 small ones).  Every split writes every row exactly once: fp64 reference, ragged last tile,
+    the fc2 form with the fp32 residual epilogue and the plain fp16 one."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).half()
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    if resid:
+        r = torch.randn(M, N, device=DEV, generator=g)
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        ops.gemm_nt(A, W, out, M, N, K, epilogue=ops.EPI_BIAS_RESID, bias=bias, resid=r, ldr=N)
+        ref += r.double()
+    else:
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+        ops.gemm_nt(A, W, out, M, N, K, bias=bias)
+    torch.cuda.synchronize()
+    assert int(torch.isnan(out).sum()) == 0
+    assert rel(out, ref) < 2e-3
+
+
 @pytest.mark.parametrize("M", [333, 2600, 8300])
 def test_gemm_nt_head_major_qkv_epilogue(ops, M):
     g = rng(19)

@@ -4,9 +4,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from modaltune_amd import ops
 
-M = 30003
-shapes = [(3072, 768), (768, 3072), (2304, 768), (768, 768), (768, 2304)]
 yard = len(sys.argv) > 1 and sys.argv[1] == "yard"
+M = int(sys.argv[2]) if len(sys.argv) > 2 else 30003      # python tools/gemm_microbench.py [yard|ours] [M]
+shapes = [(3072, 768), (768, 3072), (2304, 768), (768, 768), (768, 2304)]
 g = torch.Generator(device="cuda").manual_seed(0)
 for N, K in shapes:
     A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).half()
