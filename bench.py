@@ -653,6 +653,7 @@ def leg_size(ts, eng, sizes, L, dropout, steps=8):
     return {"patches": L, "pathways": len(sizes), "tokens": eng.cfg.num_tokens, "ms_per_step": round(1e3 * dt, 3), "value": round(1.0 / dt, 3),
             "unit": "slides/s", "steps": steps, "step_tflops": round(fl["step"] / 1e12, 3),
             "step_mfma_frac": round(fl["step"] / dt / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), "pass_groups": bool(ts._split_now(L)),
+            "pass_groups_trial_ms": ts.split_trials.get(L),
             "graph_replays": ts.graph_replays - r0, "dropout": dropout}
 
 
@@ -827,7 +828,8 @@ def main():
     # are taken on the BATCHED schedule (one B = 3 pass, every kernel alone on the chip): comparable with rounds 1-4 and with
     # `rocprofv3 --kernel-trace --stats` of `MT_SPLIT_PASSES=0 python3 bench.py` (profiles/).
     pass_groups = {"on": bool(ts._split_now(L)), "groups": [list(g) for g in ts._groups], "min_patches": ts.split_min_patches,
-                   "kernel_table": "batched schedule (one kernel at a time)"}
+                   "decided_by": ("trial at capture time (ms per replayed step, both schedules captured; training state restored behind it): " + json.dumps(ts.split_trials[L])) if L in ts.split_trials
+                   else "threshold", "kernel_table": "batched schedule (one kernel at a time)"}
     split_was, ts.split_passes = ts.split_passes, False
     if pass_groups["on"]:
         run(2, graphed=False, first=nwarm + args.steps)          # (the batched geometry's workspace and gradient arena: untimed)

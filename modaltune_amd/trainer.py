@@ -37,7 +37,7 @@ class TrainStep:
     def __init__(self, engine: Engine, lr: float = 1e-4 / 20, weight_decay: float = 0.01, betas=(0.9, 0.999),
                  eps: float = 1e-8, init_scale: float = 2.0 ** 15, growth_interval: int = 2000,
                  process_group=None, task_ids: Sequence[int] = (0, 1, 2), text_rows: Sequence[int] = (0, 1, 3),
-                 graph_cache_size: int = 8, capture_after: int = 2, split_passes: bool = True):
+                 graph_cache_size: int = 8, capture_after: int = 2, split_passes="auto"):
         self.engine, self.dev = engine, engine.device
         self.wd, self.betas, self.eps = weight_decay, betas, eps
         n = engine.store.n_flat
@@ -105,6 +105,14 @@ class TrainStep:
         # same-box, hipGraph replay, ms per step batched -> split: L = 16 000: 69.5 -> 67.6; 12 000: 51.4 -> 50.6; 10 000: 41.8 -> 40.5;
         # 9 000: 37.7 -> 36.5; 8 000: 33.7 -> 32.9; 6 500: 26.6 -> 27.4 (!); 4 096: 18.2 -> 18.1; 2 500: 12.1 -> 12.2; 1 024: 8.2 -> 8.1
         self.split_min_patches = 7500
+        # ... but between ~4 000 and ~7 500 patches the winner changes with the tile rounding of every GEMM and attention launch (round 6,
+        # same box, ms batched -> groups: 4 096: 18.37 -> 17.68; 5 500: 23.47 -> 23.11; 6 500: 26.44 -> 27.09; 7 000: 28.65 -> 28.61), so a
+        # geometry that is about to be CAPTURED (it keeps coming back) is decided by measurement: both schedules run eagerly a few times
+        # with update=False semantics (nothing but the dropout counter moves, and that is restored) and the faster one is captured.
+        # Geometries that never repeat keep the threshold.  split_passes="auto" (the default) / True (threshold only) / False.
+        self.auto_split = split_passes == "auto" and os.environ.get("MT_SPLIT_PASSES", "auto") == "auto"
+        self.split_decisions: Dict[int, bool] = {}
+        self.split_trials: Dict[int, dict] = {}
         # Data-parallel schedule of a long bag (world > 1).  "groups_joined": the two pass groups with PER-BUCKET joins -- their backwards
         # run stage by stage (a stage = one interaction block); when both groups have left a block the main stream sums that bucket's
         # ranges of the two gradient sets and starts its all-reduce, the groups keep running below (DDP's overlap of the reduction with
@@ -173,6 +181,8 @@ class TrainStep:
             return False
         if self._world() > 1 and self.dp_schedule == "batched":
             return False
+        if L is not None and L in self.split_decisions and os.environ.get("MT_SPLIT_PASSES") != "force":
+            return self.split_decisions[L]
         if L is not None and L < self.split_min_patches and os.environ.get("MT_SPLIT_PASSES") != "force":
             return False
         if hasattr(eng, "forward_slide"):
@@ -450,6 +460,11 @@ class TrainStep:
             self._stext = torch.empty(tuple(text.shape), dtype=F32, device=self.dev)
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
             self._gcache.clear()
+        if (self.auto_split and not titan and self._world() == 1 and L not in self.split_decisions and B >= 3 and L >= 2048
+                and eng.cfg.is_multi and not eng.collect_taps and self.split_passes and os.environ.get("MT_SPLIT_PASSES") != "force"
+                and self._visits.get((L, L, 1, bool(eng.stochastic), None, self.force_bucket_joins), 0) >= self.capture_after
+                and not torch.cuda.is_current_stream_capturing()):
+            self._trial_split(x, coords, genes, text, clinical, L)      # (sets split_decisions[L]; training state untouched)
         if titan:
             # TITAN configuration: the gridding kernels and the one host read-back (the token count: every shape downstream depends
             # on it) run eagerly; the captured part starts at the token gather and is keyed on (patches, TOKENS).
@@ -517,6 +532,43 @@ class TrainStep:
             self._opt_graph.replay()
             self.reducer.start_param_gather()
         return self.loss
+
+    def _trial_split(self, x, coords, genes, text, clinical, L: int, reps: int = 3):
+        """Decide the schedule of bag length L by timing what will actually run: the step captured both ways (batched / two pass groups)
+        and each capture replayed `reps` times behind one untimed replay.  Eager timings do not rank the two (the groups' ~1 300 eager
+        launches are partly host-bound: 18.8 / 19.0 ms eager against 18.4 / 17.7 replayed at L = 4 096).  The replays are real steps, so
+        every piece of training state they touch -- weights, moments, step count, loss scale, dropout counter -- is saved in front and
+        restored behind them (lr is irrelevant then); the winner's capture is kept for the step that follows."""
+        import time
+        eng = self.engine
+        saved = [(t, t.clone()) for t in (eng.store.flat, self.m, self.v, self.step_dev, self.scale, self.tracker, self.found_inf, eng.rng)]
+        was_auto, self.auto_split = self.auto_split, False
+        counters = (self.graph_replays, self.eager_steps)
+        key = (L, L, 1, bool(eng.stochastic), None, self.force_bucket_joins)
+        res, caps = {}, {}
+        try:
+            for split in (False, True):
+                self.split_decisions[L] = split
+                self._gcache.pop(key, None)       # (same key for both schedules: capture afresh)
+                for i in range(reps + 2):         # capture (visit counts are already past capture_after), one untimed replay, reps timed
+                    if i == 2:
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    self.step_graphed(x, coords, genes, text, clinical=clinical)
+                torch.cuda.synchronize()
+                res["groups" if split else "batched"] = round(1e3 * (time.perf_counter() - t0) / reps, 3)
+                caps[split] = self._gcache.get(key)
+        finally:
+            self.auto_split = was_auto
+            self.graph_replays, self.eager_steps = counters
+            for t, c in saved:
+                t.copy_(c)
+            eng.refresh_trainable_caches()
+        win = res["groups"] < res["batched"]
+        self.split_decisions[L] = win
+        self.split_trials[L] = res
+        if caps.get(win) is not None:
+            self._gcache[key] = caps[win]
 
     @property
     def _graphs(self):

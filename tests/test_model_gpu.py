@@ -1269,3 +1269,41 @@ def test_three_forwards_then_three_separate_backwards(golden_dir):
     with pytest.raises(RuntimeError, match="speculate = False"):
         (ys[1] * w[1]).sum().backward()
     grads()
+
+
+def test_recurring_geometry_picks_its_pass_schedule_by_trial():
+    """Round 6: a bag length that is about to be captured is captured both ways (batched / two pass groups), each capture is replayed a few
+    times and the faster one is kept; the trial's replays are real steps, so the training state they touch (weights, moments, step count,
+    loss scale, dropout counter) is restored behind them: bit-identical before and after."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    L, seed = 3000, 13
+    sizes = synth.toy_group_sizes(6)
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)))
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, seed))
+    eng.set_stochastic(True, seed=5)
+    ts = TrainStep(eng, capture_after=1)
+    ts.set_projector(synth.projector_state(seed))
+    inp = synth.synth_inputs(L, sizes, seed, grid=128)
+    x = torch.from_numpy(inp["x"]).cuda().half().reshape(L, -1)
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"]).cuda()
+    assert ts.auto_split
+    ts.step_graphed(x, inp["coords"], genes, text)                     # eager visit
+    torch.cuda.synchronize()
+    assert L not in ts.split_decisions
+    state = [t.clone() for t in (eng.store.flat, ts.m, ts.v, ts.step_dev, ts.scale, ts.tracker, eng.rng)]
+    ts._trial_split(x, inp["coords"], genes, text, None, L)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(state, (eng.store.flat, ts.m, ts.v, ts.step_dev, ts.scale, ts.tracker, eng.rng)))
+    tr = ts.split_trials[L]
+    assert set(tr) == {"batched", "groups"} and ts.split_decisions[L] == (tr["groups"] < tr["batched"])
+    del ts.split_decisions[L]
+    ts.step_graphed(x, inp["coords"], genes, text)                     # this visit captures: the trial runs first
+    assert L in ts.split_decisions and ts._split_now(L) == ts.split_decisions[L]
+    losses = [float(ts.step_graphed(x, inp["coords"], genes, text)) for _ in range(3)]
+    assert ts.graph_replays >= 3 and all(np.isfinite(losses))
+    assert (ts._pass_streams is not None) or not ts.split_decisions[L]
