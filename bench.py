@@ -398,6 +398,8 @@ def run_titan(args, steps=None, warmup=None, patches=None, ragged=None, cpu_base
         "launch": ("hipGraph replay per (patches, tokens) geometry -- the gridding kernels and the token-count read-back stay eager; a bag length "
                    "that has not been seen three times runs the eager schedule" if graphed else "eager"), "graph_replays": replays,
         "kernel_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:14]},
+        "pass_groups": {"by_tokens": {str(k): {"groups": bool(v), **ts.split_trials.get(k, {})} for k, v in sorted(ts.split_decisions.items())},
+                        "how": "each recurring geometry captured both ways at capture time, the faster kept (TrainStep._trial_split)"},
     }
     if args.kernel_times:
         fam = {}
@@ -520,7 +522,7 @@ def _leg(fn):
 def _brief(rec):
     """Sub-record form of a leg's full JSON line."""
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "loss", "step_tflops", "step_mfma_frac", "roofline",
-            "roofline_kernels", "launch", "kernel_ms_per_step", "graph_replays", "optimizer", "optimizer_steps_fused", "torch_adamw", "host_enqueue_ms_per_step", "task_tokens_read_back")
+            "roofline_kernels", "launch", "kernel_ms_per_step", "pass_groups", "graph_replays", "optimizer", "optimizer_steps_fused", "torch_adamw", "host_enqueue_ms_per_step", "task_tokens_read_back")
     return {k: rec[k] for k in keep if k in rec}
 
 

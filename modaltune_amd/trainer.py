@@ -78,6 +78,7 @@ class TrainStep:
         self._pool = None                   # graph memory pool shared by all captures (see _capture)
         self._cap_stream = None
         self._cap = None                    # state of a segmented capture in progress
+        self._trial_keep: list = []         # captures a schedule trial holds outside the LRU (they keep the shared graph pool alive)
         self._static_key = None
         self.graph_replays = 0
         self.eager_steps = 0
@@ -175,6 +176,22 @@ class TrainStep:
         else:
             self.reducer.start(b)
 
+    def _can_split(self) -> bool:
+        """The pass groups are possible at all for this engine (multi-task model, no per-block taps; TITAN: the native backbone with its
+        native embedding)."""
+        eng = self.engine
+        if not (self.split_passes and eng.cfg.is_multi and not eng.collect_taps):
+            return False
+        if hasattr(eng, "forward_slide"):
+            # TITAN configuration: possible (native backbone with its native embedding) but never a win -- round 6, every geometry of the
+            # bench rotation tried both ways, ms per replayed step batched / groups: 2 516 tokens 8.03 / 9.05, 3 027: 9.40 / 10.20,
+            # 4 001: 12.42 / 13.27, 4 589: 14.50 / 14.78, 5 491: 18.10 / 18.56, 6 061: 19.96 / 20.83 (twice the token-side launches for
+            # half-sized big kernels) -- so no trial is spent on it; MT_SPLIT_PASSES=force still runs it
+            bb = getattr(eng, "backbone", None)
+            return bool(os.environ.get("MT_SPLIT_PASSES") == "force" and getattr(eng, "native", False) and bb is not None
+                        and getattr(bb, "embed_w", None) is not None)
+        return True
+
     def _split_now(self, L: Optional[int] = None) -> bool:
         eng = self.engine
         if not (self.split_passes and eng.cfg.is_multi and not eng.collect_taps):
@@ -182,7 +199,7 @@ class TrainStep:
         if self._world() > 1 and self.dp_schedule == "batched":
             return False
         if L is not None and L in self.split_decisions and os.environ.get("MT_SPLIT_PASSES") != "force":
-            return self.split_decisions[L]
+            return self.split_decisions[L] and self._can_split()
         if L is not None and L < self.split_min_patches and os.environ.get("MT_SPLIT_PASSES") != "force":
             return False
         if hasattr(eng, "forward_slide"):
@@ -460,11 +477,6 @@ class TrainStep:
             self._stext = torch.empty(tuple(text.shape), dtype=F32, device=self.dev)
             self._sclin = torch.empty(1, eng.cfg.clinfeat_dim, dtype=F32, device=self.dev) if eng.cfg.clinical else None
             self._gcache.clear()
-        if (self.auto_split and not titan and self._world() == 1 and L not in self.split_decisions and B >= 3 and L >= 2048
-                and eng.cfg.is_multi and not eng.collect_taps and self.split_passes and os.environ.get("MT_SPLIT_PASSES") != "force"
-                and self._visits.get((L, L, 1, bool(eng.stochastic), None, self.force_bucket_joins), 0) >= self.capture_after
-                and not torch.cuda.is_current_stream_capturing()):
-            self._trial_split(x, coords, genes, text, clinical, L)      # (sets split_decisions[L]; training state untouched)
         if titan:
             # TITAN configuration: the gridding kernels and the one host read-back (the token count: every shape downstream depends
             # on it) run eagerly; the captured part starts at the token gather and is keyed on (patches, TOKENS).
@@ -477,6 +489,11 @@ class TrainStep:
             for nb, sl in list(zip(gB, self._group_slots))[1:]:
                 eng._workspace(nb, L, slot=sl)    # (all groups' workspaces exist -- and have grown -- before anything is captured)
             eng.stage_inputs(x, coords, B=gB[0])  # (may grow the workspace: bumps eng.generation)
+        if self.auto_split and Lv not in self.split_decisions and B >= 3 and Lv >= 2048 and self._world() == 1 and self._can_split():
+            # this geometry's schedule is still to be decided by a trial (below, on the visit that captures it): the workspaces of BOTH
+            # schedules exist and have grown NOW, on an eager visit -- a growth bumps eng.generation and retires every capture
+            for nb, sl in [(B, 0)] + list(zip([b - a for a, b in self._groups], self._group_slots)):
+                eng._workspace(nb, Lv, slot=sl)
         self._wait_params()                       # last step's sharded parameter all-gather ran under the staging above
         self._sgenes.copy_(gflat, non_blocking=True)
         self._stext.copy_(text, non_blocking=True)
@@ -491,6 +508,11 @@ class TrainStep:
         # (the data-parallel schedule is part of the key: bench.py --gpus N times the three schedules one after the other)
         key = (L, Lv, world, bool(eng.stochastic), self.dp_schedule if world > 1 else None, self.force_bucket_joins)
         ent = self._gcache.get(key)
+        if (self.auto_split and world == 1 and Lv not in self.split_decisions and B >= 3 and Lv >= 2048 and self._can_split()
+                and (ent is None or ent.segs is None) and self._visits.get(key, 0) >= self.capture_after
+                and not torch.cuda.is_current_stream_capturing()):
+            self._trial_split(x, coords, genes, text, clinical, Lv, key)     # (sets split_decisions[Lv]; training state untouched)
+            return self.step_graphed(x, coords, genes, text, clinical=clinical)
 
         def fwd_bwd():
             self._fwd_bwd(None, None, self._sgenes, self._stext, self._sclin, staged_geometry=(B, Lv))
@@ -533,7 +555,7 @@ class TrainStep:
             self.reducer.start_param_gather()
         return self.loss
 
-    def _trial_split(self, x, coords, genes, text, clinical, L: int, reps: int = 3):
+    def _trial_split(self, x, coords, genes, text, clinical, L: int, key: tuple, reps: int = 3):
         """Decide the schedule of bag length L by timing what will actually run: the step captured both ways (batched / two pass groups)
         and each capture replayed `reps` times behind one untimed replay.  Eager timings do not rank the two (the groups' ~1 300 eager
         launches are partly host-bound: 18.8 / 19.0 ms eager against 18.4 / 17.7 replayed at L = 4 096).  The replays are real steps, so
@@ -544,7 +566,6 @@ class TrainStep:
         saved = [(t, t.clone()) for t in (eng.store.flat, self.m, self.v, self.step_dev, self.scale, self.tracker, self.found_inf, eng.rng)]
         was_auto, self.auto_split = self.auto_split, False
         counters = (self.graph_replays, self.eager_steps)
-        key = (L, L, 1, bool(eng.stochastic), None, self.force_bucket_joins)
         res, caps = {}, {}
         try:
             for split in (False, True):
@@ -558,7 +579,10 @@ class TrainStep:
                 torch.cuda.synchronize()
                 res["groups" if split else "batched"] = round(1e3 * (time.perf_counter() - t0) / reps, 3)
                 caps[split] = self._gcache.get(key)
+                if caps[split] is not None:
+                    self._trial_keep.append(caps[split])
         finally:
+            self._trial_keep = []
             self.auto_split = was_auto
             self.graph_replays, self.eager_steps = counters
             for t, c in saved:
@@ -587,7 +611,7 @@ class TrainStep:
         # blocks an evicted (or still cached) geometry's temporaries occupied.  A fresh pool per capture left every evicted graph's
         # segments reserved-but-unusable until the allocator's out-of-memory sweep: +0.24 GiB per recapture at L ~ 4 000 when more
         # lengths rotate than the LRU holds (tools/soak.py).
-        if self._pool is None or not (self._opt_graph is not None or any(e.segs for e in self._gcache.values())):
+        if self._pool is None or not (self._opt_graph is not None or any(e.segs for e in list(self._gcache.values()) + self._trial_keep)):
             self._pool = torch.cuda.graph_pool_handle()      # (a pool dies with the last graph captured into it: take a fresh handle)
         pool = self._pool
         segs = []

@@ -1296,12 +1296,13 @@ def test_recurring_geometry_picks_its_pass_schedule_by_trial():
     torch.cuda.synchronize()
     assert L not in ts.split_decisions
     state = [t.clone() for t in (eng.store.flat, ts.m, ts.v, ts.step_dev, ts.scale, ts.tracker, eng.rng)]
-    ts._trial_split(x, inp["coords"], genes, text, None, L)
+    ts._trial_split(x, inp["coords"], genes, text, None, L, (L, L, 1, True, None, False))
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(state, (eng.store.flat, ts.m, ts.v, ts.step_dev, ts.scale, ts.tracker, eng.rng)))
     tr = ts.split_trials[L]
     assert set(tr) == {"batched", "groups"} and ts.split_decisions[L] == (tr["groups"] < tr["batched"])
     del ts.split_decisions[L]
+    ts._gcache.clear()
     ts.step_graphed(x, inp["coords"], genes, text)                     # this visit captures: the trial runs first
     assert L in ts.split_decisions and ts._split_now(L) == ts.split_decisions[L]
     losses = [float(ts.step_graphed(x, inp["coords"], genes, text)) for _ in range(3)]
