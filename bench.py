@@ -30,10 +30,10 @@ CPU_REFERENCE = {"value": 0.0054, "unit": "slides/s", "cores": 8, "kind": "refer
                            "8-core build container: 185.6 s/slide (the reference cannot travel to the GPU box)"}
 # rocprofv3 --pmc passes of the dominant kernel cannot run inside this script (one counter group per run, gpurun refuses
 # tracing + PMC together): the committed summary file is parsed at run time instead of a literal
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_hbm_attn_bwd.txt")
-PMC_TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r04_pmc_hbm_attn_bwd.txt")
-PMC_TRAFFIC_DENSE = os.path.join(ROOT, "profiles", "r05_pmc_dense_attn.txt")              # (the build with the XCD-balanced work mapping)
-PMC_TRAFFIC_DENSE_FALLBACK = os.path.join(ROOT, "profiles", "r04_pmc_dense_attn.txt")      # tools/dense_microbench.py geometry: N = 4097, 3 passes
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_hbm_attn_bwd.txt")
+PMC_TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r05_pmc_hbm_attn_bwd.txt")
+PMC_TRAFFIC_DENSE = os.path.join(ROOT, "profiles", "r06_pmc_dense_attn.txt")
+PMC_TRAFFIC_DENSE_FALLBACK = os.path.join(ROOT, "profiles", "r05_pmc_dense_attn.txt")      # tools/dense_microbench.py geometry: N = 4097, 3 passes
 
 
 def parse_args():

@@ -7,6 +7,10 @@ out=gpurun_out/prof_$tag; mkdir -p $out
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 python bench.py --kernel-times > $out/bench.json 2> $out/kernel_times.txt
 python bench.py --no-cpu-baseline --no-legs --ragged > $out/bench_ragged.json 2>/dev/null
+# the mid-size regime: per-kernel table at L = 4 096 on the batched schedule, and the line as the step runs it
+MT_SPLIT_PASSES=0 python bench.py --patches 4096 --kernel-times --no-legs --no-cpu-baseline > $out/bench_L4096_batched.json 2> $out/L4096_kernel_times.txt
+python bench.py --patches 4096 --no-legs --no-cpu-baseline > $out/bench_L4096.json 2>/dev/null
+python bench.py --pathways real --no-legs --no-cpu-baseline > $out/bench_real_pathways.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-legs --eager > $out/bench_eager.json 2>/dev/null
 # kernel stats on the BATCHED schedule (every kernel alone on the chip: what `roofline` / `roofline_kernels` are taken on) ...
 export MT_SPLIT_PASSES=0
