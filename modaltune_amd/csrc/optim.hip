@@ -302,7 +302,7 @@ extern "C" int mt_row_absmax_f32(const float* x, float* out, int M, int D, mt_st
   return MT_OK;
 }
 
-extern "C" int mt_version(void) { return 200; }
+extern "C" int mt_version(void) { return 210; }      // (2.1: mt_build_id; the binary itself is identified by mt_build_id(), not by this number)
 
 extern "C" const char* mt_status_string(int status) {
   switch (status) {
