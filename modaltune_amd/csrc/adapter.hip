@@ -507,18 +507,28 @@ __global__ __launch_bounds__(256) void extract_attn_bwd_kernel(const float* __re
 // token-side products, so its latency is exposed.  256 threads = 64 tokens per sweep: 13 us at T = 65, the 65th token costs a
 // whole second sweep.)
 MT_DEVINL f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Score rows of the forward: T entries padded to a multiple of four, row stride S1 = 4 x odd >= that (sixteen tokens of a wave then start
+// on sixteen different 16-byte bank groups), so that the value sweep reads FOUR probabilities with one 16-byte read -- every LDS read of
+// that loop is in the 8 / 16-byte banking class (common.h: no counted lgkmcnt wait may span both classes).
+MT_DEVINL int mha_t4(int T) { return (T + 3) & ~3; }
+MT_DEVINL int mha_s1(int T) { const int t4 = mha_t4(T); return ((t4 >> 2) & 1) ? t4 : t4 + 4; }
 __global__ __launch_bounds__(512) void token_mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             int T, int E, int heads, float* __restrict__ out, float* __restrict__ probs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int T4 = mha_t4(T), S1 = mha_s1(T);
   float* ks = smem;                 // [T][16]
-  float* vs = ks + T * AD;
-  float* ss = vs + T * AD;          // [T][T + 1]
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, sub = tid & 3, S1 = T + 1;
-  for (int i = tid; i < T * 4; i += 512) {
+  float* vs = ks + T * AD;          // [T4][16], rows T .. T4 - 1 zero
+  float* ss = vs + T4 * AD;         // [T][S1], entries T .. T4 - 1 of a row zero
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, sub = tid & 3;
+  for (int i = tid; i < T4 * 4; i += 512) {
     const int tt = i >> 2, c = (i & 3) * 4;
-    const long o = ((long)b * T + tt) * E + h * AD + c;
-    *reinterpret_cast<f32x4*>(ks + tt * AD + c) = ld4(k + o);
-    *reinterpret_cast<f32x4*>(vs + tt * AD + c) = ld4(v + o);
+    if (tt < T) {
+      const long o = ((long)b * T + tt) * E + h * AD + c;
+      *reinterpret_cast<f32x4*>(ks + tt * AD + c) = ld4(k + o);
+      *reinterpret_cast<f32x4*>(vs + tt * AD + c) = ld4(v + o);
+    } else {
+      *reinterpret_cast<f32x4*>(vs + tt * AD + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
   }
   const int t = tid >> 2;
   const bool act = t < T;
@@ -543,6 +553,7 @@ __global__ __launch_bounds__(512) void token_mha_fwd_kernel(const float* __restr
       ss[t * S1 + j] = s;
       mx = fmaxf(mx, s);
     }
+    if (T + sub < T4) ss[t * S1 + T + sub] = 0.f;      // (the row's padding: at most one entry per thread)
     mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
     float l = 0.f;
@@ -555,10 +566,13 @@ __global__ __launch_bounds__(512) void token_mha_fwd_kernel(const float* __restr
   }
   __syncthreads();          // a row's four writers -> its four readers
   if (act) {
+    // value sweep, four keys per step: one 16-byte read of the row's probabilities, four 16-byte value rows (all one banking class)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // (4-byte LDS reads only: the 16-byte value rows next to the 4-byte probabilities put both banking classes in flight, and hipcc
-    // consumed them behind counted lgkmcnt waits -- unsafe beside another stream's transposed LDS reads: lds_f32, common.h)
-    for (int j = 0; j < T; ++j) acc += lds_f32(&ss[t * S1 + j]) * lds_f32x4_by_dword(vs + j * AD + 4 * sub);
+    for (int j = 0; j < T4; j += 4) {
+      const f32x4 p4 = ld4(ss + t * S1 + j);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += p4[u] * ld4(vs + (j + u) * AD + 4 * sub);
+    }
     *reinterpret_cast<f32x4*>(out + ((long)b * T + t) * E + h * AD + 4 * sub) = acc;
   }
 }
@@ -699,7 +713,8 @@ extern "C" int mt_token_mha_fwd(const float* q, const float* k, const float* v, 
                                 float* out, float* probs, mt_stream_t stream) {
   const float* ps[] = {q, k, v, out};
   if (!mha_ptrs_ok(ps, 4, E) || !probs || B < 1 || T < 1 || T > TMAX || E != heads * AD) return MT_ERR_BAD_ARG;
-  const size_t shm = sizeof(float) * (2 * T * AD + T * (T + 1));
+  const int T4 = (T + 3) & ~3, S1 = ((T4 >> 2) & 1) ? T4 : T4 + 4;      // (mha_t4 / mha_s1 of the kernel)
+  const size_t shm = sizeof(float) * ((size_t)T * AD + (size_t)T4 * AD + (size_t)T * S1);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)token_mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

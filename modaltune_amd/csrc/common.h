@@ -22,8 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // registers, wrong sums, once in ~10 launches of mt_token_mha_fwd beside mt_gemm_tn_f16 (round 6; tools/diag/victim_stress2.py,
 // profiles/r06_lds_counted_wait.txt).  The same instructions behind ONE full wait, or as 4-byte reads only, never failed.
 // hipcc places its waits itself (an asm wait does not hold back register-only arithmetic), so the token-side kernels whose loops mixed
-// the two classes read through these helpers instead: `volatile` 4-byte reads are never merged into 8 / 16-byte ones, every LDS read
-// of the loop is of ONE class and its counted waits mean what they say.  tests/test_isa_lds_waits.py scans the ISA of every kernel
+// the two classes keep ONE class per loop instead -- either everything 16 bytes wide (mt_token_mha_fwd: padded score rows), or through
+// these helpers: `volatile` 4-byte reads are never merged into 8 / 16-byte ones -- and their counted waits mean what they say.  tests/test_isa_lds_waits.py scans the ISA of every kernel
 // for the pattern (tools/diag/lds_wait_scan.py).
 MT_DEVINL float lds_f32(const float* p) { return *reinterpret_cast<const volatile float*>(p); }
 MT_DEVINL f32x4 lds_f32x4_by_dword(const float* p) {
