@@ -752,12 +752,27 @@ def main():
         torch.cuda.synchronize()
 
     nwarm = max(args.warmup, len(slides) if args.ragged else 3)   # 2 eager visits + the capture step (same geometry)
+    warm_fallback = None
     try:
         run(nwarm)
     except Exception as e:            # graph capture unavailable -> same arithmetic with eager launches
-        if args.eager or world > 1:   # multi-rank: a capture failure must not pass unnoticed (ranks could also diverge on it):
+        if world > 1 and not args.eager and ts.dp_schedule != "batched" and "MT_DP_SCHEDULE" not in os.environ:
+            # the two-stream data-parallel schedule could not be captured here (it has never run over RCCL before the driver's node):
+            # the same code fails the same way on every rank, so all of them fall back to the batched schedule -- and the line says so
+            warm_fallback = f"{ts.dp_schedule} failed in warm-up ({type(e).__name__}: {e}"[:300] + "); batched schedule"
+            print(f"[bench] {warm_fallback}", file=sys.stderr)
+            os.environ["MT_DP_SCHEDULE"] = "batched"
+            ts.dp_schedule = "batched"
+            ts._gcache.clear(); ts._cap = None
+            ts.reducer.pending.clear(); ts.reducer.started.clear()
+            torch.cuda.synchronize()
+            run(nwarm)
+        elif args.eager or world > 1:   # multi-rank: a capture failure must not pass unnoticed (ranks could also diverge on it):
             raise                     # the run fails with a non-zero exit code; `--eager` is the explicit way to time eager launches
-        print(f"[bench] hipGraph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+        else:
+            warm_fallback = f"hipGraph path failed ({type(e).__name__}: {e})"[:300] + "; eager launches"
+    if warm_fallback is not None and warm_fallback.endswith("eager launches"):
+        print(f"[bench] {warm_fallback}", file=sys.stderr)
         args.eager = True
         ts._gcache.clear()
         ts._cap = None
@@ -773,7 +788,7 @@ def main():
         torch.distributed.all_reduce(probe)
         comm = {"ranks_seen_by_all_reduce": int(round(float(probe))), "backend": torch.distributed.get_backend(),
                 "bucket_bytes": [4 * sum(n for _, n in bk) for bk in ts.reducer.buckets],
-                "last_bucket_sharded": bool(ts.reducer.sharded)}
+                "last_bucket_sharded": bool(ts.reducer.sharded), "warmup_fallback": warm_fallback}
         if comm["ranks_seen_by_all_reduce"] != world:
             raise RuntimeError(f"all_reduce of ones returned {float(probe)} on a world of {world}")
         # Which data-parallel schedule of a long bag is fastest HERE (interconnect, payload, bag length)?  TrainStep.dp_schedule:
@@ -788,19 +803,34 @@ def main():
         timings = {}
         for sched in cands:
             ts.dp_schedule = sched
+            steps_before = int(ts.step_dev)
+            try:
+                run(3, first=nwarm)                  # eager visits + capture of this schedule's graphs
+                ts.comm_events = []
+                barrier()
+                t0 = time.perf_counter()
+                run(4, first=nwarm)
+                barrier()
+            except Exception as e:                   # (the same code on every rank: a schedule that cannot be captured here fails everywhere;
+                if len(cands) == 1:                  # the others are still timed.  Nothing is hidden: the record names the error)
+                    raise
+                timings[sched] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                ts._gcache.clear(); ts._cap = None
+                ts.reducer.pending.clear(); ts.reducer.started.clear()
+                ts.comm_events = None
+                torch.cuda.synchronize()
+                extra_steps += int(ts.step_dev) - steps_before
+                continue
             extra_steps += 7
-            run(3, first=nwarm)                      # eager visits + capture of this schedule's graphs
-            ts.comm_events = []
-            barrier()
-            t0 = time.perf_counter()
-            run(4, first=nwarm)
-            barrier()
             tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if args.backend != "nccl" else dev)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             ev, ts.comm_events = ts.comm_events, None
             exposed = [a.elapsed_time(b) for k, a, b in ev if k == "grad"]
             timings[sched] = {"ms_per_step": round(1e3 * float(tt) / 4, 3), "comm_exposed_ms_this_rank": round(sum(exposed) / max(1, len(exposed)), 3)}
-        chosen = min(timings, key=lambda k: timings[k]["ms_per_step"])
+        ok = {k: v for k, v in timings.items() if "ms_per_step" in v}
+        if not ok:
+            raise RuntimeError(f"no data-parallel schedule could be timed: {timings}")
+        chosen = min(ok, key=lambda k: ok[k]["ms_per_step"])
         ts.dp_schedule = chosen
         comm["schedule_chosen"], comm["schedule_timings"] = chosen, timings
         comm["schedule_how"] = ("each candidate captured, then 4 replayed steps between barriers, MAX over ranks; the timed region below runs the "
