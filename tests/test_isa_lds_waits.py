@@ -1,7 +1,7 @@
 """CPU: no kernel of the library consumes LDS reads of BOTH banking classes behind a counted `s_waitcnt lgkmcnt(N > 0)`.
 
-Round 6 (modaltune_amd/csrc/common.h, `lds_f32`): beside another kernel's `ds_read_b64_tr_b16` on the same CU -- the two pass groups of
-the train step on two HIP streams -- such a count was met while an older 16-byte read had not delivered lanes 48-63; mt_token_mha_fwd
+Round 6 (modaltune_amd/csrc/common.h, `lds_f32`): beside another kernel's LDS traffic on the same CU -- the two pass groups of the train
+step on two HIP streams -- such a count was met while an older 16-byte read had not delivered lanes 48-63; mt_token_mha_fwd
 then summed stale value rows once in ~10 launches beside mt_gemm_tn_f16.  The kernels that mixed the classes (prompt self-attention,
 pathway networks) now keep every LDS read of such a loop in ONE class; this test compiles every source to ISA with the build's own flags
 and scans it (tools/diag/lds_wait_scan.py), so a later edit -- or a compiler that starts merging reads differently -- cannot bring the

@@ -79,11 +79,44 @@ print("recorded", len(REC), "launches:", {n: len(v) for n, v in by_name.items()}
 
 g = torch.Generator(device="cuda").manual_seed(1)
 T, E, H = 65, 192, 12
+VICTIM = os.environ.get("VICTIM", "token_mha_fwd")
 q, k_, v = (torch.randn(1, T, E, generator=g, device="cuda") for _ in range(3))
 out, probs = torch.empty(1, T, E, device="cuda"), torch.empty(1 * H * T * T, device="cuda")
-ops.token_mha_fwd(q, k_, v, out, probs, 1, T, E, H)
+if VICTIM == "token_mha_fwd":
+    outs = [out, probs]
+
+    def victim():
+        ops.token_mha_fwd(q, k_, v, out, probs, 1, T, E, H)
+elif VICTIM == "token_mha_bwd":
+    ops.token_mha_fwd(q, k_, v, out, probs, 1, T, E, H)
+    dout = torch.randn(1, T, E, generator=g, device="cuda")
+    dq, dk, dv = (torch.empty(1, T, E, device="cuda") for _ in range(3))
+    outs = [dq, dk, dv]
+
+    def victim():
+        ops.token_mha_bwd(q, k_, v, probs, dout, dq, dk, dv, 1, T, E, H)
+elif VICTIM in ("gene_snn_fwd", "gene_snn_bwd"):
+    # the recorded launch of the step (6 pathways: the eight-workgroups-per-pathway kernels), replayed on its own tensors; the backward
+    # accumulates into the flat gradient buffer, so that is cleared in front of every run
+    n_, a_, kw_ = next((n, a, k) for n, a, k in REC if n == VICTIM)
+    if VICTIM == "gene_snn_fwd":
+        outs = [a_[7], a_[8], a_[9]]
+
+        def victim():
+            orig[VICTIM](*a_, **kw_)
+    else:
+        gbuf = torch.zeros_like(a_[1])          # a gradient buffer of its own (the aggressor's launches add into the step's)
+        a_ = (a_[0], gbuf) + tuple(a_[2:])
+        outs = [gbuf]
+
+        def victim():
+            gbuf.zero_()
+            orig[VICTIM](*a_, **kw_)
+else:
+    raise SystemExit("VICTIM = token_mha_fwd | token_mha_bwd | gene_snn_fwd | gene_snn_bwd")
+victim()
 torch.cuda.synchronize()
-ref_out, ref_probs = out.clone(), probs.clone()
+refs = [t.clone() for t in outs]
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 bad = torch.zeros(2, dtype=torch.int64, device="cuda")
 
@@ -94,16 +127,17 @@ def trial(name, calls, iters):
     ci = 0
     with torch.cuda.stream(sa):
         for i in range(iters):
-            ops.token_mha_fwd(q, k_, v, out, probs, 1, T, E, H)
-            bad[0] += (out != ref_out).any()
-            bad[1] += (probs != ref_probs).any()
+            victim()
+            bad[0] += (outs[0] != refs[0]).any()
+            for t, r in zip(outs[1:], refs[1:]):
+                bad[1] += (t != r).any()
             if calls and i % 4 == 0:
                 with torch.cuda.stream(sb):
                     n, a, k = calls[ci % len(calls)]
                     orig[n](*a, **k)
                     ci += 1
     torch.cuda.synchronize()
-    print(f"{name:28s} ({len(calls):3d} recorded launches): victim wrong out {int(bad[0])} / probs {int(bad[1])} of {iters}", flush=True)
+    print(f"{name:28s} ({len(calls):3d} recorded launches): victim {VICTIM} wrong first output {int(bad[0])} / other outputs {int(bad[1])} of {iters}", flush=True)
 
 
 ONLY = os.environ.get("ONLY")
