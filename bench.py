@@ -62,6 +62,11 @@ def parse_args():
     ap.add_argument("--optim", default="fused", choices=["fused", "torch"],
                     help="--api module: modaltune_amd.optim.AdamW (the second import of INTEGRATION.md section 1: torch.optim.AdamW's surface, one "
                          "fused launch on the model's flat buffers) or torch.optim.AdamW itself, as the reference trainer builds it")
+    ap.add_argument("--dp-rehearsal", action="store_true",
+                    help="--gpus 1 only: a ONE-rank process group on --backend (default nccl = RCCL) with MT_DP_REHEARSE=1 -- every collective of "
+                         "the data-parallel step is issued (per-bucket all-reduce from inside the backward, reduce-scatter / all-gather of the "
+                         "sharded bucket, flag MAX), the three schedules are captured and timed and `comm` is reported: what the data-parallel "
+                         "machinery costs on one GPU, and the only way to run the RCCL branches on a one-GPU box")
     ap.add_argument("--config", default="gigapath", choices=["gigapath", "titan"],
                     help="gigapath: BASELINE config 2 (the headline metric); titan: BASELINE config 4 (TITAN backbone configuration, "
                          "--patches foreground cells, --ragged: mixed bag lengths) -- a separate JSON line, never the headline")
@@ -710,7 +715,13 @@ def main():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the hot path)")
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if args.dp_rehearsal:
+        if world != 1:
+            raise SystemExit("--dp-rehearsal is a one-rank run (--gpus 1)")
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"], os.environ["MT_DP_REHEARSE"] = "127.0.0.1", str(port_), "1"
+    dp_on = world > 1 or args.dp_rehearsal
+    if dp_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -756,7 +767,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -765,7 +776,7 @@ def main():
     try:
         run(nwarm)
     except Exception as e:            # graph capture unavailable -> same arithmetic with eager launches
-        if world > 1 and not args.eager and ts.dp_schedule != "batched" and "MT_DP_SCHEDULE" not in os.environ:
+        if dp_on and not args.eager and ts.dp_schedule != "batched" and "MT_DP_SCHEDULE" not in os.environ:
             # the two-stream data-parallel schedule could not be captured here (it has never run over RCCL before the driver's node):
             # the same code fails the same way on every rank, so all of them fall back to the batched schedule -- and the line says so
             warm_fallback = f"{ts.dp_schedule} failed in warm-up ({type(e).__name__}: {e}"[:300] + "); batched schedule"
@@ -776,7 +787,7 @@ def main():
             ts.reducer.pending.clear(); ts.reducer.started.clear()
             torch.cuda.synchronize()
             run(nwarm)
-        elif args.eager or world > 1:   # multi-rank: a capture failure must not pass unnoticed (ranks could also diverge on it):
+        elif args.eager or dp_on:   # multi-rank: a capture failure must not pass unnoticed (ranks could also diverge on it):
             raise                     # the run fails with a non-zero exit code; `--eager` is the explicit way to time eager launches
         else:
             warm_fallback = f"hipGraph path failed ({type(e).__name__}: {e})"[:300] + "; eager launches"
@@ -791,7 +802,7 @@ def main():
     eng.check_inputs()
     comm = None
     extra_steps = 0
-    if world > 1:
+    if dp_on:
         # the collective path is real before anything is timed: an all-reduce of ones must come back as the world size
         probe = torch.ones(1, device=dev) if args.backend == "nccl" else torch.ones(1)
         torch.distributed.all_reduce(probe)
@@ -884,7 +895,7 @@ def main():
     # replayed -- what the ~220 small dependent launches cost INSIDE the replayed step (HIP events around each launch of the eager pass
     # above add the event overhead to every one of them: that table's `token_side` row is an upper bound)
     token_graph = None
-    if world == 1 and not args.ragged:
+    if not dp_on and not args.ragged:
         try:
             ops.RECORD, ops.RECORD_KEEP[:] = [], []
             run(1, graphed=False, first=nwarm + args.steps + prof_steps)
@@ -913,7 +924,7 @@ def main():
             ops.RECORD = None
             ops.RECORD_KEEP[:] = []
     ts.split_passes = split_was
-    if world > 1:
+    if dp_on:
         host = args.backend != "nccl"
         tt = torch.tensor([dt, comm["comm_exposed_ms"], comm["param_gather_exposed_ms"]], device="cpu" if host else dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -965,7 +976,9 @@ def main():
                                       f"per layer and on the Extractor FFN (Philox masks regenerated in backward)")
                                    + ("; ragged: bag lengths " + "/".join(str(v) for v in lengths) + " in rotation" if args.ragged else ""),
                        "patches": L, "tokens": T, "parallelism": f"dp{world}", "dropout": not args.no_dropout, "pass_groups": pass_groups,
-                       "backend": args.backend if world > 1 else None},
+                       "backend": args.backend if dp_on else None,
+                       **({"dp_rehearsal": "ONE rank: every collective of the data-parallel step issued on a one-rank communicator "
+                                           "(MT_DP_REHEARSE=1); `value` is NOT a scaling point"} if args.dp_rehearsal else {})},
             "loss": loss, "skipped_steps": skipped,
             "step_tflops": fl["step"] / 1e12, "step_mfma_frac": fl["step"] * value / world / 1e12 / PEAK_F16_MFMA_TFLOPS,
             "roofline": {"kernel": "dilated_attn_bwd_kv_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS,
@@ -992,7 +1005,7 @@ def main():
         from modaltune_amd import _lib
         bi = _lib.build_info()       # which binary this line timed: the sha256 of (csrc/*, include/*, flags) it was built from
         out["build_id"], out["build_id_matches_tree"], out["lib"] = bi["build_id"], bi["build_id_matches_tree"], bi["lib"]
-        default_line = world == 1 and not (args.ragged or args.eager)
+        default_line = world == 1 and not (args.ragged or args.eager or args.dp_rehearsal)
         if default_line and not args.no_legs:
             # secondary configurations as short sub-records of the SAME driver-observed line (each <= ~10 s; never the headline)
             out["pcie_inclusive"] = _leg(lambda: leg_pcie(ts, eng, sizes, L, value))
@@ -1013,11 +1026,11 @@ def main():
             out["module_api"] = _leg(module_leg)
             torch.cuda.empty_cache()
             out["titan"] = _leg(lambda: _brief(run_titan(args, steps=16, warmup=8, patches=4096, ragged=True, cpu_baseline=False)))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.dp_rehearsal:
             out["cpu_baseline"] = cpu_baseline_leg(L, "real" if args.pathways == 331 else args.pathways)
             out["cpu_baseline_reference"] = CPU_REFERENCE
         print(json.dumps(out))
-    if world > 1:
+    if dp_on:
         torch.distributed.destroy_process_group()
 
 

@@ -7,6 +7,7 @@ gradients (utils/base_trainer.py:192-211, 283-286, 483-484).
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -34,20 +35,27 @@ def shard_indices(n_items: int, world: int, rank: int, epoch: int = 0, seed: int
     return idx[rank:total:world]
 
 
+def single_rank_rehearsal() -> bool:
+    """MT_DP_REHEARSE=1: with an initialised process group of ONE rank, issue every collective of the data-parallel step anyway (a
+    one-rank RCCL communicator runs them as copies): the only way to execute the `nccl` branches -- asynchronous all-reduce per
+    bucket, reduce-scatter / all-gather of the sharded bucket, the flag MAX, the constructor broadcast -- on a one-GPU box."""
+    return os.environ.get("MT_DP_REHEARSE") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
     """In-place SUM all-reduce of the flat gradient buffer; returns the world size (the mean is folded into the AdamW
     kernel as grad_mult = 1/world).  No-op without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     world = dist.get_world_size(group)
-    if world > 1:
+    if world > 1 or single_rank_rehearsal():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return world
 
 
 def broadcast_params_(flat: torch.Tensor, src: int = 0, group=None):
     """DDP's constructor broadcast: every rank starts from rank `src`'s trainable parameters."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank_rehearsal()):
         dist.broadcast(flat, src=src, group=group)
 
 
@@ -111,12 +119,14 @@ class GradReducer:
                  shard_last: bool = True):
         self.flat, self.buckets, self.group = flat_grad, buckets, group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # `active`: collectives are issued (world > 1, or the one-rank rehearsal); `world` stays the arithmetic world size (1 / world)
+        self.active = self.world > 1 or single_rank_rehearsal()
+        self.rank = dist.get_rank(group) if self.active else 0
         self.views = [[flat_grad[o:o + n] for o, n in bk] for bk in buckets]
         self.pending: list = []
         self.started: set = set()
         self.param = flat_param
-        self.sharded = bool(self.world > 1 and shard_last and flat_param is not None and len(buckets) > 0)
+        self.sharded = bool(self.active and shard_last and flat_param is not None and len(buckets) > 0)
         self._param_pending: list = []
         self._rs: list = []                   # (range offset, elements per rank, reduce-scatter output buffer)
         self._tails: list = []                # (offset, length) of the few elements past W * s of a range: plain all-reduce
@@ -128,11 +138,11 @@ class GradReducer:
                     self._rs.append((o, s, torch.empty(s, dtype=flat_grad.dtype, device=flat_grad.device)))
                 if n - W * s > 0:
                     self._tails.append((o + W * s, n - W * s))
-        self._host = self.world > 1 and dist.get_backend(group) == "gloo"      # rehearsal backend: RS / AG through host copies
+        self._host = self.active and dist.get_backend(group) == "gloo"      # rehearsal backend: RS / AG through host copies
 
     # -- gradient side
     def start(self, b: int):
-        if self.world == 1 or b in self.started:
+        if not self.active or b in self.started:
             return
         self.started.add(b)
         if self.sharded and b == len(self.buckets) - 1:

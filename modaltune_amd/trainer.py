@@ -168,6 +168,10 @@ class TrainStep:
     def _world(self) -> int:
         return self.reducer.world
 
+    def _dp(self) -> bool:
+        """Collectives are part of the step (world > 1, or dp.single_rank_rehearsal())."""
+        return self.reducer.active
+
     def _on_grad_ready(self, block: int):
         """Engine callback from inside the backward: the gradients of interaction block `block` (and above) are final."""
         b = self._nint - 1 - block
@@ -196,7 +200,7 @@ class TrainStep:
         eng = self.engine
         if not (self.split_passes and eng.cfg.is_multi and not eng.collect_taps):
             return False
-        if self._world() > 1 and self.dp_schedule == "batched":
+        if self._dp() and self.dp_schedule == "batched":
             return False
         if L is not None and L in self.split_decisions and os.environ.get("MT_SPLIT_PASSES") != "force":
             return self.split_decisions[L] and self._can_split()
@@ -267,7 +271,7 @@ class TrainStep:
         fork.record(main)
         # per-bucket joins: the groups' backwards advance stage by stage so that a bucket's all-reduce starts as soon as BOTH groups
         # have left its interaction block (see __init__: dp_schedule)
-        joined = (self._world() > 1 and self.dp_schedule == "groups_joined" and reduce) or self.force_bucket_joins
+        joined = (self._dp() and self.dp_schedule == "groups_joined" and reduce) or self.force_bucket_joins
         eng.record_markers = bool(joined)
         calls = []
         self.buckets_started_early = 0
@@ -365,7 +369,7 @@ class TrainStep:
         if self._split_now(Lnow):
             return self._fwd_bwd_split(x, coords, genes, text, clinical, staged_geometry, reduce=reduce)
         self._wait_params()               # the all-gather of the last step's sharded parameter update (no-op otherwise)
-        eng.grad_ready_hook = self._on_grad_ready if (reduce and self._world() > 1) else None
+        eng.grad_ready_hook = self._on_grad_ready if (reduce and self._dp()) else None
         if eng.stochastic:
             ops.rng_advance(eng.rng)          # a fresh set of dropout / DropPath masks per step
         target = self.project_text(text)
@@ -489,7 +493,7 @@ class TrainStep:
             for nb, sl in list(zip(gB, self._group_slots))[1:]:
                 eng._workspace(nb, L, slot=sl)    # (all groups' workspaces exist -- and have grown -- before anything is captured)
             eng.stage_inputs(x, coords, B=gB[0])  # (may grow the workspace: bumps eng.generation)
-        if self.auto_split and Lv not in self.split_decisions and B >= 3 and Lv >= 2048 and self._world() == 1 and self._can_split():
+        if self.auto_split and Lv not in self.split_decisions and B >= 3 and Lv >= 2048 and not self._dp() and self._can_split():
             # this geometry's schedule is still to be decided by a trial (below, on the visit that captures it): the workspaces of BOTH
             # schedules exist and have grown NOW, on an eager visit -- a growth bumps eng.generation and retires every capture
             for nb, sl in [(B, 0)] + list(zip([b - a for a, b in self._groups], self._group_slots)):
@@ -499,16 +503,16 @@ class TrainStep:
         self._stext.copy_(text, non_blocking=True)
         if self._sclin is not None:
             self._sclin.copy_(clinical.reshape(1, -1), non_blocking=True)
-        world = self._world()
+        world, dp_on = self._world(), self._dp()
         if self._ggen != eng.generation:          # buffers the old captures point to are gone (visit counts stay)
             for e in self._gcache.values():
                 e.segs = e.logits = None
             self._opt_graph = None
             self._ggen = eng.generation
         # (the data-parallel schedule is part of the key: bench.py --gpus N times the three schedules one after the other)
-        key = (L, Lv, world, bool(eng.stochastic), self.dp_schedule if world > 1 else None, self.force_bucket_joins)
+        key = (L, Lv, world, bool(eng.stochastic), self.dp_schedule if dp_on else None, self.force_bucket_joins)
         ent = self._gcache.get(key)
-        if (self.auto_split and world == 1 and Lv not in self.split_decisions and B >= 3 and Lv >= 2048 and self._can_split()
+        if (self.auto_split and not dp_on and Lv not in self.split_decisions and B >= 3 and Lv >= 2048 and self._can_split()
                 and (ent is None or ent.segs is None) and self._visits.get(key, 0) >= self.capture_after
                 and not torch.cuda.is_current_stream_capturing()):
             self._trial_split(x, coords, genes, text, clinical, Lv, key)     # (sets split_decisions[Lv]; training state untouched)
@@ -543,7 +547,7 @@ class TrainStep:
                 self.reducer.start(bucket)
         self.last_logits = ent.logits
         self.graph_replays += 1
-        if world > 1:
+        if dp_on:
             e0 = self._mark()
             self.reducer.start_rest()
             self.reducer.wait()
@@ -621,7 +625,7 @@ class TrainStep:
             self._cap = {"segs": segs, "cur": g, "pool": pool}
             try:
                 fwd_bwd()
-                if world == 1:
+                if not self._dp():
                     self.optimizer_step()
             except BaseException:
                 try:
@@ -633,7 +637,7 @@ class TrainStep:
             self._cap["cur"].capture_end()
             segs.append((self._cap["cur"], None))
             self._cap = None
-            if world > 1 and self._opt_graph is None:
+            if self._dp() and self._opt_graph is None:
                 og = torch.cuda.CUDAGraph()
                 og.capture_begin(pool=pool, capture_error_mode="thread_local")
                 try:

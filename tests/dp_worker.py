@@ -52,7 +52,23 @@ def trainstep(rank, world, out):
     nseg = max(len(s) for s in ts._graphs) if ts._graphs else 0
     np.savez(out, flat=eng.store.flat.cpu().numpy(), losses=np.array(losses), replays=ts.graph_replays, nseg=nseg,
              steps=int(ts.step_dev), buckets=len(ts.reducer.buckets), early=int(ts.buckets_started_early),
-             split=int(ts._pass_streams is not None))
+             split=int(ts._pass_streams is not None), sharded=int(ts.reducer.sharded), backend=dist.get_backend())
+
+
+def seqpar_calls(rank, world, out):
+    """The two collectives of modaltune_amd.seqpar on the process group as it is (device tensors as they are on `nccl`): with one rank
+    both are identities -- what is checked is that RCCL accepts the calls (flat fp16 views, split sizes) and returns the payload."""
+    from modaltune_amd import seqpar
+    sp = seqpar.SeqParallelAttention.__new__(seqpar.SeqParallelAttention)
+    sp.dist, sp.group, sp.W, sp.rank = dist, None, world, rank
+    g = torch.Generator(device="cuda").manual_seed(3 + rank)
+    kv = torch.randn(2, 16 * 37 * 48, device="cuda", generator=g).half()
+    gathered = sp._all_gather(kv)
+    pay = torch.randn(world * 4096, device="cuda", generator=g).half()
+    recv = sp._all_to_all(pay, [4096] * world)
+    torch.cuda.synchronize()
+    np.savez(out, gather_ok=int(torch.equal(gathered[rank], kv)), shape=np.array(gathered.shape),
+             a2a_ok=int(torch.equal(recv[rank * 4096:(rank + 1) * 4096], pay[rank * 4096:(rank + 1) * 4096])), backend=dist.get_backend())
 
 
 def ragged(rank, world, out):
@@ -168,6 +184,6 @@ if __name__ == "__main__":
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        {"trainstep": trainstep, "ddp_module": ddp_module, "ragged": ragged, "titan": titan}[mode](rank, world, out)
+        {"trainstep": trainstep, "ddp_module": ddp_module, "ragged": ragged, "titan": titan, "seqpar_calls": seqpar_calls}[mode](rank, world, out)
     finally:
         dist.destroy_process_group()

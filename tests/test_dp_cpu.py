@@ -128,6 +128,47 @@ def _worker(rank, world, port, n):
         dist.destroy_process_group()
 
 
+def _rehearsal_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MT_DP_REHEARSE="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from modaltune_amd import synth
+        from modaltune_amd.config import ModelConfig
+        from modaltune_amd.engine import ParamStore
+        assert dp.single_rank_rehearsal()
+        cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)))
+        st = ParamStore(cfg, synth.toy_group_sizes(), "cpu")
+        buckets = dp.grad_buckets(st.slots, 3, st.n_flat)
+        g0 = torch.arange(st.n_flat, dtype=torch.float32) % 977
+        p0 = torch.arange(st.n_flat, dtype=torch.float32) % 13
+        for host in (True, False):
+            st.flat_grad.copy_(g0); st.flat.copy_(p0)
+            red = dp.GradReducer(st.flat_grad, buckets, flat_param=st.flat)
+            assert red.active and red.world == 1 and red.rank == 0 and red.sharded      # collectives on, arithmetic world still 1
+            red._host = host
+            red.start(1); red.start_rest()
+            assert len(red.started) == len(buckets) and (host or red.pending)
+            assert red.wait() == 1
+            assert torch.equal(st.flat_grad, g0)                                         # the sum over one rank
+            pieces = red.adam_pieces(st.n_flat)
+            assert sum(k for _, k in pieces) == st.n_flat                                # one rank owns every shard
+            for o, k in pieces:
+                st.flat[o:o + k] -= 0.5 * st.flat_grad[o:o + k]
+            red.start_param_gather(); red.wait_params()
+            assert torch.equal(st.flat, p0 - 0.5 * g0)
+        flat = g0.clone()
+        assert dp.allreduce_sum_(flat) == 1 and torch.equal(flat, g0)
+        dp.broadcast_params_(flat, 0)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_rehearsal_issues_the_collectives():
+    """MT_DP_REHEARSE=1 on a one-rank group (what `bench.py --dp-rehearsal` and the one-rank RCCL tests of tests/test_dp_gpu.py use):
+    the reducer is active and sharded with world == 1, every collective is issued and is the identity."""
+    mp.spawn(_rehearsal_worker, args=(1, _free_port()), nprocs=1, join=True)
+
+
 def test_grad_buckets_follow_the_backward_order():
     """Bucket 0 = fusion head + interaction block 2 (+ its prompt self-attention), ..., last = gene encoder / gene_pe /
     task tokens; together they tile the flat gradient buffer exactly once."""

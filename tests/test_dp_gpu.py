@@ -95,6 +95,66 @@ def test_two_rank_trainstep_with_the_batched_schedule_forced(tmp_path):
     _check_trainstep(res, nseg=4)
 
 
+@pytest.mark.parametrize("sched,nseg,split,early", [("groups_joined", 4, 1, 3), ("groups_exposed", 1, 1, 0), ("batched", 4, 0, 0)])
+def test_one_rank_rccl_rehearsal_issues_every_collective_of_the_step(tmp_path, sched, nseg, split, early):
+    """RCCL on a one-GPU box: ONE rank on the `nccl` backend with MT_DP_REHEARSE=1 (dp.single_rank_rehearsal) -- the constructor
+    broadcast, every bucket's asynchronous all-reduce from inside the (segmented, captured) backward, the sharded bucket's
+    reduce-scatter / AdamW on the shard / all-gather of the parameters and the found_inf MAX all run over a one-rank RCCL
+    communicator, under each of the three data-parallel schedules.  The sum over one rank is the identity, so the run must land
+    on the plain single-process training run of the same slide."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    (r,) = _run_ranks("trainstep", tmp_path, world=1, backend="nccl",
+                      extra_env={"MT_DP_REHEARSE": "1", "MT_SPLIT_PASSES": "force", "MT_DP_SCHEDULE": sched})
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker as W
+    from modaltune_amd import synth
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    assert str(r["backend"]) == "nccl" and int(r["sharded"]) == 1 and int(r["buckets"]) == 4
+    assert int(r["steps"]) == W.STEPS and int(r["replays"]) == W.STEPS - 1 and int(r["nseg"]) == nseg
+    assert int(r["split"]) == split and int(r["early"]) >= early
+    sizes = synth.toy_group_sizes()
+    cfg = W._cfg()
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, W.SEED))
+    ts = TrainStep(eng, lr=1e-3)
+    ts.set_projector(synth.projector_state(W.SEED))
+    slide = W._slide(0, sizes)
+    ref_losses = np.array([float(ts.step(*slide)) for _ in range(W.STEPS)])
+    torch.cuda.synchronize()
+    assert np.allclose(r["losses"], ref_losses, rtol=2e-3), (r["losses"], ref_losses)
+    d = np.abs(r["flat"] - eng.store.flat.cpu().numpy())
+    assert d.max() <= 2.0 * W.STEPS * 1e-3 + 1e-7                    # (same bars as the two-rank check below)
+    assert np.mean(d > 0.05 * 1e-3) < 0.02, (np.mean(d > 0.05 * 1e-3), d.max())
+
+
+def test_one_rank_rccl_rehearsal_of_the_sequence_parallel_collectives(tmp_path):
+    """seqpar's all_gather_into_tensor / all_to_all_single on device tensors over a one-rank RCCL communicator (the `else:` arms that
+    gloo's host staging never takes)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    (r,) = _run_ranks("seqpar_calls", tmp_path, world=1, backend="nccl")
+    assert str(r["backend"]) == "nccl" and int(r["gather_ok"]) == 1 and int(r["a2a_ok"]) == 1 and tuple(r["shape"]) == (1, 2, 16 * 37 * 48)
+
+
+def test_bench_one_rank_rccl_rehearsal():
+    """`bench.py --dp-rehearsal`: the data-parallel bench path (schedule candidates, comm record) on a one-rank RCCL communicator."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dp-rehearsal", "--patches", "7600", "--steps", "3", "--warmup", "3",
+                        "--no-cpu-baseline"], env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    c = out["comm"]
+    assert out["n_gpus"] == 1 and c["backend"] == "nccl" and c["ranks_seen_by_all_reduce"] == 1 and c["last_bucket_sharded"] is True
+    assert set(c["schedule_timings"]) == {"groups_joined", "groups_exposed", "batched"}
+    assert all("ms_per_step" in v for v in c["schedule_timings"].values()), c["schedule_timings"]
+    assert out["launch"] == "hipGraph replay" and out["skipped_steps"] == 0 and "dp_rehearsal" in out["config"]
+
+
 def _check_ragged(res):
     assert all(int(r["sharded"]) == 1 and int(r["steps"]) == 18 for r in res)
     assert np.isfinite(res[0]["losses"]).all() and np.isfinite(res[1]["losses"]).all()
