@@ -90,11 +90,16 @@ def _bridge_backward(ctx, dlogits):
             ops.absmax_scale(dl, grp.scale, 1024.0)
             store.flat_grad.zero_()
             grp.started = True
-        scaled = torch.empty_like(dl)
-        ops.axpy_dev(None, dl, grp.scale[0:1], scaled)
+        replay = getattr(ctx, "replay", None)
+        scaled = torch.empty_like(dl) if replay is None else None
+        if replay is None:
+            ops.axpy_dev(None, dl, grp.scale[0:1], scaled)
         hook, eng.grad_ready_hook = eng.grad_ready_hook, None      # (a TrainStep sharing the engine must not see this pass)
         try:
-            if split is None:
+            if replay is not None:
+                module._replay.backward(replay, lambda dst: ops.axpy_dev(None, dl, grp.scale[0:1], dst))
+                ctx.replay = None
+            elif split is None:
                 eng.backward(scaled, call=ctx.call)
             else:        # every group replays its tape on its own stream into its own gradient set; the sets are summed behind the join
                 main = torch.cuda.current_stream()
@@ -141,7 +146,14 @@ class _ModelFn(torch.autograd.Function):
         grp = module._group if need else None
         B = int(onehots.shape[0])
         L = int(x.reshape(-1, x.shape[-1]).shape[0])
-        ctx.split = None
+        ctx.split = ctx.replay = None
+        served = module._replay.forward(x, coords, genes, onehots, clinical, token) if (need and grp is not None and module._replay is not None) else None
+        if served is not None:
+            # steady state of a training loop: this geometry's forward / backward are hipGraph replays (module_graph.ModuleReplay)
+            logits, ctx.replay = served
+            ctx.module, ctx.call, ctx.group, ctx.has_pred = module, "replay", grp, False
+            ctx.batched = module.is_multi and logits.shape[0] > 1
+            return logits, torch.zeros((), dtype=F32, device=logits.device)
         if need and grp is not None and B >= 3 and L >= module.split_min_patches and module.split_passes and not eng.collect_taps:
             # A batched pass over a long bag runs as TWO concurrent pass groups (B - B // 3 and B // 3 task passes on two HIP streams:
             # trainer.TrainStep._fwd_bwd_split has the measurements) -- own workspace, tape, dropout masks and gradient set per group,
@@ -214,6 +226,8 @@ class LongNetGeneAdapter(Aggregator):
         self._group = self._token = None
         self._spec = self._hist = self._spec_rows = None      # speculative batching of the per-task calls (_forward_one_task)
         self.speculate = True                                 # (False: every call runs on its own; the calls of a step still share one hand-over)
+        from .module_graph import ModuleReplay
+        self._replay = ModuleReplay(self)                     # hipGraph replay of a recurring geometry's forward / backward
         self._init_nosync()
         self.train(True)
 
