@@ -9,6 +9,7 @@
 // (global_load_lds_dwordx4, issued for tile t+1 before the MFMAs of tile t; one barrier per K-tile), XOR-swizzled
 // 128-B rows so the ds_read_b128 fragment reads are bank-conflict free.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -482,6 +483,9 @@ int launch_nt(const GemmNtArgs& a, hipStream_t s) {
       if (rest_rows > 0 && cdiv(rest_rows, 128) * nbn <= ncu && 10L * full + 6 < best) { best = 10L * full + 6; big_rt = rt; }
     }
     if (6L * cdiv(cdiv(a.M, 128) * nbn, ncu) < best) big_rt = 0;
+    static const char* force = getenv("MT_GEMM_FORCE");    // experiments (tools/gemm_candidates.py)
+    if (force && !strcmp(force, "pp_big")) big_rt = nrt;
+    if (force && !strcmp(force, "pp_small")) big_rt = 0;
     GemmNtArgs g1 = a;
     g1.m_begin = 0; g1.m_end = min(a.M, big_rt * 256);
     if (big_rt > 0) hipLaunchKernelGGL((gemm_nt_pp_kernel<128, EPI, OutT>), dim3(big_rt * nbn), dim3(512), 0, s, g1);
@@ -509,7 +513,17 @@ int launch_nt_bn(const GemmNtArgs& a, hipStream_t s) {
   // N = 192 / 384 / 576 (adapter projections) tile exactly with BN = 64; everything else uses 128
   if (a.N % 128 != 0) return launch_nt<64, EPI, OutT>(a, s);
   static const bool pp_ok = getenv("MT_GEMM_NOPP") == nullptr;
+  static const char* force = getenv("MT_GEMM_FORCE");      // experiments (tools/gemm_candidates.py)
+  if (force && !strncmp(force, "pp", 2) && a.N % 256 == 0) return launch_nt<256, EPI, OutT>(a, s);
+  if (force && !strcmp(force, "k128")) return launch_nt<128, EPI, OutT>(a, s);
   if (pp_ok && a.N % 256 == 0 && a.M >= 8192 && (a.N >= 2304 || a.K >= 2304)) return launch_nt<256, EPI, OutT>(a, s);
+  // the small square shape (N = K = 768: attention output projection and its dX) where 256-row tiles fill their rounds: M = 18 435: 32.9 us
+  // against 38.6 for the 128 x 128 kernel, M = 20 002 (the B = 2 pass group at 10 000 patches): 33.3 against 36.3; at half-filled rounds
+  // (M = 10 001: 26.7 against 22.4) the small tiles stay (tools/gemm_candidates.py, round 6)
+  if (pp_ok && a.N % 256 == 0 && a.M >= 8192) {
+    const long tiles = (long)cdiv(a.M, 256) * (a.N / 256), ncu = 256;
+    if (5 * tiles >= 4 * cdiv(tiles, ncu) * ncu) return launch_nt<256, EPI, OutT>(a, s);
+  }
   return launch_nt<128, EPI, OutT>(a, s);
 }
 

@@ -27,6 +27,7 @@
 // vmcnt is one in-order counter for loads and stores: the wait names the number of YOUNGER operations that may stay in flight (the
 // pieces of slice q + 2 -- with the bias piece if that slice opens a tile -- and the drain stores of slices q - 2 and q - 1).
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -408,13 +409,17 @@ int mt_gemm_ps_launch(const void* A, long lda, const void* W, int M, int N, int 
   const int rounds = cdiv(ntiles, ncu);
   // (a SINGLE round is not worth it either: the cold prologue and the drain in the open are not amortised -- round 6, M = 12 291:
   // 768 x 768 on 195 tiles 37.6 us against 28.2 us for the 128 x 128 kernel, N = 768 / K = 2304 86.8 against 62.6 for the ping-pong kernel)
-  if (2 * ntiles < 3 * ncu || 5L * ntiles < 4L * rounds * ncu) return MT_ERR_UNSUPPORTED;
+  static const char* force = getenv("MT_GEMM_FORCE");      // experiments (tools/gemm_candidates.py): "ps" lifts the fill rule, anything else declines
+  if (force && force[0] && strcmp(force, "ps") != 0) return MT_ERR_UNSUPPORTED;
+  // (the fill bound: 75 % -- tools/gemm_candidates.py, round 6: at 76-77 % fill this kernel still leads the others, M = 8 194 / N = 2304:
+  // 37.7 us against 46.8 (ping-pong) and 43.5 (128 x 128); M = 6 147 / N = 3072: 38.5 against 47.6 / 42.7; at 67 % it trails, M = 8 194 / N = 3072)
+  if (!(force && force[0]) && (2 * ntiles < 3 * ncu || 4L * ntiles < 3L * rounds * ncu)) return MT_ERR_UNSUPPORTED;
   if (ldc != N && epilogue != MT_EPI_QKV_HM) return MT_ERR_UNSUPPORTED;      // (the store descriptor spans M * N contiguous halves)
   // K = 3072 (fc2, dX of fc1): the A operand is 184 MB that the previous kernel has just written; with operands from HBM the issue of
   // the LDS-DMA pieces itself backs up (stamps: the slice body 1000 -> 1560 cycles, the vmcnt wait unchanged) and a wave that is alone on
   // its SIMD has nobody to run MFMAs meanwhile.  tools/gemm_cold_bench.py: 175 vs 161 us cold, 124 vs 133 warm; in the step: 3.82 vs 3.83 ms
   // for the 24 launches.  A five-slot ring (DMA four slices ahead, all 160 KB of LDS) changed neither.  Left to the ping-pong kernel.
-  if (K > 2304) return MT_ERR_UNSUPPORTED;
+  if (K > 2304 && !(force && force[0])) return MT_ERR_UNSUPPORTED;
   int grid = min(ncu, ntiles);
   grid = max(8, grid / 8 * 8);
   // 32-bit byte offsets: the A descriptor's extent and the per-lane A offsets are formed from lda (a strided A -- lda > K, e.g. a column
