@@ -12,6 +12,9 @@ MT_SPLIT_PASSES=0 python bench.py --patches 4096 --kernel-times --no-legs --no-c
 python bench.py --patches 4096 --no-legs --no-cpu-baseline > $out/bench_L4096.json 2>/dev/null
 python bench.py --pathways real --no-legs --no-cpu-baseline > $out/bench_real_pathways.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-legs --eager > $out/bench_eager.json 2>/dev/null
+# the data-parallel step on a ONE-rank RCCL communicator (every collective issued; three schedules captured and timed): toy and real pathways
+python bench.py --dp-rehearsal --no-cpu-baseline > $out/bench_dp_rehearsal_rccl.json 2>/dev/null
+python bench.py --dp-rehearsal --pathways real --no-cpu-baseline > $out/bench_dp_rehearsal_rccl_real_pathways.json 2>/dev/null
 # kernel stats on the BATCHED schedule (every kernel alone on the chip: what `roofline` / `roofline_kernels` are taken on) ...
 export MT_SPLIT_PASSES=0
 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-legs > $out/stats.log 2>&1
@@ -30,6 +33,8 @@ find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 # the reference trainer's own loop on the drop-in nn.Module (3 model calls, torch loss / GradScaler / AdamW)
 python bench.py --api module --optim fused > $out/bench_module.json 2>/dev/null
 python bench.py --api module --optim torch > $out/bench_module_torch_adamw.json 2>/dev/null
+MT_MODULE_GRAPH=0 python bench.py --api module --optim fused --no-cpu-baseline > $out/bench_module_eager_bridge.json 2>/dev/null
+MT_MODULE_GRAPH=0 python bench.py --api module --optim torch --no-cpu-baseline > $out/bench_module_torch_adamw_eager_bridge.json 2>/dev/null
 python tools/diag/module_phases.py 10000 fused host > $out/module_phases_host.txt 2>/dev/null
 python tools/diag/module_phases.py > $out/module_phases.txt 2>/dev/null
 # BASELINE config 4 (TITAN configuration, mixed bag lengths): bench line + rocprofv3 kernel-trace stats of the same command
