@@ -60,6 +60,7 @@ class ModuleReplay:
         self.lease = None                 # weakref to the _Lease of the replayed forward whose backward is still to come
         self.res = None                   # streams / gradient sets / tapes of the two pass groups
         self.replays = self.captures = self.eager_fallbacks = self.primed = 0
+        self.ncap = {}                    # captures per geometry: one that had to be captured AGAIN was evicted in between -> the cache grows
 
     # ---------------------------------------------------------------- resources
     def _busy(self) -> bool:
@@ -159,6 +160,9 @@ class ModuleReplay:
             self.primed += 1
         else:
             if ent.gf is None:
+                self.ncap[key] = self.ncap.get(key, 0) + 1
+                if self.ncap[key] >= 2 and self.cache_size < 16 and len(self.cache) >= self.cache_size:
+                    self.cache_size *= 2      # more recurring geometries than entries (a rotation would recapture on every visit)
                 self._capture(ent, L, B, groups, slots, split)
                 if self.gen != eng.generation:    # the capture itself moved a buffer: these graphs are stale -- prime and capture again
                     ent.gf = ent.gb = None

@@ -757,6 +757,40 @@ def test_module_graph_replays_draw_fresh_dropout_masks(golden_dir):
     assert torch.equal(a, b)
 
 
+def test_module_replay_cache_grows_when_more_geometries_recur_than_it_holds():
+    """Three bag lengths in rotation through a replay cache of two: the first geometry that has to be captured a SECOND time (it was
+    evicted in between) doubles the cache, so a rotation does not recapture on every visit (tools/diag/module_replay_soak.py is the long
+    form: 7 lengths, reserved memory flat)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    sizes = synth.toy_group_sizes()
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3, init_seed=0,
+                              **dict(GIGAPATH_JSON, depth=3, slide_ngrids=32, interaction_indexes=[[0, 0], [1, 1], [2, 2]], pretrained=False,
+                                     dropout=0.0, drop_path_rate=0.0))
+    rp = model._replay
+    rp.cache_size = 2
+    eye = torch.eye(3).cuda()
+    slides = {}
+    for L in (120, 190, 260):
+        inp = synth.synth_inputs(L, sizes, L, grid=32)
+        slides[L] = (torch.from_numpy(inp["x"]).cuda(), torch.from_numpy(inp["coords"]).cuda(), {i: torch.from_numpy(a).cuda() for i, a in enumerate(inp["genes"])})
+    model.train()
+    caps = []
+    for r in range(10):
+        for L, (x, c, g) in slides.items():
+            xs = x.clone()
+            ys = torch.cat([model(x=xs, coords=c, genes=g, clinical=[], task_token=eye[t]) for t in (0, 1, 2)])
+            ys.square().sum().backward()
+            assert torch.isfinite(ys).all()
+            for p in model.parameters():
+                p.grad = None
+        caps.append(rp.captures)
+    assert rp.cache_size == 4 and caps[-1] == caps[-3] and caps[-1] <= 6, (rp.cache_size, caps)      # the rotation settled into replays
+    assert rp.replays >= 3 * 4
+
+
 def test_graph_replay_matches_eager(golden_dir):
     """hipGraph replay of the whole train step reproduces the eager step (same kernels, same order; the fp32-atomic
     weight-gradient reductions make two runs agree to rounding, not bitwise, and AdamW's normalised update amplifies
