@@ -261,6 +261,7 @@ def _check_ddp(results):
     for r in (r0, r1):
         assert np.abs(r["avg"] - mean).max() < 2e-3 * scale        # DDP averaged exactly what the flat all-reduce path sums
         assert np.abs(r["avg2"] - mean).max() < 2e-3 * scale       # and a second iteration reduces again
+        assert int(r["replays"]) >= 2 and np.abs(r["avg3"] - mean).max() < 2e-3 * scale      # ... and so do the bridge's graph replays
     assert np.array_equal(r0["avg"], r1["avg"])
     assert np.abs(r0["local"] - r1["local"]).max() > 1e-3 * scale  # (the ranks saw different slides)
 
