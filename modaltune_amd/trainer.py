@@ -98,6 +98,8 @@ class TrainStep:
         B = int(self.onehots.shape[0])
         self.split_passes = bool(split_passes) and B >= 2 and os.environ.get("MT_SPLIT_PASSES", "1") not in ("0", "off")
         self._groups = [(0, B - B // 3 if B >= 3 else 1), (B - B // 3 if B >= 3 else 1, B)] if B >= 2 else [(0, B)]
+        if os.environ.get("MT_PASS_GROUPS") == "singles" and B >= 3:      # experiments: every task pass a group of its own (B streams)
+            self._groups = [(i, i + 1) for i in range(B)]
         # workspace slot per group: the engine keys its workspace storage on the pass count, so groups of EQUAL size (B = 2: one pass
         # each) must not share it -- they run concurrently on two streams
         self._group_slots = [sum(1 for (a2, b2) in self._groups[:gi] if b2 - a2 == b - a) for gi, (a, b) in enumerate(self._groups)]
