@@ -8,8 +8,9 @@ host's pace; a replay does not (bench.py `module_api`).
 A bag geometry (patch count, pass count, gene count) that has been seen `capture_after` times with gradients enabled is run twice more
 through this class WITHOUT capture (same launches on the long-lived workspaces and tapes: the tapes size their zero-initialised gradient
 arenas from those two visits, as TrainStep's eager visits do) and captured on the next visit; other geometries, chained calls (a slide's later calls that were not part of the batched pass) and every no-grad call keep the eager
-path.  The captured pair works on the engine's long-lived workspaces (like trainer.TrainStep), so only ONE replayed forward may be
-waiting for its backward at a time: a second forward before that backward runs eagerly on a private workspace.  Dropout / DropPath:
+path.  The captured pair works on long-lived workspaces of its own (the engine's slots 8 ..: a TrainStep, an EmbeddingExtractor or a no-grad
+forward on the same engine use slots 0 ..), so only ONE replayed forward may be waiting for its backward at a time: a second forward before
+that backward runs eagerly on a private workspace.  Dropout / DropPath:
 the forward graph advances the engine's device-side Philox state first, so every replay draws fresh masks (the backward graph
 regenerates them from the same state).
 """
@@ -85,8 +86,11 @@ class ModuleReplay:
     def _groups(B: int):
         return [(0, B - B // 3), (B - B // 3, B)]
 
+    SLOT0 = 8         # workspace slots of this class: its own, so that a TrainStep / EmbeddingExtractor / no-grad forward on the same engine
+                      # (slots 0 ..) between a replayed forward and its backward cannot overwrite the saved activations
+
     def _slots(self, groups):
-        return [sum(1 for (a2, b2) in groups[:gi] if b2 - a2 == b - a) for gi, (a, b) in enumerate(groups)]
+        return [self.SLOT0 + sum(1 for (a2, b2) in groups[:gi] if b2 - a2 == b - a) for gi, (a, b) in enumerate(groups)]
 
     # ---------------------------------------------------------------- forward
     def forward(self, x, coords, genes, onehots, clinical, token) -> Optional[tuple]:
@@ -127,10 +131,10 @@ class ModuleReplay:
             self.sclin = torch.empty(1, int(clinical.numel()), dtype=F32, device=dev) if clinical is not None else None
             self.cache.clear()
         groups = self._groups(B) if split else [(0, B)]
-        slots = self._slots(groups) if split else [0]
+        slots = self._slots(groups)
         for (a, b), sl in list(zip(groups, slots))[1:]:
             eng._workspace(b - a, L, slot=sl)                       # (all workspaces exist -- and have grown -- before anything is captured)
-        eng.stage_inputs(x2, coords, B=groups[0][1] - groups[0][0])  # (may grow the workspace: bumps eng.generation)
+        eng.stage_inputs(x2, coords, eng._workspace(groups[0][1] - groups[0][0], L, slot=slots[0]))      # (may grow the workspace: bumps eng.generation)
         self.sgenes.copy_(torch.cat([g.reshape(-1) for g in gl]).to(F32) if len(gl) > 1 else gl[0].reshape(-1), non_blocking=True)
         self.sonehots.copy_(onehots, non_blocking=True)
         if self.sclin is not None:
@@ -183,10 +187,10 @@ class ModuleReplay:
             ops.rng_advance(eng.rng)
         if not split:
             logits = eng.forward(None, None, self.sgenes, self.sonehots, need_grad=True, staged=True, geometry=(B, L), clinical=self.sclin,
-                                 tape=res["tapes"][0], site_group=1, ws_slot=0)
+                                 tape=res["tapes"][0], site_group=1, ws_slot=slots[0])
             ent.logits.copy_(logits)
             return [eng.last_call]
-        ws0 = eng._workspace(groups[0][1] - groups[0][0], L)
+        ws0 = eng._workspace(groups[0][1] - groups[0][0], L, slot=slots[0])
         eng._embed_patches(None, None, ws0, True, L)            # task-independent: once, in front of the fork
         share = {"x0": ws0["x0"]}
         main = torch.cuda.current_stream()

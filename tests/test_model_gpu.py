@@ -701,10 +701,21 @@ def test_module_steady_state_runs_as_graph_replays(golden_dir, split):
         assert float((gr - g_ref).norm() / g_ref.norm()) < 2e-3, (i, float((gr - g_ref).norm() / g_ref.norm()))
     assert seen == [(0, 0, 0), (0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)], seen
     assert (model._split is not None) == split
+    # a no-grad forward of another slide between a replayed forward and its backward (a validation batch inside the step): it runs on
+    # the engine's slot-0 workspaces, the replayed pair on its own slots -- the saved activations survive
+    n0 = rp.replays
+    ys = fwd()
+    with torch.no_grad():
+        xo = torch.roll(x, 7, 0).clone()
+        [model(x=xo, coords=coords, genes=genes, clinical=[], task_token=eye[t].clone()) for t in (0, 1, 2)]
+    sum((y * w[t]).sum() for t, y in enumerate(ys)).backward()
+    gr = grads()
+    assert rp.replays == n0 + 1 and torch.equal(torch.cat([y.detach() for y in ys]), y_ref)
+    assert float((gr - g_ref).norm() / g_ref.norm()) < 2e-3
     # two forwards before the first backward: the second one cannot use the captured pair
     ya = fwd()
     yb = fwd()
-    assert rp.replays == 4 and rp.eager_fallbacks == 1
+    assert rp.replays == 5 and rp.eager_fallbacks == 1
     sum((y * w[t]).sum() for t, y in enumerate(yb)).backward()
     gb = grads()
     sum((y * w[t]).sum() for t, y in enumerate(ya)).backward()
@@ -715,11 +726,11 @@ def test_module_steady_state_runs_as_graph_replays(golden_dir, split):
     # pair's lease) alive until the next slide's pass has replaced it -- that slide runs on the eager bridge, the one after replays again
     del ya, yb
     fwd()
-    assert rp.replays == 5
+    assert rp.replays == 6
     y, gr = slide()
-    assert rp.replays == 5 and rp.eager_fallbacks == 2 and torch.equal(y, y_ref) and float((gr - g_ref).norm() / g_ref.norm()) < 2e-3
+    assert rp.replays == 6 and rp.eager_fallbacks == 2 and torch.equal(y, y_ref) and float((gr - g_ref).norm() / g_ref.norm()) < 2e-3
     y, gr = slide()
-    assert rp.replays == 6 and torch.equal(y, y_ref) and float((gr - g_ref).norm() / g_ref.norm()) < 2e-3
+    assert rp.replays == 7 and torch.equal(y, y_ref) and float((gr - g_ref).norm() / g_ref.norm()) < 2e-3
 
 
 def test_module_graph_replays_draw_fresh_dropout_masks(golden_dir):
