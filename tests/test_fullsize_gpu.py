@@ -24,6 +24,16 @@ def _rel(a, b):
 
 
 def test_one_longnet_layer_fwd_bwd_at_N10001_vs_oracle():
+    _layer_vs_oracle(N_FULL)
+
+
+def test_one_longnet_layer_fwd_bwd_at_the_reference_threshold_N25001_vs_oracle():
+    """The largest bag the reference's loader produces (threshold = 25 000 patches: 25 segments of 1 024, 4 + a tail of 5 792, one
+    segment for the three sparse branches): the same layer-level parity against the oracle."""
+    _layer_vs_oracle(25001)
+
+
+def _layer_vs_oracle(N_):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from modaltune_amd import ops
@@ -31,7 +41,7 @@ def test_one_longnet_layer_fwd_bwd_at_N10001_vs_oracle():
     from modaltune_amd.engine import Engine
     from oracle import modaltune_oracle as O
     torch.set_num_threads(min(32, torch.get_num_threads() or 1))
-    N, L, B, D = N_FULL, N_FULL - 1, 1, 768
+    N, L, B, D = N_, N_ - 1, 1, 768
     cfg = ModelConfig(depth=1, interaction_indexes=((0, 0),))
     sizes = synth.toy_group_sizes()
     sd_np = synth.synth_state_dict(cfg, sizes, seed=31)
