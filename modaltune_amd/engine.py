@@ -435,6 +435,9 @@ class Engine:
             x = x.reshape(-1, x.shape[-1])
             L = x.shape[0]
             B = task_onehots.shape[0]
+        if L < 1 or B < 1:
+            raise ValueError(f"empty bag: {L} patches, {B} task passes (a slide needs at least one patch embedding; the reference's "
+                             "datasets never produce an empty one, data_utils/datasets.py:213-285)")
         N, D, Fd, E, T = L + 1, cfg.embed_dim, cfg.ffn_dim, cfg.adapter_dim, self.T
         M, Mp = B * N, B * L
         ws = self._workspace(B, L, fresh=fresh, slot=ws_slot)
@@ -600,6 +603,8 @@ class Engine:
         cfg = self.cfg
         x = x.reshape(-1, x.shape[-1])
         L = x.shape[0]
+        if L < 1:
+            raise ValueError("empty bag: 0 patches (a slide needs at least one patch embedding)")
         if ws is None:
             ws = self._workspace(B, L)
         if torch.is_tensor(coords) and coords.is_cuda:

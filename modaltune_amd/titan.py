@@ -756,6 +756,8 @@ class TitanEngine(Engine):
         if getattr(self, "_grid_stage", None) is None:
             self._grid_stage = GridStage(self.device)
         x = x.reshape(-1, x.shape[-1])
+        if x.shape[0] < 1:
+            raise ValueError("empty bag: 0 tile embeddings (a slide needs at least one)")
         if self._grid_stage.ensure(x.shape[0], x.shape[1]):
             self.generation += 1            # captured graphs read the old buffers
         return self._grid_stage.run(x, coords, patch_size_lv0, self._titan_err)      # (ONE copy: host / device, any float dtype -> the static fp32 buffer)
@@ -773,6 +775,8 @@ class TitanEngine(Engine):
                                "MahmoodLab/TITAN snapshot> (its source is not part of ModalTune; parity unpinned)")
         B = int(task_onehots.shape[0])
         self._need = need_grad
+        if not staged and x is not None and x.reshape(-1, x.shape[-1]).shape[0] < 1:
+            raise ValueError("empty bag: 0 tile embeddings (a slide needs at least one)")
         if not staged and x is not None:
             x = x.to(self.device)
         if share is not None and "tok" in share:

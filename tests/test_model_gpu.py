@@ -333,6 +333,41 @@ def test_tiny_bags_against_the_oracle(L):
     assert not bad, (ref_max, bad[:10])
 
 
+def test_empty_bag_is_refused_with_a_clear_error():
+    """Zero patches: a ValueError on the host from every entry (engine, TrainStep eager / graphed, module), no kernel launched on it."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from modaltune_amd.aggregators import Aggregator
+    from modaltune_amd.engine import Engine
+    from modaltune_amd.trainer import TrainStep
+    sizes = synth.toy_group_sizes()
+    cfg = ModelConfig(depth=3, interaction_indexes=((0, 0), (1, 1), (2, 2)), slide_ngrids=32)
+    eng = Engine(cfg, sizes, "cuda")
+    eng.load_state_dict(synth.synth_state_dict(cfg, sizes, 3))
+    ts = TrainStep(eng)
+    ts.set_projector(synth.projector_state(3))
+    inp = synth.synth_inputs(8, sizes, 3, grid=32)
+    x0 = torch.zeros(0, 1536, device="cuda")
+    c0 = torch.zeros(0, 2, device="cuda")
+    genes = [torch.from_numpy(a).cuda() for a in inp["genes"]]
+    text = torch.from_numpy(inp["text"]).cuda()
+    with pytest.raises(ValueError, match="empty bag"):
+        eng.forward(x0, c0, genes, torch.eye(3, device="cuda"), need_grad=False)
+    with pytest.raises(ValueError, match="empty bag"):
+        ts.step(x0, c0, genes, text, update=False)
+    with pytest.raises(ValueError, match="empty bag"):
+        ts.step_graphed(x0, c0, genes, text)
+    groups = {i: ["g"] * n for i, n in enumerate(sizes)}
+    model = Aggregator.create("longnetvit_gene_adapter", gene_group_defination=groups, multi_task=3, init_seed=0,
+                              **dict(GIGAPATH_JSON, depth=3, slide_ngrids=32, interaction_indexes=[[0, 0], [1, 1], [2, 2]], pretrained=False))
+    with pytest.raises(ValueError, match="empty bag"):
+        model(x=x0.reshape(1, 0, 1536), coords=c0.reshape(1, 0, 2), genes={i: g for i, g in enumerate(genes)}, clinical=[],
+              task_token=torch.eye(3, device="cuda")[0])
+    # ... and the engine still works afterwards
+    x = torch.from_numpy(inp["x"]).cuda()
+    assert torch.isfinite(ts.step(x, torch.from_numpy(inp["coords"]).cuda(), genes, text, update=False)).all()
+
+
 def test_optimizer_step_matches_oracle_adamw(golden_dir):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
