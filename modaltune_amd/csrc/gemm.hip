@@ -516,14 +516,13 @@ int launch_nt_bn(const GemmNtArgs& a, hipStream_t s) {
   static const char* force = getenv("MT_GEMM_FORCE");      // experiments (tools/gemm_candidates.py)
   if (force && !strncmp(force, "pp", 2) && a.N % 256 == 0) return launch_nt<256, EPI, OutT>(a, s);
   if (force && !strcmp(force, "k128")) return launch_nt<128, EPI, OutT>(a, s);
-  const long tiles128 = (long)cdiv(a.M, 128) * (a.N / 128), tiles256 = (long)cdiv(a.M, 256) * (a.N / 256);
-  // (tools/gemm_candidates.py, round 6: a deep-K product on few columns -- N = 768, K = 2304 / 3072 -- whose 128 x 128 tiles all fit the
-  // chip at once, two workgroups per CU, is faster there than on one under-filled round of ping-pong tiles: M = 8 194: 50.5 us against
-  // 55.8, M = 10 001: 54.0 against 59.2; from M = 10 923 on -- 512 tiles -- the ping-pong kernel leads, 71.9 against 84.2 at M = 12 291)
-  const bool deep_few = a.K >= 2304 && a.N < 2304 && tiles128 <= 512;
-  if (pp_ok && a.N % 256 == 0 && a.M >= 8192 && (a.N >= 2304 || a.K >= 2304) && !deep_few) return launch_nt<256, EPI, OutT>(a, s);
-  // (... and a wide product below the M >= 8 192 gate whose 256-row tiles fill three quarters of a round: M = 4 097 / N = 3072: 28.0 us
-  // against 32.2 on 128 x 128 tiles, M = 6 147 / N = 2304: 28.2 against 33.3)
+  const long tiles256 = (long)cdiv(a.M, 256) * (a.N / 256);
+  if (pp_ok && a.N % 256 == 0 && a.M >= 8192 && (a.N >= 2304 || a.K >= 2304)) return launch_nt<256, EPI, OutT>(a, s);
+  // (N = 768 / K >= 2304 at M = 8 194 ... 10 922: alone and warm the 128 x 128 kernel leads the ping-pong kernel's 128-row tiles by 6-9 %
+  // -- tools/gemm_candidates.py -- but INSIDE the step, next to the other pass group's kernels, sending M = 10 001 there cost 0.15-0.25 ms
+  // at 10 000 patches, same box, two pairs: not done)
+  // A wide product below the M >= 8 192 gate whose 256-row tiles fill three quarters of a round: M = 4 097 / N = 3072: 28.0 us
+  // against 32.2 on 128 x 128 tiles, M = 6 147 / N = 2304: 28.2 against 33.3 (in the step at 4 096 patches: 18.33 -> 18.27 ms)
   if (pp_ok && a.N % 256 == 0 && a.M >= 4096 && a.M < 8192 && a.N >= 2304 && tiles256 <= 256 && 4 * tiles256 >= 3 * 256)
     return launch_nt<256, EPI, OutT>(a, s);
   // the small square shape (N = K = 768: attention output projection and its dX) where 256-row tiles fill their rounds: M = 18 435: 32.9 us
