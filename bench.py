@@ -964,6 +964,10 @@ def main():
         table = kernel_rooflines(summ, prof_steps, fl, L, T) if not args.ragged else []
         meas = ops.measured_mfma_peak_tflops()
         peak_meas = {"value": meas, "unit": "TFLOP/s", "vendor_peak": PEAK_F16_MFMA_TFLOPS,
+                     "pool_typical": 1760.0, "box_speed_vs_pool_typical": round(meas / 1760.0, 3),
+                     "box_note": "the same bare MFMA loop measured 1750-1783 TFLOP/s on most boxes of this pool in rounds 4-6 and 1630-1670 on its slow "
+                                 "ones, where every MFMA-bound kernel (and ms_per_step) is 6-8 % slower with identical binaries (DESIGN section 5): compare "
+                                 "lines of different boxes through roofline_frac_of_measured / step_frac_of_measured",
                      "roofline_frac_of_measured": achieved / meas, "step_frac_of_measured": fl["step"] * value / world / 1e12 / meas,
                      "how": "bare v_mfma_f32_32x32x16_f16 loop, 4 independent accumulators, pseudo-random register operands, 1024 workgroups x 4 "
                             "waves, best of 3 (mt_mfma_probe); `roofline.frac` stays priced against the 2.5 PF/s vendor figure"}
