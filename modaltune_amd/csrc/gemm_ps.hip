@@ -420,8 +420,7 @@ int mt_gemm_ps_launch(const void* A, long lda, const void* W, int M, int N, int 
   // its SIMD has nobody to run MFMAs meanwhile.  tools/gemm_cold_bench.py: 175 vs 161 us cold, 124 vs 133 warm; in the step: 3.82 vs 3.83 ms
   // for the 24 launches.  A five-slot ring (DMA four slices ahead, all 160 KB of LDS) changed neither.  Left to the ping-pong kernel.
   if (K > 2304 && !(force && force[0])) return MT_ERR_UNSUPPORTED;
-  static const int reserve = getenv("MT_PS_RESERVE") ? atoi(getenv("MT_PS_RESERVE")) : 0;      // experiments: CUs left to other streams' kernels
-  int grid = min(ncu - reserve, ntiles);
+  int grid = min(ncu, ntiles);
   grid = max(8, grid / 8 * 8);
   // 32-bit byte offsets: the A descriptor's extent and the per-lane A offsets are formed from lda (a strided A -- lda > K, e.g. a column
   // slice of a wider buffer -- must not wrap them either)
