@@ -231,12 +231,15 @@ class LongNetGeneAdapter(Aggregator):
         self._init_nosync()
         self.train(True)
 
-    def _split_state(self):
-        """Streams and gradient sets of the two pass groups a long batched pass runs as (created on first use)."""
+    def _split_state(self, n: int = 2):
+        """Streams and gradient sets of the pass groups a long batched pass runs as (created on first use; n > 2: experiments)."""
         if getattr(self, "_split", None) is None:
             eng = self.engine
             self._split = {"streams": [torch.cuda.Stream(device=eng.device) for _ in range(2)],
                            "sets": [(eng.store.flat_grad, eng.store.grads), eng.store.new_grad_set()]}
+        while len(self._split["streams"]) < n:
+            self._split["streams"].append(torch.cuda.Stream(device=self.engine.device))
+            self._split["sets"].append(self.engine.store.new_grad_set())
         return self._split
 
     def _init_nosync(self):

@@ -72,18 +72,20 @@ class ModuleReplay:
         eng = self.module.engine
         if self.res is None:
             tapes = []
-            for _ in range(3):                         # [0]: the batched pass, [1], [2]: the two pass groups
+            for _ in range(5):                         # [0]: the batched pass, [1] ..: the pass groups
                 t = Tape(eng.device)
                 t.on_realloc = eng._bump_generation    # captured graphs point into the tapes' gradient arenas
                 tapes.append(t)
             self.res = {"tapes": tapes}
         if split and "streams" not in self.res:
-            sp = self.module._split_state()            # the module's own two streams and gradient sets (shared with its eager split path)
+            sp = self.module._split_state(3 if os.environ.get("MT_MODULE_GROUPS") == "singles" else 2)            # the module's own two streams and gradient sets (shared with its eager split path)
             self.res.update(streams=sp["streams"], sets=sp["sets"])
         return self.res
 
     @staticmethod
     def _groups(B: int):
+        if os.environ.get("MT_MODULE_GROUPS") == "singles":       # experiments: every task pass a group of its own (balanced: they meet at the loss)
+            return [(i, i + 1) for i in range(B)]
         return [(0, B - B // 3), (B - B // 3, B)]
 
     SLOT0 = 8         # workspace slots of this class: its own, so that a TrainStep / EmbeddingExtractor / no-grad forward on the same engine
